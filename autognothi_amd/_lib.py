@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI declared in ``include/autognothi_hip.h``.
+
+The product path has no CPU or eager-PyTorch fallback: if ``lib/libautognothi_hip.so`` is
+missing, or a compute op is called with non-GPU tensors, this raises.  Build the library with
+``python -c "import __graft_entry__ as g; g.build()"`` (or ``autognothi_amd/csrc/build.sh``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libautognothi_hip.so")
+
+AG_OK = 0
+AG_F32, AG_BF16 = 0, 1
+AG_MASK_VIT_MUL, AG_MASK_BERT_ADD = 0, 1
+AG_EPI_BIAS, AG_EPI_BIAS_GELU, AG_EPI_BIAS_RESID, AG_EPI_BIAS_F32, AG_EPI_BIAS_TANH = 0, 1, 2, 3, 4
+AG_MT_STATE_BYTES = 2560
+
+vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
+
+
+class ag_layer_weights(C.Structure):
+    _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
+                                  "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class ag_encoder_desc(C.Structure):
+    _fields_ = [("kind", i32), ("dtype", i32), ("T", i32), ("H", i32), ("I", i32), ("heads", i32),
+                ("ln_eps", f32), ("n_layers", i32), ("layers", C.POINTER(ag_layer_weights))]
+
+
+# name -> (restype, argtypes); mirrors include/autognothi_hip.h one to one
+SIGNATURES = {
+    "ag_abi_version": (i32, []),
+    "ag_last_error": (C.c_char_p, []),
+    "ag_device_info": (i32, [i32, C.POINTER(i32), C.c_char_p, sz]),
+    "ag_mt19937_seed": (i32, [vp, u32, vp]),
+    "ag_mt19937_import": (i32, [vp, vp, i32, vp]),
+    "ag_mt19937_export": (i32, [vp, vp, C.POINTER(i32), vp]),
+    "ag_mt19937_raw": (i32, [vp, vp, i64, vp]),
+    "ag_mask_shapley_new": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
+    "ag_mask_purely_uniform": (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    "ag_pack_mask": (i32, [vp, i32, i32, vp, vp]),
+    "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "ag_layernorm": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
+    "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "ag_vit_assemble": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ag_bert_embed": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, f32, vp, vp, i32, vp]),
+    "ag_softmax_rows": (i32, [vp, vp, i32, i32, vp]),
+    "ag_shapley_normalize": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "ag_shapley_normalize_bwd": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "ag_shapley_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),
+    "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} is not built; there is no CPU fallback. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library drift
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != AG_OK:
+        msg = lib().ag_last_error()
+        raise RuntimeError(f"autognothi_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "autognothi_amd: this op only runs on an MI355X (ROCm) device tensor; got a "
+                f"{t.device} tensor. There is deliberately no CPU fallback.")
+
+
+def ptr(t) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,281 @@
+// attention.hip — fused masked multi-head attention for the K-mask surrogate forward.
+//
+// Replaces reference models/vanilla_vit.py:436-465 (scores * mask, i.e. a masked KEY keeps logit 0
+// and still receives soft-max weight) and models/vanilla_bert.py:503-537 (scores + (1-mask)*f32min,
+// i.e. a masked key gets exactly zero weight).  The reference materialises the [R,heads,T,T] score
+// tensor four times per layer; here scores never leave registers.
+//
+// bf16 path (throughput mode), one workgroup per (row, head), one wave per 32-query block:
+//   * K and V head slices ([T,64] bf16, 128-byte rows) are staged once into LDS (16-B chunks,
+//     XOR-swizzled so both the row reads and the transposed reads are bank-conflict free).
+//   * S^T = K·Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane owns one query column,
+//     so the soft-max row reductions are in-register plus one cross-half shuffle.
+//   * mask bits (one uint32 per 32-key block, bit = key) are applied BEFORE the running max:
+//     ViT  s = bit ? s : 0 ;  BERT s = bit ? s : -inf ;  padded keys (>= T) always -inf.
+//   * the S^T accumulator tile, converted to bf16, is directly the B operand of the PV product
+//     O^T += V^T·P^T (no LDS round trip); V^T fragments come from the row-major V image through
+//     ds_read_b64_tr_b16.
+// fp32 path (AG_F32 parity mode): plain VALU kernel, one query per thread, K/V tiles broadcast from LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;        // head dim (all shipped configs: 192/3, 768/12, 1024/16)
+constexpr int ROWB = 128;     // bytes per K/V row in bf16
+constexpr float NEG_BIG = -3.0e38f;
+
+// 16-B chunk slot swizzle: bijective on 8 consecutive same-parity rows (row reads) and sends rows
+// r, r+2 to different 64-B halves (transposed reads) — see DESIGN.md "attention LDS image".
+__device__ __forceinline__ int swz(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1);
+}
+
+struct AttnArgs {
+    const char* qkv;  // [R_src, T, 3H]
+    const uint32_t* mask;  // [R, Tw]
+    char* ctx;        // [R, T, H]
+    int R, T, H, heads, share, mode, Tw, Tp, nq;
+};
+
+__global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsV = smem + p.Tp * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int src = row / p.share;
+    const long rowstride = (long)3 * p.H * 2;  // bytes per token in qkv
+    const char* qbase = p.qkv + (long)src * p.T * rowstride + (long)head * HD * 2;
+    const char* kbase = qbase + (long)p.H * 2;
+    const char* vbase = qbase + (long)2 * p.H * 2;
+
+    // ---- stage K, V (zero-fill padded keys so 0-weight x garbage can never make a NaN) ----
+    for (int c = tid; c < p.Tp * 8; c += blockDim.x) {
+        const int r = c >> 3, ch = c & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (r < p.T) {
+            kv = *reinterpret_cast<const uint4*>(kbase + (long)r * rowstride + ch * 16);
+            vv = *reinterpret_cast<const uint4*>(vbase + (long)r * rowstride + ch * 16);
+        }
+        const int off = r * ROWB + ((ch ^ swz(r)) << 4);
+        *reinterpret_cast<uint4*>(ldsK + off) = kv;
+        *reinterpret_cast<uint4*>(ldsV + off) = vv;
+    }
+    __syncthreads();
+
+    const int nkb = p.Tp >> 5;           // 32-key blocks
+    const int nqb = (p.nq + 31) >> 5;    // 32-query blocks
+    const int lr = lane & 31, lh = lane >> 5;
+    const uint32_t* mrow = p.mask + (long)row * p.Tw;
+    const float scale = 0.125f;          // 1/sqrt(64), exact
+
+    for (int qb = wave; qb < nqb; qb += nwaves) {
+        int q = qb * 32 + lr;
+        const bool qvalid = q < p.nq;
+        const int qc = qvalid ? q : p.T - 1;
+        // Q fragments (B operand): lane holds Q[q][16ks + 8lh .. +8]
+        uint4 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const uint4*>(qbase + (long)qc * rowstride + (2 * ks + lh) * 16);
+
+        f32x16_t o0, o1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+        float m_run = NEG_BIG, l_run = 0.f;
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16_t s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            const int krow = kb * 32 + lr;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(ldsK + krow * ROWB + (((2 * ks + lh) ^ swz(krow)) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                            __builtin_bit_cast(bf16x8_t, qf[ks]), s, 0, 0, 0);
+            }
+            // lane holds keys kb*32 + (i&3) + 8*(i>>2) + 4*lh for query lr
+            const uint32_t mw = mrow[kb];
+            const int kvalid = p.T - kb * 32;  // keys [0,kvalid) of this block exist
+            float bmax = NEG_BIG;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                const bool on = (mw >> kk) & 1u;
+                float v = s[i] * scale;
+                if (p.mode == AG_MASK_VIT_MUL) v = on ? v : 0.f; else v = on ? v : NEG_BIG;
+                v = kk < kvalid ? v : NEG_BIG;
+                s[i] = v;
+                bmax = fmaxf(bmax, v);
+            }
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const float m_new = fmaxf(m_run, bmax);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = s[i] > -1.0e38f ? __expf(s[i] - m_new) : 0.f;
+                s[i] = pv;
+                psum += pv;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+            // P^T fragments: regs 8s..8s+7 -> k-step s; element j <-> key 16s + 8(j>>2) + 4lh + (j&3)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 pf;
+                pf.x = pack_bf16x2(s[8 * st + 0], s[8 * st + 1]);
+                pf.y = pack_bf16x2(s[8 * st + 2], s[8 * st + 3]);
+                pf.z = pack_bf16x2(s[8 * st + 4], s[8 * st + 5]);
+                pf.w = pack_bf16x2(s[8 * st + 6], s[8 * st + 7]);
+                // V^T fragments via transposed reads: 16-lane group g: d cols 16(g&1)+i, half h=g>>1
+                const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int k0 = kb * 32 + 16 * st + 4 * (g >> 1) + tq;   // row for first read
+                    const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
+                    const int a0 = k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
+                    const int k1 = k0 + 8;
+                    const int a1 = k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
+                    typedef __attribute__((ext_vector_type(4))) short s16x4;
+                    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + a0));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + a1));
+                    const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
+                    else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o1, 0, 0, 0);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (qvalid) {
+            char* out = p.ctx + ((long)row * p.T + q) * p.H * 2 + (long)head * HD * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 8 * g4 + 4 * lh;  // within a 32-wide d tile
+                *reinterpret_cast<uint2*>(out + d * 2) =
+                    make_uint2(pack_bf16x2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv), pack_bf16x2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv));
+                *reinterpret_cast<uint2*>(out + (32 + d) * 2) =
+                    make_uint2(pack_bf16x2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv), pack_bf16x2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv));
+            }
+        }
+    }
+}
+
+// ---- fp32 parity-mode kernel: one query per thread, 64-key K/V tiles broadcast from LDS ----------
+constexpr int FKT = 64;
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float sK[FKT * HD];
+    __shared__ __attribute__((aligned(16))) float sV[FKT * HD];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int src = row / p.share;
+    const long ts = (long)3 * p.H;  // floats per token
+    const float* base = reinterpret_cast<const float*>(p.qkv) + (long)src * p.T * ts + (long)head * HD;
+    const uint32_t* mrow = p.mask + (long)row * p.Tw;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)HD);
+
+    for (int q0 = 0; q0 < p.nq; q0 += blockDim.x) {
+        const int q = q0 + tid;
+        const bool qvalid = q < p.nq;
+        float qv[HD], o[HD];
+        const float* qp = base + (long)(qvalid ? q : 0) * ts;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + d);
+            qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
+            o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+        }
+        float m_run = NEG_BIG, l_run = 0.f;
+        for (int k0 = 0; k0 < p.T; k0 += FKT) {
+            __syncthreads();
+            for (int c = tid; c < FKT * (HD / 4); c += blockDim.x) {
+                const int r = c / (HD / 4), ch = c % (HD / 4);
+                float4 kv = make_float4(0, 0, 0, 0), vv = kv;
+                if (k0 + r < p.T) {
+                    kv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * ts + p.H + ch * 4);
+                    vv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * ts + 2 * p.H + ch * 4);
+                }
+                *reinterpret_cast<float4*>(sK + r * HD + ch * 4) = kv;
+                *reinterpret_cast<float4*>(sV + r * HD + ch * 4) = vv;
+            }
+            __syncthreads();
+            const int kn = min(FKT, p.T - k0);
+            for (int kk = 0; kk < kn; ++kk) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(sK + kk * HD + d);
+                    s = fmaf(qv[d], t.x, s); s = fmaf(qv[d + 1], t.y, s); s = fmaf(qv[d + 2], t.z, s); s = fmaf(qv[d + 3], t.w, s);
+                }
+                s = s * inv_sqrt_d;
+                const int key = k0 + kk;
+                const bool on = (mrow[key >> 5] >> (key & 31)) & 1u;
+                if (p.mode == AG_MASK_VIT_MUL) s = on ? s : 0.f;
+                else if (!on) continue;  // exactly zero weight
+                const float m_new = fmaxf(m_run, s);
+                const float alpha = expf(m_run - m_new);
+                const float pv = expf(s - m_new);
+                l_run = l_run * alpha + pv;
+                m_run = m_new;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(sV + kk * HD + d);
+                    o[d] = fmaf(pv, t.x, o[d] * alpha); o[d + 1] = fmaf(pv, t.y, o[d + 1] * alpha);
+                    o[d + 2] = fmaf(pv, t.z, o[d + 2] * alpha); o[d + 3] = fmaf(pv, t.w, o[d + 3] * alpha);
+                }
+            }
+        }
+        if (qvalid) {
+            const float inv = 1.0f / l_run;
+            float* out = reinterpret_cast<float*>(p.ctx) + ((long)row * p.T + q) * p.H + (long)head * HD;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4)
+                *reinterpret_cast<float4*>(out + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
+                                   int heads, int qkv_share, int mask_mode, int n_query, int dtype, void* stream) {
+    AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention: null pointer");
+    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H == heads * HD, "ag_masked_attention: head_dim must be %d (H=%d heads=%d)", HD, H, heads);
+    AG_REQUIRE(qkv_share >= 1 && R % qkv_share == 0, "ag_masked_attention: R=%d not a multiple of share=%d", R, qkv_share);
+    AG_REQUIRE(mask_mode == AG_MASK_VIT_MUL || mask_mode == AG_MASK_BERT_ADD, "ag_masked_attention: bad mask mode %d", mask_mode);
+    if (R == 0) return AG_OK;
+    AttnArgs a;
+    a.qkv = (const char*)d_qkv; a.mask = d_mask_bits; a.ctx = (char*)d_ctx;
+    a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = qkv_share; a.mode = mask_mode;
+    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32;
+    a.nq = (n_query > 0 && n_query < T) ? n_query : T;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == AG_BF16) {
+        const size_t lds = (size_t)2 * a.Tp * ROWB;
+        AG_REQUIRE(lds <= 160 * 1024, "ag_masked_attention: T=%d too long for the single-pass LDS image", T);
+        const int nqb = (a.nq + 31) / 32;
+        int nwaves = nqb < 8 ? nqb : 8;
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(attn_bf16_kernel, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
+    } else if (dtype == AG_F32) {
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(R * heads), dim3(256), 0, s, a);
+    } else {
+        return ag_fail(AG_ERR_INVALID, "ag_masked_attention: bad dtype %d", dtype);
+    }
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}

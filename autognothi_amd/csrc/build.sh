@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build the C-ABI shared library for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+OBJS=()
+for src in gemm.hip attention.hip sampler.hip elementwise.hip shapley.hip encoder.cpp capi.cpp; do
+  obj="$OUT/${src%.*}.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ ../../include/autognothi_hip.h -nt "$obj" ]; then
+    echo "hipcc $src"
+    $HIPCC $FLAGS -x hip -c "$src" -o "$obj" &
+  fi
+  OBJS+=("$obj")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libautognothi_hip.so" "${OBJS[@]}"
+echo "built $OUT/libautognothi_hip.so"

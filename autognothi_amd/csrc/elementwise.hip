@@ -1,0 +1,255 @@
+// elementwise.hip — the HBM-bound pieces of the masked forward: LayerNorm, embeddings, soft-max
+// heads, dtype casts.  One wave per row, 16-byte accesses, fp32 statistics.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        Store<T>::store(dst + i, v.x); Store<T>::store(dst + i + 1, v.y);
+        Store<T>::store(dst + i + 2, v.z); Store<T>::store(dst + i + 3, v.w);
+    }
+    if (i < n) for (int64_t j = i; j < n && j < i + 4; ++j) Store<T>::store(dst + j, src[j]);
+}
+
+// torch.nn.LayerNorm: biased variance, y = (x-mean)*rsqrt(var+eps)*g + b.  One wave per row; the row
+// is held in registers (H <= 64*4*MAXV floats) so x is read from HBM exactly once.
+constexpr int LN_MAXV = 8;  // supports H up to 2048
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int rows, int H,
+                                                        const float* __restrict__ g, const float* __restrict__ b,
+                                                        float eps, T* __restrict__ ys, float* __restrict__ yf) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float4 v[LN_MAXV];
+    float sum = 0.f;
+    const int nv = H >> 2;  // float4 per row
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + c * 4);
+            const float4 bv = *reinterpret_cast<const float4*>(b + c * 4);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gv.x + bv.x; o.y = (v[i].y - mean) * rstd * gv.y + bv.y;
+            o.z = (v[i].z - mean) * rstd * gv.z + bv.z; o.w = (v[i].w - mean) * rstd * gv.w + bv.w;
+            if (yf) *reinterpret_cast<float4*>(yf + (int64_t)row * H + c * 4) = o;
+            if (ys) {
+                T* yp = ys + (int64_t)row * H + c * 4;
+                if (sizeof(T) == 2) {
+                    *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+                } else {
+                    *reinterpret_cast<float4*>(yp) = o;
+                }
+            }
+        }
+    }
+}
+
+// im2col for Conv2d(k = s = patch): cols[(b*gh + py)*gw + px][c*patch*patch + iy*patch + ix]
+template <typename T>
+__global__ void im2col_kernel(const float* __restrict__ img, int B, int C, int px, int patch, T* __restrict__ cols) {
+    const int g = px / patch;
+    const int kdim = C * patch * patch;
+    const int64_t total = (int64_t)B * g * g * kdim / 4;  // 4 consecutive ix per thread (patch % 4 == 0)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const int k = (int)(e % kdim);
+        const int64_t prow = e / kdim;
+        const int pxi = (int)(prow % g), pyi = (int)((prow / g) % g), bi = (int)(prow / ((int64_t)g * g));
+        const int ix = k % patch, iy = (k / patch) % patch, c = k / (patch * patch);
+        const float4 v = *reinterpret_cast<const float4*>(img + (((int64_t)bi * C + c) * px + (pyi * patch + iy)) * px + pxi * patch + ix);
+        T* o = cols + e;
+        Store<T>::store(o, v.x); Store<T>::store(o + 1, v.y); Store<T>::store(o + 2, v.z); Store<T>::store(o + 3, v.w);
+    }
+}
+
+__global__ void vit_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls, const float* __restrict__ pos,
+                                    int B, int P, int H, float* __restrict__ h0) {
+    const int T = P + 1;
+    const int64_t total = (int64_t)B * T * H / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const int hcol = (int)(e % H);
+        const int64_t tok = e / H;
+        const int t = (int)(tok % T), b = (int)(tok / T);
+        const float4 pv = *reinterpret_cast<const float4*>(pos + (int64_t)t * H + hcol);
+        float4 v;
+        if (t == 0) v = *reinterpret_cast<const float4*>(cls + hcol);
+        else v = *reinterpret_cast<const float4*>(pe + ((int64_t)b * P + (t - 1)) * H + hcol);
+        v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+        *reinterpret_cast<float4*>(h0 + e) = v;
+    }
+}
+
+// BERT embeddings: one wave per token: gather word row + type[0] + pos[t], LayerNorm in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restrict__ ids, int B, int Tn, int H,
+                                                         const float* __restrict__ word, int vocab,
+                                                         const float* __restrict__ type0, const float* __restrict__ pos,
+                                                         const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                         float* __restrict__ h0, T* __restrict__ hs) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tok >= B * Tn) return;
+    const int t = tok % Tn;
+    int64_t id = ids[tok];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* wr = word + id * H;
+    float4 v[LN_MAXV];
+    float sum = 0.f;
+    const int nv = H >> 2;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 a = *reinterpret_cast<const float4*>(wr + c * 4);
+            const float4 ty = *reinterpret_cast<const float4*>(type0 + c * 4);
+            const float4 po = *reinterpret_cast<const float4*>(pos + (int64_t)t * H + c * 4);
+            // reference order: (word + type) then += pos  (models/vanilla_bert.py:319-322)
+            v[i].x = (a.x + ty.x) + po.x; v[i].y = (a.y + ty.y) + po.y; v[i].z = (a.z + ty.z) + po.z; v[i].w = (a.w + ty.w) + po.w;
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + c * 4);
+            const float4 bv = *reinterpret_cast<const float4*>(b + c * 4);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gv.x + bv.x; o.y = (v[i].y - mean) * rstd * gv.y + bv.y;
+            o.z = (v[i].z - mean) * rstd * gv.z + bv.z; o.w = (v[i].w - mean) * rstd * gv.w + bv.w;
+            *reinterpret_cast<float4*>(h0 + (int64_t)tok * H + c * 4) = o;
+            if (hs) {
+                T* yp = hs + (int64_t)tok * H + c * 4;
+                if (sizeof(T) == 2) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+                else *reinterpret_cast<float4*>(yp) = o;
+            }
+        }
+    }
+}
+
+__global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float m = -3.0e38f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[(int64_t)row * C + c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(x[(int64_t)row * C + c] - m);
+    s = wave_sum(s);
+    for (int c = lane; c < C; c += 64) y[(int64_t)row * C + c] = expf(x[(int64_t)row * C + c] - m) / s;
+}
+
+}  // namespace
+
+extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream) {
+    AG_REQUIRE(d_src && d_dst && n >= 0, "ag_cast_f32: bad arguments");
+    if (n == 0) return AG_OK;
+    const int blocks = (int)((n / 4 + 255) / 256 < 2048 ? (n / 4 + 255) / 256 + 1 : 2048);
+    if (dtype == AG_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_src, (bf16_t*)d_dst, n);
+    else if (dtype == AG_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_src, (float*)d_dst, n);
+    else return ag_fail(AG_ERR_INVALID, "ag_cast_f32: bad dtype %d", dtype);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_layernorm(const float* d_x, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
+                            float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream) {
+    AG_REQUIRE(d_x && d_gamma && d_beta && (d_y_store || d_y_f32), "ag_layernorm: null pointer");
+    AG_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAXV && ldx % 4 == 0, "ag_layernorm: H=%d unsupported (multiple of 4, <= %d)", H, 64 * 4 * LN_MAXV);
+    if (rows == 0) return AG_OK;
+    const int blocks = ceil_div(rows, 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == AG_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
+    else if (dtype == AG_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
+    else return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_vit_im2col(const float* d_img, int B, int Cin, int px, int patch, void* d_cols, int dtype, void* stream) {
+    AG_REQUIRE(d_img && d_cols, "ag_vit_im2col: null pointer");
+    AG_REQUIRE(patch > 0 && px % patch == 0 && patch % 4 == 0 && px % 4 == 0, "ag_vit_im2col: px=%d patch=%d unsupported", px, patch);
+    if (B == 0) return AG_OK;
+    const int64_t total = (int64_t)B * px * px * Cin / 4;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == AG_BF16) hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d_img, B, Cin, px, patch, (bf16_t*)d_cols);
+    else if (dtype == AG_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, d_img, B, Cin, px, patch, (float*)d_cols);
+    else return ag_fail(AG_ERR_INVALID, "ag_vit_im2col: bad dtype %d", dtype);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_vit_assemble(const float* d_patch_emb, const float* d_cls, const float* d_pos, int B, int P, int H,
+                               float* d_h0, void* stream) {
+    AG_REQUIRE(d_patch_emb && d_cls && d_pos && d_h0 && H % 4 == 0, "ag_vit_assemble: bad arguments");
+    if (B == 0) return AG_OK;
+    const int64_t total = (int64_t)B * (P + 1) * H / 4;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_patch_emb, d_cls, d_pos, B, P, H, d_h0);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_bert_embed(const int64_t* d_ids, int B, int T, int H, const float* d_word, int vocab, const float* d_type0,
+                             const float* d_pos, const float* d_gamma, const float* d_beta, float eps,
+                             float* d_h0, void* d_h0_store, int dtype, void* stream) {
+    AG_REQUIRE(d_ids && d_word && d_type0 && d_pos && d_gamma && d_beta && d_h0, "ag_bert_embed: null pointer");
+    AG_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAXV, "ag_bert_embed: H=%d unsupported", H);
+    if (B == 0) return AG_OK;
+    const int blocks = ceil_div((int64_t)B * T, 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == AG_BF16) hipLaunchKernelGGL(bert_embed_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d_ids, B, T, H, d_word, vocab, d_type0, d_pos, d_gamma, d_beta, eps, d_h0, (bf16_t*)d_h0_store);
+    else if (dtype == AG_F32) hipLaunchKernelGGL(bert_embed_kernel<float>, dim3(blocks), dim3(256), 0, s, d_ids, B, T, H, d_word, vocab, d_type0, d_pos, d_gamma, d_beta, eps, d_h0, (float*)d_h0_store);
+    else return ag_fail(AG_ERR_INVALID, "ag_bert_embed: bad dtype %d", dtype);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_softmax_rows(const float* d_x, float* d_y, int rows, int C, void* stream) {
+    AG_REQUIRE(d_x && d_y && rows >= 0 && C >= 1, "ag_softmax_rows: bad arguments");
+    if (rows == 0) return AG_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, rows, C);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}

@@ -1,0 +1,248 @@
+// gemm.hip — C[M,N] = epilogue(A[M,K] · W[N,K]^T + bias) on gfx950 MFMA.
+//
+// Replaces every nn.Linear on the masked-forward path (reference models/vanilla_vit.py:422-424,
+// :477, :491, :510; models/vanilla_bert.py:488-490, :557, :576, :601).
+//
+// Structure (v1, "128x128x128B, two barriers per K tile"):
+//   * block = 256 threads = 4 waves (2 along M x 2 along N); block tile 128(M) x 128(N); each wave
+//     owns 64x64 = 4x4 MFMA 16x16 sub-tiles (64 accumulator VGPRs).
+//   * K is walked in 128-byte slices per row (64 bf16 / 32 fp32), so both storage dtypes use the
+//     same staging code: each tile row is 8 x 16-B chunks, staged global->LDS with
+//     global_load_lds_dwordx4 (no VGPR round trip), double-buffered.
+//   * LDS image is lane-linear (what LDS-DMA requires); the bank-conflict swizzle
+//     slot = chunk ^ (row & 7) is applied on the SOURCE address and again on the ds_read_b128.
+//   * operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so a lane ends up with
+//     4 consecutive output features of one token: bias / residual / output are 8- or 16-byte
+//     vector accesses along N.
+//   * bf16: v_mfma_f32_16x16x32_bf16 (one per 16-B fragment pair); fp32: v_mfma_f32_16x16x4_f32
+//     (four per 16-B fragment pair; exact fp32 fma chain) — the AG_F32 parity mode.
+//   * blockIdx -> tile map is XCD-aware: the 8 XCDs get contiguous tile ranges, N-tiles fastest,
+//     so the blocks that share one A row-panel run on one XCD and hit its L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per tile row
+constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand tile
+constexpr int NTHREADS = 256;
+
+struct GemmArgs {
+    const char* A; long lda_b;  // byte strides
+    const char* W; long ldw_b;
+    const float* bias;
+    char* C; long ldc;          // element stride
+    const float* R; long ldr;
+    int T, share;
+    int M, N, K;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// stage one 128-row x 128-byte operand tile; rows beyond `rows_total` are clamped (their products
+// only reach accumulators that the epilogue never stores).
+__device__ __forceinline__ void stage_tile(const char* base, long ld_b, int row0, int rows_total, long kbyte0,
+                                           char* lds_tile, int wave, int lane) {
+    const int r_in = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + r_in;
+        int grow = row0 + row;
+        grow = grow < rows_total ? grow : rows_total - 1;
+        const int chunk = slot ^ (row & 7);
+        glds16(base + (long)grow * ld_b + kbyte0 + chunk * 16, lds_tile + (wave * 32 + i * 8) * ROWB);
+    }
+}
+
+__device__ __forceinline__ uint4 lds_frag(const char* lds_tile, int row, int chunk) {
+    return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + ((chunk ^ (row & 7)) << 4));
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    // bijective XCD remap (blocks b and b+8 share an XCD under round-robin dispatch)
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    f32x4_t acc[4][4];  // [n sub-tile][m sub-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(((long)p.K * (long)sizeof(T)) / ROWB);
+    // LDS: [buf0: A tile | W tile][buf1: A tile | W tile]
+    stage_tile(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane);
+    stage_tile(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane);
+            stage_tile(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane);
+        }
+        const char* tA = smem + cur * 2 * TILE_BYTES;
+        const char* tW = tA + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fw[4], fx[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fw[s] = lds_frag(tW, wn * 64 + s * 16 + frow, kk * 4 + fq);
+                fx[s] = lds_frag(tA, wm * 64 + s * 16 + frow, kk * 4 + fq);
+            }
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn)
+#pragma unroll
+                for (int sm = 0; sm < 4; ++sm) Mma<T>::run(fw[sn], fx[sm], acc[sn][sm]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15) per sub-tile ----
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_F32 || sizeof(T) == 4);
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (EPI != AG_EPI_BIAS_RESID || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+        const int m = m0 + wm * 64 + sm * 16 + frow;
+        if (m >= p.M) continue;
+        long rrow = 0;
+        if (EPI == AG_EPI_BIAS_RESID) {
+            const int seq = m / p.T, t = m - seq * p.T;
+            rrow = (long)(seq / p.share) * p.T + t;
+        }
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+            const int n = n0 + wn * 64 + sn * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
+            if (vec_ok) {
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (EPI == AG_EPI_BIAS_RESID) {
+                    const float4 rv = *reinterpret_cast<const float4*>(p.R + rrow * p.ldr + n);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j < p.N) {
+                        if (p.bias) v[j] += p.bias[n + j];
+                        if (EPI == AG_EPI_BIAS_RESID) v[j] += p.R[rrow * p.ldr + n + j];
+                    }
+                }
+            }
+            if (EPI == AG_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
+            if (EPI == AG_EPI_BIAS_TANH) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = tanhf(v[j]);
+            }
+            if (OUT_F32) {
+                float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                if (vec_ok) {
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) cp[j] = v[j];
+                }
+            } else {
+                bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+                if (vec_ok) {
+                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) cp[j] = f32_to_bf16(v[j]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(tiles), dim3(NTHREADS), 4 * TILE_BYTES, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+template <typename T>
+int dispatch(int epi, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case AG_EPI_BIAS: return launch<T, AG_EPI_BIAS>(a, s);
+        case AG_EPI_BIAS_GELU: return launch<T, AG_EPI_BIAS_GELU>(a, s);
+        case AG_EPI_BIAS_RESID: return launch<T, AG_EPI_BIAS_RESID>(a, s);
+        case AG_EPI_BIAS_F32: return launch<T, AG_EPI_BIAS_F32>(a, s);
+        case AG_EPI_BIAS_TANH: return launch<T, AG_EPI_BIAS_TANH>(a, s);
+        default: return ag_fail(AG_ERR_INVALID, "ag_gemm: unknown epilogue %d", epi);
+    }
+}
+
+}  // namespace
+
+extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                       const float* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
+                       int epilogue, int dtype, void* stream) {
+    AG_REQUIRE(d_A && d_W && d_C, "ag_gemm: null pointer");
+    AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gemm: bad dtype %d", dtype);
+    const size_t es = dtype_size(dtype);
+    AG_REQUIRE((K * es) % ROWB == 0, "ag_gemm: K=%d must be a multiple of %d for this dtype", K, (int)(ROWB / es));
+    AG_REQUIRE((lda * es) % 16 == 0, "ag_gemm: lda=%ld rows must be 16-byte aligned", (long)lda);
+    AG_REQUIRE(epilogue != AG_EPI_BIAS_RESID || (d_R && rows_per_seq > 0 && resid_share > 0),
+               "ag_gemm: residual epilogue needs R, rows_per_seq and resid_share");
+    if (M == 0) return AG_OK;
+    GemmArgs a;
+    a.A = (const char*)d_A; a.lda_b = (long)lda * es;
+    a.W = (const char*)d_W; a.ldw_b = (long)K * es;
+    a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc;
+    a.R = d_R; a.ldr = ldr; a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
+    a.M = M; a.N = N; a.K = K;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == AG_BF16 ? dispatch<bf16_t>(epilogue, a, s) : dispatch<float>(epilogue, a, s);
+}

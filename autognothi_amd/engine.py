@@ -1,0 +1,164 @@
+"""Host-side driver of the masked forward: packs module parameters into the layout the HIP
+kernels want and strings the C-ABI calls together for the recipes' ``fw_*`` callables.
+
+Nothing here computes: tensors are allocated by torch, every op is a libautognothi_hip kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from . import ops
+
+_PRECISION = {"dtype": L.AG_BF16}
+
+
+def set_precision(name: str) -> None:
+    """'bf16' (throughput mode, BASELINE config 2) or 'fp32' (exact-fp32 MFMA; the mode in which the
+    1e-4 Shapley-value parity criterion is checked)."""
+    _PRECISION["dtype"] = {"bf16": L.AG_BF16, "fp32": L.AG_F32, "f32": L.AG_F32}[name]
+
+
+def get_precision() -> int:
+    return _PRECISION["dtype"]
+
+
+def precision_name() -> str:
+    return "bf16" if _PRECISION["dtype"] == L.AG_BF16 else "fp32"
+
+
+class _Workspace:
+    """One growing HBM scratch buffer per device (sized for 288 GB parts: never shrinks)."""
+
+    def __init__(self):
+        self.buf: Dict[str, Tensor] = {}
+
+    def get(self, device: torch.device, nbytes: int) -> Tensor:
+        key = str(device)
+        cur = self.buf.get(key)
+        if cur is None or cur.numel() < nbytes:
+            self.buf[key] = torch.empty(int(nbytes * 1.05) + 256, dtype=torch.uint8, device=device)
+        return self.buf[key]
+
+
+WORKSPACE = _Workspace()
+
+
+def _versions(params: Sequence[Tensor]) -> Tuple:
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+class PackedLinear:
+    """weight [N,K] in the storage dtype + fp32 bias, rebuilt when the parameters change."""
+
+    def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor]):
+        self.weights, self.biases = list(weights), list(biases)
+        self.key = None
+        self.w: Optional[Tensor] = None
+        self.b: Optional[Tensor] = None
+
+    def get(self, dtype: int) -> Tuple[Tensor, Tensor]:
+        key = (dtype, _versions(self.weights + self.biases))
+        if key != self.key:
+            with torch.no_grad():
+                w = torch.cat([x.detach().reshape(x.shape[0], -1) for x in self.weights], dim=0).float().contiguous()
+                self.w = ops.cast(w, dtype)
+                self.b = torch.cat([x.detach().float() for x in self.biases], dim=0).contiguous()
+            self.key = key
+        return self.w, self.b
+
+
+def _f32(p: Optional[Tensor]) -> Optional[Tensor]:
+    return None if p is None else p.detach().float().contiguous()
+
+
+class PackedEncoder:
+    """A stack of transformer layers (reference VanillaViTLayer / VanillaBertLayer modules)."""
+
+    def __init__(self, layers: Sequence[nn.Module], kind: int, T: int, H: int, I: int, heads: int, eps: float):
+        self.kind, self.T, self.H, self.I, self.heads, self.eps = kind, T, H, I, heads, eps
+        self.layers = list(layers)
+        self.lin = []
+        for ly in self.layers:
+            att = ly.attention
+            self.lin.append(dict(
+                qkv=PackedLinear([att.self.query.weight, att.self.key.weight, att.self.value.weight],
+                                 [att.self.query.bias, att.self.key.bias, att.self.value.bias]),
+                o=PackedLinear([att.output.dense.weight], [att.output.dense.bias]),
+                fc1=PackedLinear([ly.intermediate.dense.weight], [ly.intermediate.dense.bias]),
+                fc2=PackedLinear([ly.output.dense.weight], [ly.output.dense.bias]),
+            ))
+        self._keep: List = []
+
+    def _ln(self, ly: nn.Module, which: int) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+        if self.kind == L.AG_MASK_VIT_MUL:
+            mod = ly.layernorm_before if which == 1 else ly.layernorm_after
+        else:
+            mod = ly.attention.output.LayerNorm if which == 1 else ly.output.LayerNorm
+        if isinstance(mod, nn.Identity):
+            return None, None
+        return _f32(mod.weight), _f32(mod.bias)
+
+    def desc(self, dtype: int) -> L.ag_encoder_desc:
+        arr = (L.ag_layer_weights * len(self.layers))()
+        keep = []
+        for i, ly in enumerate(self.layers):
+            lw = arr[i]
+            for name, cw, cb in (("qkv", "w_qkv", "b_qkv"), ("o", "w_o", "b_o"), ("fc1", "w_fc1", "b_fc1"), ("fc2", "w_fc2", "b_fc2")):
+                w, b = self.lin[i][name].get(dtype)
+                keep += [w, b]
+                setattr(lw, cw, w.data_ptr())
+                setattr(lw, cb, b.data_ptr())
+            g1, b1 = self._ln(ly, 1)
+            g2, b2 = self._ln(ly, 2)
+            keep += [g1, b1, g2, b2]
+            lw.ln1_g, lw.ln1_b = L.ptr(g1), L.ptr(b1)
+            lw.ln2_g, lw.ln2_b = L.ptr(g2), L.ptr(b2)
+        d = L.ag_encoder_desc(self.kind, dtype, self.T, self.H, self.I, self.heads, self.eps, len(self.layers), arr)
+        self._keep = [keep, arr]
+        return d
+
+    def forward(self, h0: Tensor, rows: int, share: int, mask_bits: Tensor, cls_only_last: bool, dtype: int) -> Tensor:
+        """h0 fp32 [rows/share, T, H] -> hidden fp32 [rows, T, H]."""
+        L.require_gpu(h0, mask_bits)
+        assert h0.dtype == torch.float32 and h0.is_contiguous()
+        d = self.desc(dtype)
+        out = torch.empty((rows, self.T, self.H), dtype=torch.float32, device=h0.device)
+        with torch.cuda.device(h0.device):
+            need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
+            ws = WORKSPACE.get(h0.device, need)
+            L.check(L.lib().ag_encoder_forward(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
+                                               1 if cls_only_last else 0, L.ptr(ws), ws.numel(), L.stream()))
+        return out
+
+
+def ones_mask_bits(rows: int, n_players: int, device: torch.device) -> Tensor:
+    """Key bits of an all-ones mask [rows, P] with CLS prepended (bits beyond T are zero)."""
+    t = n_players + 1
+    tw = ops.mask_words(n_players)
+    words = []
+    for w in range(tw):
+        nbits = max(0, min(32, t - 32 * w))
+        v = (1 << nbits) - 1
+        words.append(v - (1 << 32) if v >= (1 << 31) else v)
+    return torch.tensor(words, dtype=torch.int32, device=device).repeat(rows, 1).contiguous()
+
+
+def to_mask_bits(attention_mask: Tensor, n_players: int) -> Tensor:
+    """Accept what the reference passes to ``forward`` — an int64 [R, T] mask whose first column is the
+    CLS column (recipes/*._fw_xs_preprocess) — or pre-packed int32 key bits [R, Tw]."""
+    if attention_mask.dtype == torch.int32 and attention_mask.shape[1] == ops.mask_words(n_players):
+        return attention_mask.contiguous()
+    if attention_mask.shape[1] != n_players + 1:
+        raise ValueError(f"attention_mask must be [R, {n_players + 1}] (CLS + players), got {tuple(attention_mask.shape)}")
+    # the CLS column is defined to be 1 by every caller; the packed form hard-wires it
+    return ops.pack_mask(attention_mask[:, 1:])
+
+
+def linear_head(x_rows: Tensor, lda: int, m: int, lin: PackedLinear, epilogue: int, dtype: int) -> Tensor:
+    w, b = lin.get(dtype)
+    return ops.gemm(x_rows, w, b, epilogue, dtype, m=m, lda=lda)

@@ -1,0 +1,265 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point).
+
+torch is plumbing here: it owns the HBM allocations and the HIP stream; every computation is a
+kernel of ``libautognothi_hip.so`` launched on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+F32, BF16 = L.AG_F32, L.AG_BF16
+
+
+def storage_dtype(dtype: int) -> torch.dtype:
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def mask_words(n_players: int) -> int:
+    return (n_players + 1 + 31) // 32
+
+
+# ----------------------------------------------------------------------------- RNG / samplers
+class DeviceMT19937:
+    """MT19937 state resident in HBM; bit-compatible with torch's CPU generator
+    (reference consumers: models/shapley.py:69,114,133)."""
+
+    def __init__(self, device: torch.device, seed: Optional[int] = None):
+        self.device = torch.device(device)
+        self.state = torch.zeros(L.AG_MT_STATE_BYTES // 4, dtype=torch.int32, device=self.device)
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed: int) -> "DeviceMT19937":
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ag_mt19937_seed(L.ptr(self.state), seed & 0xFFFFFFFF, L.stream()))
+        return self
+
+    def import_torch_cpu_state(self, gen: Optional[torch.Generator] = None) -> "DeviceMT19937":
+        """Continue torch's *CPU* generator stream on the device (layout of
+        torch.get_rng_state(): u64 seed, i32 left, i32 seeded, u64 next, u64 state[624], ...)."""
+        st = (gen.get_state() if gen is not None else torch.get_rng_state()).numpy()
+        left = int(st[8:12].view(np.int32)[0])
+        nxt = int(st[16:24].view(np.uint64)[0])
+        mt = np.ascontiguousarray(st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32))
+        pos = 624 if left == 1 else nxt  # left==1: the next draw twists first
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ag_mt19937_import(L.ptr(self.state), mt.ctypes.data, pos, L.stream()))
+        return self
+
+    def export_to_torch_cpu(self, gen: Optional[torch.Generator] = None) -> None:
+        """Write the advanced state back into torch's CPU generator (synchronises)."""
+        mt = np.zeros(624, dtype=np.uint32)
+        import ctypes as C
+        pos = C.c_int(0)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ag_mt19937_export(L.ptr(self.state), mt.ctypes.data, C.byref(pos), L.stream()))
+        st = (gen.get_state() if gen is not None else torch.get_rng_state()).clone()
+        a = st.numpy()
+        p = pos.value
+        a[8:12].view(np.int32)[0] = 1 if p >= 624 else 624 - p
+        a[12:16].view(np.int32)[0] = 1
+        a[16:24].view(np.uint64)[0] = 0 if p >= 624 else p
+        a[24:24 + 624 * 8].view(np.uint64)[:] = mt.astype(np.uint64)
+        (gen.set_state(st) if gen is not None else torch.set_rng_state(st))
+
+    def raw(self, n: int) -> Tensor:
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().ag_mt19937_raw(L.ptr(self.state), L.ptr(out), n, L.stream()))
+        return out
+
+
+_PREFIX_CACHE = {}
+
+
+def shapley_prefix_table(n_players: int, device: torch.device) -> Tensor:
+    """The size-prior prefix table of reference models/shapley.py:65-67,:132, computed once per P
+    with the same torch CPU ops the reference uses (sum / cumsum reduction order is part of the
+    bit-exact contract) and kept resident on the device."""
+    key = (n_players, str(device))
+    if key not in _PREFIX_CACHE:
+        k = torch.arange(1, n_players)
+        probs = 1 / (k * (n_players - k))
+        probs = probs / probs.sum()
+        prefix = torch.cumsum(probs, dim=0) - probs
+        _PREFIX_CACHE[key] = prefix.to(torch.float32).to(device)
+    return _PREFIX_CACHE[key]
+
+
+def mask_shapley_new(rng: DeviceMT19937, n_mask_samples: int, n_players: int, want_i64: bool = True,
+                     want_bits: bool = True, prefix: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """reference models/shapley.py:56-79 -> (int64 [n,P] masks, uint32-as-int32 [n,Tw] key bits)."""
+    if n_mask_samples % 2 != 0:
+        raise AssertionError("n_mask_samples must be even (reference models/shapley.py:62)")
+    dev = rng.device
+    prefix = shapley_prefix_table(n_players, dev) if prefix is None else prefix
+    L.require_gpu(rng.state, prefix)
+    mi = torch.empty((n_mask_samples, n_players), dtype=torch.int64, device=dev) if want_i64 else None
+    mb = torch.empty((n_mask_samples, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
+    scratch = torch.empty(max(1, n_mask_samples // 2 * (n_players + 1)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().ag_mask_shapley_new(L.ptr(rng.state), n_mask_samples, n_players, L.ptr(prefix),
+                                            L.ptr(mi), L.ptr(mb), L.ptr(scratch), L.stream()))
+    return mi, mb
+
+
+def mask_purely_uniform(rng: DeviceMT19937, batch: int, n_players: int, want_i64: bool = True,
+                        want_bits: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """reference models/shapley.py:109-115."""
+    dev = rng.device
+    mi = torch.empty((batch, n_players), dtype=torch.int64, device=dev) if want_i64 else None
+    mb = torch.empty((batch, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
+    scratch = torch.empty(max(1, batch * (n_players + 1)), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().ag_mask_purely_uniform(L.ptr(rng.state), batch, n_players, L.ptr(mi), L.ptr(mb),
+                                               L.ptr(scratch), L.stream()))
+    return mi, mb
+
+
+def pack_mask(mask_i64: Tensor) -> Tensor:
+    """[R,P] int64 0/1 -> [R, ceil((P+1)/32)] key bits with the always-on CLS bit prepended
+    (recipes/vanilla_vit.py:219-224)."""
+    L.require_gpu(mask_i64)
+    m = mask_i64.contiguous()
+    if m.dtype != torch.int64:
+        m = m.to(torch.int64)
+    rows, p = m.shape
+    bits = torch.empty((rows, mask_words(p)), dtype=torch.int32, device=m.device)
+    with torch.cuda.device(m.device):
+        L.check(L.lib().ag_pack_mask(L.ptr(m), rows, p, L.ptr(bits), L.stream()))
+    return bits
+
+
+def perturbed_masks(attr: Tensor, steps: int, mask_base: int) -> Tuple[Tensor, Tensor]:
+    """scripts/measure_faithfulness.py:225-251 for attr [n_attr, P] -> (stops [S], masks [n_attr,S,P])."""
+    L.require_gpu(attr)
+    a = attr.contiguous().float()
+    n_attr, p = a.shape
+    s = min(p, steps)
+    stops = torch.empty(s, dtype=torch.int64, device=a.device)
+    masks = torch.empty((n_attr, s, p), dtype=torch.int64, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().ag_perturbed_masks(L.ptr(a), n_attr, p, steps, mask_base, L.ptr(stops), L.ptr(masks), L.stream()))
+    return stops, masks
+
+
+# ----------------------------------------------------------------------------- building blocks
+def cast(src: Tensor, dtype: int) -> Tensor:
+    L.require_gpu(src)
+    s = src.contiguous().float()
+    out = torch.empty(s.shape, dtype=storage_dtype(dtype), device=s.device)
+    with torch.cuda.device(s.device):
+        L.check(L.lib().ag_cast_f32(L.ptr(s), L.ptr(out), s.numel(), dtype, L.stream()))
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, rows: Optional[int] = None,
+              ldx: Optional[int] = None, want_store: bool = True, want_f32: bool = False):
+    """x fp32 [..., H] (or a strided view described by rows/ldx)."""
+    L.require_gpu(x, gamma, beta)
+    h = gamma.numel()
+    rows = x.numel() // h if rows is None else rows
+    ldx = h if ldx is None else ldx
+    ys = torch.empty((rows, h), dtype=storage_dtype(dtype), device=x.device) if want_store else None
+    yf = torch.empty((rows, h), dtype=torch.float32, device=x.device) if want_f32 else None
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_layernorm(L.ptr(x), ldx, rows, h, L.ptr(gamma), L.ptr(beta), eps, L.ptr(ys), L.ptr(yf),
+                                     dtype, L.stream()))
+    return ys, yf
+
+
+def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int, m: Optional[int] = None,
+         lda: Optional[int] = None, resid: Optional[Tensor] = None, ldr: Optional[int] = None,
+         rows_per_seq: int = 1, resid_share: int = 1, out: Optional[Tensor] = None, ldc: Optional[int] = None) -> Tensor:
+    """epilogue(A[M,K] @ W[N,K]^T + bias).  a, w in the storage dtype; bias / resid fp32."""
+    L.require_gpu(a, w, bias, resid, out)
+    n, k = w.shape
+    m = a.numel() // k if m is None else m
+    lda = k if lda is None else lda
+    out_f32 = epilogue in (L.AG_EPI_BIAS_RESID, L.AG_EPI_BIAS_F32) or dtype == F32
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32 if out_f32 else storage_dtype(dtype), device=a.device)
+    ldc = n if ldc is None else ldc
+    ldr = (n if ldr is None else ldr) if resid is not None else 0
+    with torch.cuda.device(a.device):
+        L.check(L.lib().ag_gemm(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr,
+                                rows_per_seq, resid_share, m, n, k, epilogue, dtype, L.stream()))
+    return out
+
+
+def masked_attention(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, heads: int, share: int,
+                     mask_mode: int, dtype: int, n_query: int = 0) -> Tensor:
+    L.require_gpu(qkv, mask_bits)
+    ctx = torch.empty((rows, t, h), dtype=storage_dtype(dtype), device=qkv.device)
+    if n_query:
+        ctx.zero_()
+    with torch.cuda.device(qkv.device):
+        L.check(L.lib().ag_masked_attention(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, share,
+                                            mask_mode, n_query, dtype, L.stream()))
+    return ctx
+
+
+def softmax_rows(x: Tensor) -> Tensor:
+    L.require_gpu(x)
+    x = x.contiguous().float()
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_softmax_rows(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], L.stream()))
+    return y
+
+
+# ----------------------------------------------------------------------------- Shapley reductions
+def shapley_normalize(pred: Tensor, grand: Optional[Tensor], null: Optional[Tensor], normalize: bool = True) -> Tensor:
+    """pred [B,T,C] (T includes CLS) -> phi [B,C,P] (models/shapley.py:82-93 + vanilla_vit.py:129)."""
+    L.require_gpu(pred, grand, null)
+    pred = pred.contiguous().float()
+    b, t, c = pred.shape
+    phi = torch.empty((b, c, t - 1), dtype=torch.float32, device=pred.device)
+    g = grand.contiguous().float() if grand is not None else None
+    n = null.contiguous().float() if null is not None else None
+    with torch.cuda.device(pred.device):
+        L.check(L.lib().ag_shapley_normalize(L.ptr(pred), L.ptr(g), L.ptr(n), b, t, c, 1 if normalize else 0,
+                                             L.ptr(phi), L.stream()))
+    return phi
+
+
+def shapley_normalize_bwd(dphi: Tensor, t: int, normalize: bool = True) -> Tensor:
+    L.require_gpu(dphi)
+    dphi = dphi.contiguous().float()
+    b, c, p = dphi.shape
+    dpred = torch.empty((b, t, c), dtype=torch.float32, device=dphi.device)
+    with torch.cuda.device(dphi.device):
+        L.check(L.lib().ag_shapley_normalize_bwd(L.ptr(dphi), b, t, c, 1 if normalize else 0, L.ptr(dpred), L.stream()))
+    return dpred
+
+
+def shapley_loss(mask_bits: Tensor, v0: Tensor, vs: Tensor, phi: Tensor, batch: int, k: int, want_grad: bool = True):
+    """models/shapley.py:9-53 -> (loss [1] fp32 on device, dphi [B,C,P] or None)."""
+    L.require_gpu(mask_bits, v0, vs, phi)
+    phi = phi.contiguous().float()
+    b, c, p = phi.shape
+    assert b == batch and vs.shape[0] == batch * k
+    loss = torch.empty(1, dtype=torch.float32, device=phi.device)
+    dphi = torch.empty_like(phi) if want_grad else None
+    scratch = torch.empty(batch * k * c, dtype=torch.float32, device=phi.device)
+    with torch.cuda.device(phi.device):
+        L.check(L.lib().ag_shapley_loss(L.ptr(mask_bits), L.ptr(v0.contiguous().float()), L.ptr(vs.contiguous().float()),
+                                        L.ptr(phi), batch, k, p, c, L.ptr(loss), L.ptr(dphi), L.ptr(scratch), L.stream()))
+    return loss, dphi
+
+
+def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
+    """models/shapley.py:96-106 -> (loss [1], dloss/dcur or None)."""
+    L.require_gpu(ref, cur)
+    ref, cur = ref.contiguous().float(), cur.contiguous().float()
+    loss = torch.empty(1, dtype=torch.float32, device=ref.device)
+    d = torch.empty_like(cur) if want_grad else None
+    with torch.cuda.device(ref.device):
+        L.check(L.lib().ag_kl_loss(L.ptr(ref), L.ptr(cur), ref.shape[0], ref.shape[1], L.ptr(loss), L.ptr(d), L.stream()))
+    return loss, d

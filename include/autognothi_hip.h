@@ -1,0 +1,197 @@
+/*
+ * autognothi_hip.h — C ABI of the MI355X (gfx950) masked-forward / Shapley hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every device pointer
+ * is caller-owned HBM (the Python host allocates it through torch), `stream` is a hipStream_t
+ * passed as void* (0 = default stream); all calls are asynchronous on that stream unless noted.
+ * Every function returns AG_OK (0) or a negative AG_ERR_* code; ag_last_error() gives the text.
+ *
+ * The reference (gszfwsb/AutoGnothi) is Python-only, so there is no pre-existing FFI: each entry
+ * point below replaces the stock-PyTorch implementation of the reference symbol cited next to it
+ * (file:line relative to the reference repo).  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add to call them from recipes/<kind>.py / models/shapley.py.
+ *
+ * Storage dtypes (AG_BF16 / AG_F32) select what GEMM operands and inter-kernel activations are
+ * stored in; accumulation, LayerNorm statistics, soft-max and the residual stream are fp32 in
+ * both modes.  AG_F32 runs the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) and is the mode the
+ * 1e-4 Shapley-value parity criterion is checked in; AG_BF16 is the throughput mode.
+ */
+#ifndef AUTOGNOTHI_HIP_H_
+#define AUTOGNOTHI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_ABI_VERSION 1
+
+enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
+enum { AG_F32 = 0, AG_BF16 = 1 };
+/* attention mask semantics: ViT multiplies key logits by the 0/1 mask (reference
+ * models/vanilla_vit.py:446-450); BERT adds (1-mask)*finfo(f32).min (models/vanilla_bert.py:520-523). */
+enum { AG_MASK_VIT_MUL = 0, AG_MASK_BERT_ADD = 1 };
+/* GEMM epilogues */
+enum {
+    AG_EPI_BIAS = 0,        /* C = A·Wᵀ + b                     -> storage dtype            */
+    AG_EPI_BIAS_GELU = 1,   /* C = gelu_erf(A·Wᵀ + b)           -> storage dtype            */
+    AG_EPI_BIAS_RESID = 2,  /* C = A·Wᵀ + b + R                 -> fp32 (residual stream)   */
+    AG_EPI_BIAS_F32 = 3,    /* C = A·Wᵀ + b                     -> fp32                     */
+    AG_EPI_BIAS_TANH = 4,   /* C = tanh(A·Wᵀ + b)               -> storage dtype (pooler)   */
+    AG_EPI_BIAS_GELU_F32 = 5 /* reserved */
+};
+
+int ag_abi_version(void);
+const char* ag_last_error(void);
+/* number of CUs / gfx arch of `device`; both out-params optional.  Synchronous. */
+int ag_device_info(int device, int* cu_count, char* arch, size_t arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident MT19937 (the engine behind torch's CPU generator) and the mask samplers.
+ * d_state: AG_MT_STATE_BYTES of HBM holding {mt[624], pos}.  The stream of 32-bit draws is
+ * bit-identical to at::mt19937; fp32 uniforms are (x & 0xFFFFFF) * 2^-24, as torch.rand.
+ * ---------------------------------------------------------------------------------------------- */
+#define AG_MT_STATE_BYTES 2560 /* 624 words + pos, padded */
+/* == torch.manual_seed(seed) on the CPU generator (reference utils/tools.py:33-43 set_seed). */
+int ag_mt19937_seed(void* d_state, uint32_t seed, void* stream);
+/* import / export the 624-word state + position (0..624; 624 = twist on next draw), e.g. from
+ * torch.get_rng_state() so the device stream continues the host generator.  Export synchronises. */
+int ag_mt19937_import(void* d_state, const uint32_t* h_mt624, int pos, void* stream);
+int ag_mt19937_export(const void* d_state, uint32_t* h_mt624, int* pos, void* stream);
+/* raw draws (testing / other samplers): out[n] u32, advances the state. */
+int ag_mt19937_raw(void* d_state, uint32_t* d_out, int64_t n, void* stream);
+
+/* reference models/shapley.py:56-79 mask_shapley_new(n_mask_samples, n_players) (+ _torch_choice
+ * :131-135).  d_prefix = the fp32 exclusive-prefix table of the size prior (P-1 entries, :65-67,:132).
+ * Outputs (either may be NULL): d_mask_i64 [n, P] int64 0/1 — the reference's return value;
+ * d_mask_bits [n, ceil((P+1)/32)] uint32 — the T-wide key mask with the always-on CLS bit 0
+ * prepended (recipes/vanilla_vit.py:219-224 _fw_xs_preprocess), bit t of word t/32.
+ * Consumes n/2*P + n/2 draws in the reference's order.  d_scratch: >= n/2*(P+1) uint32. */
+int ag_mask_shapley_new(void* d_state, int n_mask_samples, int n_players, const float* d_prefix,
+                        int64_t* d_mask_i64, uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream);
+/* reference models/shapley.py:109-115 mask_purely_uniform(batch, n_features).
+ * d_scratch: >= batch*(P+1) uint32. */
+int ag_mask_purely_uniform(void* d_state, int batch, int n_players, int64_t* d_mask_i64,
+                           uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream);
+/* recipes/<kind>.py _fw_xs_preprocess: int64 [R,P] 0/1 mask -> [R, ceil((P+1)/32)] bits with CLS prepended. */
+int ag_pack_mask(const int64_t* d_mask_i64, int rows, int n_players, uint32_t* d_mask_bits, void* stream);
+/* scripts/measure_faithfulness.py:225-251 _get_perturbed_samples for `n_attr` attribution vectors
+ * at once: d_attr [n_attr, P] fp32; stops = linspace(0,P,steps) as int64; mask i flips the `stops[i]`
+ * highest-attribution players of an all-`mask_base` row.  Ties rank the higher index first (stable
+ * ascending argsort reversed).  d_stops [steps] int64, d_mask_i64 [n_attr, steps, P]. */
+int ag_perturbed_masks(const float* d_attr, int n_attr, int n_players, int steps, int mask_base,
+                       int64_t* d_stops, int64_t* d_mask_i64, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building-block kernels (also used one by one by the parity tests).
+ * ---------------------------------------------------------------------------------------------- */
+/* fp32 -> storage dtype conversion (weights packing). */
+int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream);
+
+/* torch.nn.LayerNorm over the last dim (reference call sites models/vanilla_vit.py:353-362,:205;
+ * models/vanilla_bert.py:323,:559,:603).  x fp32 [rows, H] with row stride ldx (elements);
+ * y_store (storage dtype, stride H) and/or y_f32 (stride H) may be NULL. */
+int ag_layernorm(const float* d_x, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
+                 float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream);
+
+/* C[M,N] = epilogue(A[M,K] · W[N,K]ᵀ + bias[N]) — every nn.Linear on the path (q/k/v fused into
+ * one [3H,H] weight: models/vanilla_vit.py:422-424; :477; :491; :510).  A, W in storage dtype
+ * (A row stride lda, W dense [N,K]); bias fp32.  For AG_EPI_BIAS_RESID, R is fp32 with row stride
+ * ldr and row index ((m / T) / resid_share) * T + m % T  (T = rows_per_seq; resid_share > 1 lets
+ * the K masked copies of one input share the layer-0 residual).  K % 64 == 0 (bf16) / K % 32 == 0
+ * (fp32) required; N, M arbitrary. */
+int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+            const float* d_R, int64_t ldr, int rows_per_seq, int resid_share,
+            int M, int N, int K, int epilogue, int dtype, void* stream);
+
+/* Fused masked multi-head attention (reference models/vanilla_vit.py:436-465,
+ * models/vanilla_bert.py:503-537): per row r and head h, softmax(mask_op(Q·Kᵀ/sqrt(d)))·V.
+ * d_qkv: storage dtype [R_src, T, 3H] (q | k | v column blocks, heads contiguous inside each);
+ * row r reads source row r / qkv_share (layer-0 sharing of q/k/v across the masks of one input).
+ * d_mask_bits [R, ceil(T/32)]; d_ctx storage dtype [R, T, H].  head_dim must be 64.
+ * n_query: only queries [0, n_query) of each row are computed/written (0 = all T; the surrogate's
+ * last layer only needs the CLS query). */
+int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
+                        int heads, int qkv_share, int mask_mode, int n_query, int dtype, void* stream);
+
+/* reference models/vanilla_vit.py:242-253 + :279-284: Conv2d(k=s=patch) patch embedding as
+ * im2col (this call) + ag_gemm + ag_vit_assemble.  d_img fp32 [B,Cin,px,px] -> d_cols storage
+ * dtype [B*(px/patch)^2, Cin*patch*patch] in (c, ph, pw) order. */
+int ag_vit_im2col(const float* d_img, int B, int Cin, int px, int patch, void* d_cols, int dtype, void* stream);
+/* h0[b,0,:] = cls + pos[0]; h0[b,1+p,:] = patch_emb[b,p,:] + pos[1+p]   (fp32 [B,T,H]). */
+int ag_vit_assemble(const float* d_patch_emb, const float* d_cls, const float* d_pos, int B, int P, int H,
+                    float* d_h0, void* stream);
+/* reference models/vanilla_bert.py:307-325: LN(word[ids] + type[0] + pos[t]); ids int64 [B,T].
+ * Writes fp32 h0 [B,T,H] and (optionally) the storage-dtype copy. */
+int ag_bert_embed(const int64_t* d_ids, int B, int T, int H, const float* d_word, int vocab, const float* d_type0,
+                  const float* d_pos, const float* d_gamma, const float* d_beta, float eps,
+                  float* d_h0, void* d_h0_store, int dtype, void* stream);
+
+/* softmax(x[rows, C]) in place / out of place, fp32 (the nn.Softmax heads, models/vanilla_vit.py:55). */
+int ag_softmax_rows(const float* d_x, float* d_y, int rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Shapley reductions.
+ * ---------------------------------------------------------------------------------------------- */
+/* reference models/shapley.py:82-93 normalize_shapley_explanation fused with the
+ * `[:, 1:, :].permute(0, 2, 1)` of models/vanilla_vit.py:129: pred fp32 [B,T,C] (T = P+1 rows
+ * INCLUDING the CLS row), grand [B,C], null [1,C] -> phi [B,C,P].  normalize=0 only drops CLS and
+ * permutes.  Token-axis sums are wavefront shuffle reductions. */
+int ag_shapley_normalize(const float* d_pred, const float* d_grand, const float* d_null, int B, int T, int C,
+                         int normalize, float* d_phi, void* stream);
+/* its backward: dpred[b,t,c] = (t>0 ? dphi[b,c,t-1] : 0) - (normalize ? sum_p dphi[b,c,p] / T : 0). */
+int ag_shapley_normalize_bwd(const float* d_dphi, int B, int T, int C, int normalize, float* d_dpred, void* stream);
+/* reference models/shapley.py:9-53 loss_shapley_new: mask bits [B*K, ceil((P+1)/32)] (CLS bit
+ * ignored), v0 [1,C], v_s [B*K,C], phi [B,C,P] -> loss (1 float, device) and optional dphi [B,C,P]
+ * (d loss / d phi).  d_scratch: >= B*K*C floats. */
+int ag_shapley_loss(const uint32_t* d_mask_bits, const float* d_v0, const float* d_vs, const float* d_phi,
+                    int B, int K, int P, int C, float* d_loss, float* d_dphi, float* d_scratch, void* stream);
+/* reference models/shapley.py:96-106 loss_logits_kl_divergence(ref, current) on [B,C] fp32 ->
+ * loss (1 float) and optional d loss / d current [B,C]. */
+int ag_kl_loss(const float* d_ref, const float* d_cur, int B, int C, float* d_loss, float* d_dcur, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole masked forward: the composite the recipes' fw_surrogate / fw_classifier / fw_explainer call.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ag_layer_weights {
+    const void* w_qkv;   /* storage dtype [3H, H]  (query | key | value rows)                */
+    const float* b_qkv;  /* [3H]                                                             */
+    const void* w_o;     /* [H, H]   attention.output.dense                                  */
+    const float* b_o;
+    const void* w_fc1;   /* [I, H]   intermediate.dense                                      */
+    const float* b_fc1;
+    const void* w_fc2;   /* [H, I]   output.dense                                            */
+    const float* b_fc2;
+    const float* ln1_g;  /* ViT layernorm_before / BERT attention.output.LayerNorm; NULL = Identity */
+    const float* ln1_b;
+    const float* ln2_g;  /* ViT layernorm_after  / BERT output.LayerNorm                     */
+    const float* ln2_b;
+} ag_layer_weights;
+
+typedef struct ag_encoder_desc {
+    int kind;        /* AG_MASK_VIT_MUL (pre-LN ViT block) or AG_MASK_BERT_ADD (post-LN BERT block) */
+    int dtype;       /* AG_F32 / AG_BF16 */
+    int T, H, I, heads;
+    float ln_eps;
+    int n_layers;
+    const ag_layer_weights* layers; /* host array [n_layers] of device pointers */
+} ag_encoder_desc;
+
+/* bytes of workspace ag_encoder_forward needs for R rows. */
+size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R);
+/* Run the encoder stack (reference models/vanilla_vit.py:315-320 / models/vanilla_bert.py:362-367)
+ * over R rows that share B = R / share distinct inputs: d_h0 fp32 [B,T,H] are the embeddings of the
+ * distinct inputs (layer 0's LN/QKV are computed once per input and its residual is shared);
+ * d_mask_bits [R, ceil(T/32)].  Output d_h fp32 [R,T,H] = last layer's hidden states (before any
+ * final LN).  cls_only_last != 0 computes the last layer's out-proj/MLP for token 0 only (legal when
+ * only h[:,0] is consumed: surrogate/classifier heads) — then only d_h[r,0,:] is defined. */
+int ag_encoder_forward(const ag_encoder_desc* desc, const float* d_h0, int R, int share,
+                       const uint32_t* d_mask_bits, float* d_h, int cls_only_last,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOGNOTHI_HIP_H_ */

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the *reference itself*.
+
+Run ONLY in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's Python (models/shapley.py, recipes/*, scripts/measure_faithfulness.py
+helper) unmodified, feeds it deterministic inputs / name-keyed synthetic weights
+(autognothi_amd/utils/synth.py) and stores inputs that cannot be regenerated plus the expected
+outputs as small .npz/.json files.  Fixtures are data only; no reference source is stored.
+"""
+import importlib.machinery
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root")
+
+from autognothi_amd.utils import synth  # noqa: E402
+
+import reference.models.shapley as rshap  # noqa: E402
+from reference.utils.tools import set_iterative_seed  # noqa: E402
+import reference.recipes.vanilla_vit as r_vvit  # noqa: E402
+import reference.recipes.vanilla_bert as r_vbert  # noqa: E402
+import reference.recipes.duo_vanilla_vit as r_dvit  # noqa: E402
+import reference.recipes.duo_vanilla_bert as r_dbert  # noqa: E402
+import reference.recipes.froyo_vit as r_fvit  # noqa: E402
+import reference.recipes.froyo_bert as r_fbert  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+def hparams(exp):
+    with open(f"/root/reference/experiments/{exp}/.hparams.json") as f:
+        return json.load(f)["net"]["params"]
+
+
+# ------------------------------------------------------------------ seeds
+def gen_seeds():
+    import hashlib
+    out = {}
+    for key in ["train_explainer[epoch=1]", "train_explainer[epoch=2]", "train_explainer[epoch=3]",
+                "train_surrogate[epoch=1]", "stage-a"]:
+        set_iterative_seed(3407, key)
+        out[key] = int(torch.initial_seed())
+    with open(os.path.join(HERE, "iterative_seeds.json"), "w") as f:
+        json.dump({"master": 3407, "derived": out}, f, indent=1)
+    print("wrote iterative_seeds.json", out)
+    return out
+
+
+# ------------------------------------------------------------------ masks
+def gen_masks(seeds):
+    arrs = {}
+    tables = {}
+    for P in (196, 127, 511):
+        probs = torch.arange(1, P) * (P - torch.arange(1, P))
+        probs = 1 / probs
+        probs = probs / probs.sum()
+        prefix = torch.cumsum(probs, dim=0) - probs
+        tables[f"prefix_{P}"] = prefix.numpy()
+        tables[f"probs_{P}"] = probs.numpy()
+    save("prefix_tables.npz", **tables)
+
+    cases = []
+    seed_list = [0, 3407, seeds["train_explainer[epoch=1]"], seeds["train_explainer[epoch=2]"]]
+    for s in seed_list:
+        for (R, P) in [(8, 196), (32, 196), (64, 196), (32, 127), (4, 511), (2, 196)]:
+            torch.manual_seed(s)
+            m1 = rshap.mask_shapley_new(R, P)
+            m2 = rshap.mask_shapley_new(R, P)  # stream continuity across calls
+            key = f"s{s}_R{R}_P{P}"
+            arrs[key + "_a"] = np.packbits(m1.numpy().astype(np.uint8), axis=1)
+            arrs[key + "_b"] = np.packbits(m2.numpy().astype(np.uint8), axis=1)
+            cases.append([int(s), R, P])
+    arrs["cases"] = np.asarray(cases, dtype=np.int64)
+    # a large draw that crosses many twists
+    torch.manual_seed(99)
+    big = rshap.mask_shapley_new(1024, 196)
+    arrs["big_s99_R1024_P196_rowsum"] = big.sum(1).numpy()
+    arrs["big_s99_R1024_P196_colsum"] = big.sum(0).numpy()
+    import zlib
+    arrs["big_s99_R1024_P196_crc"] = np.asarray([zlib.crc32(np.packbits(big.numpy().astype(np.uint8), axis=1).tobytes())], dtype=np.int64)
+    save("masks_shapley.npz", **arrs)
+
+    arrs = {}
+    cases = []
+    for s in (0, 3407):
+        for (B, P) in [(8, 196), (8, 127), (3, 511)]:
+            torch.manual_seed(s)
+            m = rshap.mask_purely_uniform(B, P)
+            arrs[f"uniform_s{s}_B{B}_P{P}"] = np.packbits(m.numpy().astype(np.uint8), axis=1)
+            random.seed(s)
+            m = rshap.mask_uniform_selective(B, P, P // 3)
+            arrs[f"selective_s{s}_B{B}_P{P}"] = np.packbits(m.numpy().astype(np.uint8), axis=1)
+            cases.append([s, B, P])
+    arrs["cases"] = np.asarray(cases, dtype=np.int64)
+    save("masks_other.npz", **arrs)
+
+
+# ------------------------------------------------------------------ shapley fns
+def gen_shapley_fns():
+    g = np.random.default_rng(1234)
+    arrs = {}
+    for tag, (B, K, P, C) in {"vit": (3, 8, 196, 10), "bert": (2, 6, 127, 2)}.items():
+        T = P + 1
+        pred = g.standard_normal((B, T, C)).astype(np.float32)
+        grand = g.random((B, C)).astype(np.float32)
+        null = g.random((1, C)).astype(np.float32)
+        out = rshap.normalize_shapley_explanation(torch.from_numpy(pred), torch.from_numpy(grand), torch.from_numpy(null))
+        arrs[f"{tag}_norm_pred"], arrs[f"{tag}_norm_grand"], arrs[f"{tag}_norm_null"] = pred, grand, null
+        arrs[f"{tag}_norm_out"] = out.numpy()
+
+        torch.manual_seed(11)
+        mask = rshap.mask_shapley_new(B * K, P).reshape(B, K, P)
+        v_s = g.random((B * K, C)).astype(np.float32)
+        v_1 = g.random((B, C)).astype(np.float32)
+        phi = (0.05 * g.standard_normal((B, C, P))).astype(np.float32)
+        phi_t = torch.from_numpy(phi).requires_grad_(True)
+        loss = rshap.loss_shapley_new(B, K, P, mask, torch.from_numpy(null), torch.from_numpy(v_s), torch.from_numpy(v_1), phi_t)
+        loss.backward()
+        arrs[f"{tag}_loss_mask"] = np.packbits(mask.numpy().astype(np.uint8), axis=2)
+        arrs[f"{tag}_loss_v0"], arrs[f"{tag}_loss_vs"], arrs[f"{tag}_loss_v1"], arrs[f"{tag}_loss_phi"] = null, v_s, v_1, phi
+        arrs[f"{tag}_loss_out"] = np.asarray([loss.item()], dtype=np.float32)
+        arrs[f"{tag}_loss_dphi"] = phi_t.grad.numpy()
+        arrs[f"{tag}_dims"] = np.asarray([B, K, P, C], dtype=np.int64)
+
+        ref = torch.softmax(torch.from_numpy(g.standard_normal((5, C)).astype(np.float32)), -1)
+        cur = torch.softmax(torch.from_numpy(g.standard_normal((5, C)).astype(np.float32)), -1)
+        kl = rshap.loss_logits_kl_divergence(ref, cur)
+        arrs[f"{tag}_kl_ref"], arrs[f"{tag}_kl_cur"] = ref.numpy(), cur.numpy()
+        arrs[f"{tag}_kl_out"] = np.asarray([kl.item()], dtype=np.float32)
+    save("shapley_fns.npz", **arrs)
+
+
+# ------------------------------------------------------------------ faithfulness masks
+def _stub_modules():
+    import transformers, datasets  # noqa: F401  (must be imported before the stand-ins)
+    def mk(name, **attrs):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    class _Any:
+        def __init__(self, *a, **k): pass
+    tv = mk("torchvision")
+    tvt = mk("torchvision.transforms", **{n: _Any for n in
+              ["CenterCrop", "ColorJitter", "Compose", "Lambda", "Normalize", "RandomHorizontalFlip", "RandomResizedCrop",
+               "RandomVerticalFlip", "Resize", "ToTensor"]})
+    tvf = mk("torchvision.transforms.functional", resize=lambda *a, **k: None)
+    tv.transforms = tvt
+    tvt.functional = tvf
+    mk("wandb", Image=_Any, log=lambda *a, **k: None, init=lambda *a, **k: None, run=None)
+    mk("shap", KernelExplainer=_Any, kmeans=lambda *a, **k: None)
+
+
+def gen_perturbed():
+    _stub_modules()
+    from reference.scripts.measure_faithfulness import _get_perturbed_samples, _auc
+    g = np.random.default_rng(77)
+    arrs = {}
+    cases = []
+    for i, (P, steps) in enumerate([(196, 4), (196, 32), (196, 300), (127, 8), (127, 127), (511, 16)]):
+        attr = g.standard_normal(P).astype(np.float32)
+        for base in (0, 1):
+            stops, masks = _get_perturbed_samples(torch.from_numpy(attr), P, steps, base)
+            arrs[f"c{i}_b{base}_stops"] = stops.numpy()
+            arrs[f"c{i}_b{base}_masks"] = np.packbits(masks.numpy().astype(np.uint8), axis=1)
+        arrs[f"c{i}_attr"] = attr
+        cases.append([P, steps])
+    arrs["cases"] = np.asarray(cases, dtype=np.int64)
+    curve = {int(k): float(v) for k, v in zip(range(0, 50, 5), g.random(10))}
+    arrs["auc_vals"] = np.asarray(list(curve.values()), dtype=np.float64)
+    arrs["auc_out"] = np.asarray([_auc(curve)], dtype=np.float64)
+    save("perturbed.npz", **arrs)
+
+
+# ------------------------------------------------------------------ model fixtures
+def checks(t):
+    a = t.detach().double().reshape(-1)
+    idx = np.linspace(0, a.numel() - 1, 16).astype(np.int64)
+    return np.asarray([a.sum().item(), a.abs().sum().item()] + a[idx].tolist(), dtype=np.float64)
+
+
+def layer_trace(model_backbone_layers, run):
+    """Run `run()` with forward hooks on each encoder layer; returns per-layer checksums."""
+    outs = []
+    hooks = [ly.register_forward_hook(lambda m, i, o: outs.append(checks(o))) for ly in model_backbone_layers]
+    try:
+        res = run()
+    finally:
+        for h in hooks:
+            h.remove()
+    return res, np.stack(outs)
+
+
+def gen_model_fixture(tag, recipe_fn, params, kind, B, K, mask_seed, duo=False, froyo=False):
+    recipe = recipe_fn()
+    cfg = recipe.t_config(**params)
+    P = recipe.n_players(cfg)
+    m_srg = recipe.t_surrogate(cfg)
+    m_exp = recipe.t_explainer(cfg)
+    synth.load_synth_weights(m_srg, seed=0)
+    synth.load_synth_weights(m_exp, seed=1)
+    m_srg.eval(); m_exp.eval()
+    if kind == "vit":
+        Xs = torch.from_numpy(synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=0))
+        null = torch.zeros((1, params["img_channels"], params["img_px_size"], params["img_px_size"]))
+        backbone_layers = m_srg.vit.encoder.layers
+    else:
+        L = params["max_position_embeddings"]
+        Xs = torch.from_numpy(synth.synth_token_ids(B, L, params["vocab_size"], seed=0))
+        null = torch.from_numpy(synth.synth_null_ids(L, params["vocab_size"]))
+        backbone_layers = m_srg.bert.encoder.layers
+    torch.manual_seed(mask_seed)
+    masks = rshap.mask_shapley_new(B * K, P)
+    Xs_ext = torch.repeat_interleave(Xs, K, dim=0)
+    ones = torch.ones((B, P), dtype=torch.long)
+    with torch.no_grad():
+        v_0, _ = recipe.fw_surrogate(m_srg, null, torch.ones((1, P), dtype=torch.long))
+        (v_s, _), trace = layer_trace(backbone_layers, lambda: recipe.fw_surrogate(m_srg, Xs_ext, masks))
+        v_1, _ = recipe.fw_surrogate(m_srg, Xs, ones)
+        # an all-zero mask row and an all-one row are legal sampler outputs: pin them too
+        edge_masks = torch.stack([torch.zeros(P, dtype=torch.long), torch.ones(P, dtype=torch.long)])
+        v_edge, _ = recipe.fw_surrogate(m_srg, Xs[:1].repeat_interleave(2, 0), edge_masks)
+    phi, extra = recipe.fw_explainer(m_exp, Xs, ones, v_1, v_0)
+    phi_leaf = phi.detach().clone().requires_grad_(True)
+    loss = rshap.loss_shapley_new(B, K, P, masks.reshape(B, K, P), v_0, v_s, v_1, phi_leaf)
+    loss.backward()
+    arrs = dict(
+        dims=np.asarray([B, K, P], dtype=np.int64), mask_seed=np.asarray([mask_seed], dtype=np.int64),
+        masks=np.packbits(masks.numpy().astype(np.uint8), axis=1),
+        v_0=v_0.numpy(), v_s=v_s.numpy(), v_1=v_1.numpy(), v_edge=v_edge.numpy(),
+        phi=phi.detach().numpy(), loss=np.asarray([loss.item()], dtype=np.float32), dphi=phi_leaf.grad.numpy(),
+        layer_trace=trace,
+    )
+    if extra is not None:
+        arrs["exp_logits"] = extra.detach().numpy()
+    with open(os.path.join(HERE, f"model_{tag}.json"), "w") as f:
+        json.dump({"kind": kind, "duo": duo, "froyo": froyo, "params": params, "B": B, "K": K,
+                   "weights": {"surrogate_seed": 0, "explainer_seed": 1}, "input_seed": 0}, f, indent=1)
+    save(f"model_{tag}.npz", **arrs)
+
+
+def gen_models():
+    tiny = hparams("vit_tiny_imagenette_vanilla")
+    gen_model_fixture("vit_tiny_c1", r_vvit.vanilla_vit_recipe, tiny, "vit", B=2, K=4, mask_seed=3407)
+    base = dict(hparams("vit_base_imagenette_vanilla"), num_hidden_layers=2)
+    gen_model_fixture("vit_base_l2", r_vvit.vanilla_vit_recipe, base, "vit", B=1, K=4, mask_seed=3407)
+    large = dict(hparams("vit_large_imagenette_vanilla"), num_hidden_layers=2)
+    gen_model_fixture("vit_large_l2", r_vvit.vanilla_vit_recipe, large, "vit", B=1, K=2, mask_seed=3407)
+    bert = dict(hparams("bert_base_tayp_vanilla"), num_hidden_layers=2, max_position_embeddings=128)
+    gen_model_fixture("bert_base_l2", r_vbert.vanilla_bert_recipe, bert, "bert", B=2, K=4, mask_seed=3407)
+    dbert = dict(hparams("bert_base_tayp_duo_vanilla"), num_hidden_layers=2, max_position_embeddings=128)
+    gen_model_fixture("duo_bert_base_l2", r_dbert.duo_vanilla_bert_recipe, dbert, "bert", B=2, K=4, mask_seed=3407, duo=True)
+    dvit = dict(tiny, num_hidden_layers=3)
+    gen_model_fixture("duo_vit_tiny_l3", r_dvit.duo_vanilla_vit_recipe, dvit, "vit", B=2, K=4, mask_seed=3407, duo=True)
+    gen_model_fixture("froyo_vit_tiny_l3", r_fvit.froyo_vit_recipe, dvit, "vit", B=2, K=4, mask_seed=3407, froyo=True)
+    fbert = dict(hparams("bert_base_tayp_froyo"), num_hidden_layers=2, max_position_embeddings=128)
+    gen_model_fixture("froyo_bert_base_l2", r_fbert.froyo_bert_recipe, fbert, "bert", B=2, K=4, mask_seed=3407, froyo=True)
+
+
+if __name__ == "__main__":
+    seeds = gen_seeds()
+    gen_masks(seeds)
+    gen_shapley_fns()
+    gen_perturbed()
+    gen_models()

@@ -1,0 +1,29 @@
+"""Pin the oracle's Shapley reductions against reference outputs (CPU)."""
+import numpy as np
+
+from oracle import shapley as osh
+from util import golden, unpack
+
+
+def test_normalize_loss_kl():
+    g = golden("shapley_fns.npz")
+    for tag in ("vit", "bert"):
+        b, k, p, c = [int(x) for x in g[f"{tag}_dims"]]
+        out = osh.normalize_shapley_explanation(g[f"{tag}_norm_pred"], g[f"{tag}_norm_grand"], g[f"{tag}_norm_null"])
+        np.testing.assert_allclose(out, g[f"{tag}_norm_out"], rtol=0, atol=1e-5)
+        mask = unpack(g[f"{tag}_loss_mask"], p)
+        loss, dphi = osh.loss_shapley_new(b, k, p, mask, g[f"{tag}_loss_v0"], g[f"{tag}_loss_vs"], g[f"{tag}_loss_v1"],
+                                          g[f"{tag}_loss_phi"])
+        np.testing.assert_allclose(loss, g[f"{tag}_loss_out"][0], rtol=1e-5)
+        np.testing.assert_allclose(dphi, g[f"{tag}_loss_dphi"], rtol=1e-4, atol=1e-6)
+        kl = osh.loss_logits_kl_divergence(g[f"{tag}_kl_ref"], g[f"{tag}_kl_cur"])
+        np.testing.assert_allclose(kl, g[f"{tag}_kl_out"][0], rtol=1e-5, atol=1e-7)
+
+
+def test_normalize_efficiency_gap_quirk():
+    """Dividing by T = P+1 then dropping the CLS row means sum(phi) != v1 - v0 exactly."""
+    g = golden("shapley_fns.npz")
+    out = osh.normalize_shapley_explanation(g["vit_norm_pred"], g["vit_norm_grand"], g["vit_norm_null"])
+    total_with_cls = out.sum(axis=1)
+    np.testing.assert_allclose(total_with_cls, g["vit_norm_grand"] - g["vit_norm_null"], atol=2e-5)
+    assert np.abs(out[:, 1:].sum(axis=1) - (g["vit_norm_grand"] - g["vit_norm_null"])).max() > 1e-4
