@@ -1,0 +1,98 @@
+"""GPU parity of the whole masked forward / explainer behind the recipes' fw_* callables against the
+reference-generated fixtures.  fp32 mode carries the north-star criterion (Shapley values within 1e-4
+rtol of the reference CPU path); bf16 (throughput mode) is checked against a stated looser bound."""
+import numpy as np
+import pytest
+import torch
+
+from util import MODEL_TAGS, build_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(c, dev, precision, share_inputs=True):
+    from autognothi_amd import engine, ops
+    engine.set_precision(precision)
+    recipe = c["recipe"]
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    null = torch.from_numpy(c["null"]).to(dev)
+    masks = torch.from_numpy(c["masks"]).to(dev)
+    ones1 = torch.ones((1, c["P"]), dtype=torch.long, device=dev)
+    onesb = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
+    with torch.no_grad():
+        v_0, _ = recipe.fw_surrogate(srg, null, ones1)
+        xin = xs if share_inputs else torch.repeat_interleave(xs, c["K"], dim=0)
+        v_s, _ = recipe.fw_surrogate(srg, xin, masks)
+        v_1, _ = recipe.fw_surrogate(srg, xs, onesb)
+        edge = torch.stack([torch.zeros(c["P"], dtype=torch.long), torch.ones(c["P"], dtype=torch.long)]).to(dev)
+        v_edge, _ = recipe.fw_surrogate(srg, xs[:1], edge)
+        g = c["g"]
+        phi, extra = recipe.fw_explainer(exp, xs, onesb, torch.from_numpy(g["v_1"]).to(dev), torch.from_numpy(g["v_0"]).to(dev))
+        bits = ops.pack_mask(masks)
+        loss, dphi = ops.shapley_loss(bits, torch.from_numpy(g["v_0"]).to(dev), torch.from_numpy(g["v_s"]).to(dev),
+                                      torch.from_numpy(g["phi"]).to(dev), c["B"], c["K"])
+    out = dict(v_0=v_0, v_s=v_s, v_1=v_1, v_edge=v_edge, phi=phi, loss=loss, dphi=dphi)
+    if extra is not None:
+        out["exp_logits"] = extra
+    return {k: v.float().cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("tag", MODEL_TAGS)
+def test_fp32_matches_reference(cuda_device, tag):
+    c = build_case(tag)
+    got, g = _run(c, cuda_device, "fp32"), c["g"]
+    for k in ("v_0", "v_s", "v_1", "v_edge"):
+        np.testing.assert_allclose(got[k], g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    # Shapley values: 1e-4 rtol of the reference CPU path (+ an absolute floor at 1e-4 of the value scale)
+    scale = float(np.abs(g["phi"]).max())
+    np.testing.assert_allclose(got["phi"], g["phi"], rtol=1e-4, atol=1e-4 * scale)
+    if "exp_logits" in g:
+        np.testing.assert_allclose(got["exp_logits"], g["exp_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got["loss"][0], g["loss"][0], rtol=1e-5)
+    np.testing.assert_allclose(got["dphi"], g["dphi"], rtol=1e-4, atol=3e-6 * max(1.0, float(np.abs(g["dphi"]).max())))
+
+
+@pytest.mark.parametrize("tag", ["vit_tiny_c1", "vit_base_l2", "bert_base_l2"])
+def test_bf16_close_to_reference(cuda_device, tag):
+    """Throughput mode: bf16 operands, fp32 accumulate/residual.  Stated bound: probabilities within 2e-2
+    absolute, Shapley values within 5 % of the value scale (NOT the parity criterion, which is fp32)."""
+    c = build_case(tag)
+    got, g = _run(c, cuda_device, "bf16"), c["g"]
+    for k in ("v_0", "v_s", "v_1"):
+        np.testing.assert_allclose(got[k], g[k], rtol=0, atol=2e-2, err_msg=k)
+    scale = float(np.abs(g["phi"]).max())
+    assert float(np.abs(got["phi"] - g["phi"]).max()) <= 5e-2 * scale
+
+
+@pytest.mark.parametrize("tag", ["vit_tiny_c1", "bert_base_l2"])
+def test_shared_inputs_equal_materialised_copies(cuda_device, tag):
+    """B inputs + R=B*K masks (layer-0 sharing) must give what K materialised copies give (the reference's
+    Xs_EXT, scripts/train_explainer.py:159-163) — bit for bit in fp32."""
+    c = build_case(tag)
+    a = _run(c, cuda_device, "fp32", share_inputs=True)["v_s"]
+    b = _run(c, cuda_device, "fp32", share_inputs=False)["v_s"]
+    np.testing.assert_array_equal(a, b)
+
+
+def test_final_module_coherency(cuda_device):
+    """The reference's own self-check (scripts/train_all.py:166-218): Final's outputs equal its parts' to 1e-5."""
+    from autognothi_amd import engine
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    recipe, cfg, dev = c["recipe"], c["cfg"], cuda_device
+    cls = recipe.t_classifier(cfg)
+    cls.load_state_dict(c["surrogate"].state_dict())
+    cls = cls.to(dev).eval()
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    with torch.no_grad():
+        final = recipe.conv_explainer_final(cfg, None, cls, srg, exp).to(dev).eval()
+        xs = torch.from_numpy(c["xs"]).to(dev)
+        logits, attr = recipe.fw_final(final, xs)
+        ones = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
+        ref_logits, _ = recipe.fw_classifier(cls, xs, ones)
+        grand, _ = recipe.fw_surrogate(srg, xs, ones)
+        ref_attr, _ = recipe.fw_explainer(exp, xs, ones, grand, final.surrogate_null)
+    assert float((logits - ref_logits).abs().max()) <= 1e-5
+    assert float((attr - ref_attr).abs().max()) <= 1e-5
+    np.testing.assert_allclose(final.surrogate_null.cpu().numpy(), c["g"]["v_0"], rtol=1e-4, atol=1e-5)
