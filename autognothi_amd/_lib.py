@@ -57,6 +57,8 @@ SIGNATURES = {
     "ag_shapley_normalize_bwd": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "ag_shapley_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "ag_profile_enable": (i32, [i32]),
+    "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),
     "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
 }

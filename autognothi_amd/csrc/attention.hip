@@ -259,6 +259,9 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32;
     a.nq = (n_query > 0 && n_query < T) ? n_query : T;
     hipStream_t s = (hipStream_t)stream;
+    const double es = dtype == AG_BF16 ? 2.0 : 4.0;
+    AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)a.nq * T * H,
+                     ((double)(R / qkv_share) * T * 3 * H + (double)R * a.nq * H) * es, s);
     if (dtype == AG_BF16) {
         const size_t lds = (size_t)2 * a.Tp * ROWB;
         AG_REQUIRE(lds <= 160 * 1024, "ag_masked_attention: T=%d too long for the single-pass LDS image", T);

@@ -31,3 +31,61 @@ extern "C" int ag_device_info(int device, int* cu_count, char* arch, size_t arch
     }
     return AG_OK;
 }
+
+// ---- per-launch event timing -------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+std::mutex g_prof_mu;
+hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+AgProfScope::AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{kernel_class, flops, bytes, take_event(), take_event()};
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    idx = (int)g_recs.size() - 1;
+}
+AgProfScope::~AgProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_recs[idx].e1, stream);
+}
+
+extern "C" int ag_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return AG_OK;
+}
+
+extern "C" int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : g_recs) {
+        if (r.cls != kernel_class) { keep.push_back(r); continue; }
+        AG_HIP_CHECK(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        AG_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms += t; fl += r.flops; by += r.bytes; ++n;
+        g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    }
+    g_recs.swap(keep);
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (total_bytes) *total_bytes = by;
+    if (launches) *launches = n;
+    return AG_OK;
+}

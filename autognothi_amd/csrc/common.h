@@ -63,3 +63,11 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t dtype_size(int dtype) { return dtype == AG_BF16 ? 2 : 4; }
+
+// ---- optional per-launch event timing (capi.cpp) -------------------------------------------
+struct AgProfScope {
+    int idx;
+    hipStream_t stream;
+    AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s);
+    ~AgProfScope();
+};

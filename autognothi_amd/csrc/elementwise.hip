@@ -199,6 +199,7 @@ extern "C" int ag_layernorm(const float* d_x, int64_t ldx, int rows, int H, cons
     if (rows == 0) return AG_OK;
     const int blocks = ceil_div(rows, 4);
     hipStream_t s = (hipStream_t)stream;
+    AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * (4.0 + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s);
     if (dtype == AG_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
     else if (dtype == AG_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
     else return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);

@@ -244,5 +244,9 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     a.R = d_R; a.ldr = ldr; a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
     hipStream_t s = (hipStream_t)stream;
+    // algorithmic work of this launch: 2*M*N*K flops; bytes = A + W + C (+R) each touched once
+    const double out_es = (epilogue == AG_EPI_BIAS_RESID || epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
+    AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
+                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * 4 : 0.0), s);
     return dtype == AG_BF16 ? dispatch<bf16_t>(epilogue, a, s) : dispatch<float>(epilogue, a, s);
 }

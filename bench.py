@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — masked-forwards/sec of the K-mask surrogate forward (BASELINE.json metric) on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic inputs resident in HBM:
+  device mask sampler (mask_shapley_new, B*K rows) -> masked ViT-base surrogate forward for the
+  B*K rows (K masks share each input's embeddings / layer-0 LN+QKV) -> v_s [B*K, C] on device.
+Workload (config.workload) = BASELINE.json configs[1]: vit_base_imagenette_vanilla, K=32, bf16.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload vit_base|bert_base|vit_large|vit_tiny]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: rows shard by image (each rank owns B images x all K masks; weights replicated; masks
+come from per-rank device generators) — no data-path collective, weak scaling.  Rank 0 prints ONE
+JSON line.  `roofline` is measured live with hipEvents around every launch of the dominant kernel
+inside the timed region; `cpu_baseline` times the numpy oracle on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from autognothi_amd import _lib as L  # noqa: E402
+from autognothi_amd import engine, ops  # noqa: E402
+from autognothi_amd.recipes import get_recipe  # noqa: E402
+from autognothi_amd.utils import synth  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF)
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak, same guide
+
+WORKLOADS = {
+    # name: (recipe kind, experiment params, BASELINE K)
+    "vit_base": ("vanilla_vit", dict(attention_probs_dropout_prob=0.1, explainer_attn_num_layers=1, explainer_head_hidden_size=3072,
+                                     explainer_normalize=True, hidden_dropout_prob=0.1, hidden_size=768, intermediate_size=3072,
+                                     layer_norm_eps=1e-12, num_attention_heads=12, num_hidden_layers=12, num_labels=10,
+                                     img_channels=3, img_px_size=224, img_patch_size=16), 32),
+    "vit_large": ("vanilla_vit", dict(attention_probs_dropout_prob=0.1, explainer_attn_num_layers=1, explainer_head_hidden_size=4096,
+                                      explainer_normalize=True, hidden_dropout_prob=0.1, hidden_size=1024, intermediate_size=4096,
+                                      layer_norm_eps=1e-12, num_attention_heads=16, num_hidden_layers=24, num_labels=10,
+                                      img_channels=3, img_px_size=224, img_patch_size=16), 64),
+    "vit_tiny": ("vanilla_vit", dict(attention_probs_dropout_prob=0.1, explainer_attn_num_layers=1, explainer_head_hidden_size=768,
+                                     explainer_normalize=True, hidden_dropout_prob=0.1, hidden_size=192, intermediate_size=768,
+                                     layer_norm_eps=1e-12, num_attention_heads=3, num_hidden_layers=12, num_labels=10,
+                                     img_channels=3, img_px_size=224, img_patch_size=16), 4),
+    "bert_base": ("vanilla_bert", dict(attention_probs_dropout_prob=0.1, explainer_attn_num_layers=1, explainer_head_hidden_size=3072,
+                                       explainer_normalize=True, hidden_dropout_prob=0.1, hidden_size=768, intermediate_size=3072,
+                                       layer_norm_eps=1e-12, max_position_embeddings=128, num_attention_heads=12,
+                                       num_hidden_layers=12, num_labels=2, pad_token_id=0, type_vocab_size=2, vocab_size=30522), 32),
+}
+
+EPI_NAMES = {0: "gemm<bias>", 1: "gemm<bias+gelu>", 2: "gemm<bias+residual>", 3: "gemm<bias,f32out>", 4: "gemm<bias+tanh>",
+             8: "masked_attention", 9: "layernorm"}
+
+
+def flops_per_forward(kind, p, T):
+    """F_ref: GEMM flops (2/MAC) of one masked forward as the reference executes it (SURVEY.md §8a footer):
+    L*(8TH^2 + 4T^2H + 4THI) + embed + head."""
+    H, I, Lr, C_ = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"], p["num_labels"]
+    f = Lr * (8 * T * H * H + 4 * T * T * H + 4 * T * H * I)
+    if kind == "vanilla_vit":
+        f += 2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H + 2 * H * C_
+    else:
+        f += 2 * H * H + 2 * H * C_
+    return float(f)
+
+
+def flops_executed(kind, p, T, K):
+    """F_exec: F_ref minus work legitimately skipped per row: embed + layer-0 QKV shared across the K masks,
+    last layer's Q-projection/attention/out-proj/MLP on the CLS token only."""
+    H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
+    f = flops_per_forward(kind, p, T)
+    shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind == "vanilla_vit" else 0)
+    f -= shared * (K - 1) / K
+    # last layer: attention for 1 query instead of T, out-proj + MLP for 1 token instead of T (QKV still full)
+    f -= (4 * T * T * H + 2 * T * H * H + 4 * T * H * I) * (T - 1) / T
+    return float(f)
+
+
+def collect(cls):
+    ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+    L.check(L.lib().ag_profile_collect(cls, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+    return ms.value, fl.value, by.value, n.value
+
+
+def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
+    """The numpy oracle ("port") timed on this host's cores over a bounded sample of the same workload."""
+    from oracle import transformer as otr
+    fn = otr.vit_surrogate if kind == "vanilla_vit" else otr.bert_surrogate
+    rows = masks_np.shape[0]
+    xs_ext = np.repeat(xs_np, rows // xs_np.shape[0], axis=0)
+    t0 = time.perf_counter()
+    fn(xs_ext, masks_np, sd_np, params)  # warm-up (BLAS threads, page-in)
+    warm = time.perf_counter() - t0
+    best = warm
+    reps = 0
+    while reps < 3 and (time.perf_counter() - t0) < 25.0:
+        t1 = time.perf_counter()
+        fn(xs_ext, masks_np, sd_np, params)
+        best = min(best, time.perf_counter() - t1)
+        reps += 1
+    return rows / best, rows, reps + 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images (or sequences) per GPU per step")
+    ap.add_argument("--workload", default="vit_base", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run --nproc-per-node N (one process per GPU)")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    kind, params, k_default = WORKLOADS[args.workload]
+    K = args.masks or k_default
+    B = args.batch
+    recipe = get_recipe(kind)
+    cfg = recipe.t_config(**params)
+    P = recipe.n_players(cfg)
+    T = P + 1
+    engine.set_precision(args.precision)
+
+    surrogate = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(surrogate, seed=0)   # random-init weights of the named architecture (no network)
+    surrogate = surrogate.to(dev).eval()
+    if kind == "vanilla_vit":
+        xs_np = synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=rank)
+    else:
+        xs_np = synth.synth_token_ids(B, params["max_position_embeddings"], params["vocab_size"], seed=rank)
+    xs = torch.from_numpy(xs_np).to(dev)
+    rng = ops.DeviceMT19937(dev, 3407 + rank)
+    R = B * K
+
+    def step():
+        _, bits = ops.mask_shapley_new(rng, R, P, want_i64=False, want_bits=True)
+        with torch.no_grad():
+            v_s, _ = recipe.fw_surrogate(surrogate, xs, bits)
+        return v_s
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.check(L.lib().ag_profile_enable(1))
+    for c in EPI_NAMES:
+        collect(c)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.check(L.lib().ag_profile_enable(0))
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+
+    stats = {c: collect(c) for c in EPI_NAMES}
+    if rank == 0:
+        total_rows = R * world * args.steps
+        value = total_rows / elapsed
+        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K)
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        # dominant kernel = the instrumented class with the largest total time
+        dom = max(stats, key=lambda c: stats[c][0])
+        ms, fl, by, n = stats[dom]
+        per_kernel = {EPI_NAMES[c]: {"launches": int(s[3]), "avg_us": round(1e3 * s[0] / max(1, s[3]), 2),
+                                     "tflops": round(s[1] / max(s[0], 1e-9) / 1e9, 1),
+                                     "algo_gb_s": round(s[2] / max(s[0], 1e-9) / 1e6, 1)}
+                      for c, s in stats.items() if s[3]}
+        roofline = {
+            "bound": "mfma", "kernel": EPI_NAMES[dom], "launches": int(n), "avg_launch_us": round(1e3 * ms / max(1, n), 2),
+            "achieved": round(fl / max(ms, 1e-9) / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": None,
+            "whole_step": {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
+                           "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
+                           "exec_tflops": round(value / world * f_exec / 1e12, 1),
+                           "exec_frac_of_peak": round(value / world * f_exec / 1e12 / peak, 4)},
+            "kernels": per_kernel,
+        }
+        line = {
+            "metric": "masked-forwards/sec (K=%d)" % K, "value": round(value, 2), "unit": "masked-forwards/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": {"vit_base": "vit_base_imagenette_vanilla", "vit_large": "vit_large_imagenette_vanilla",
+                                    "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128"}[args.workload],
+                       "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_step": R * world, "tokens": T,
+                       "sharding": "rows by input, no data-path collective", "weights": "seeded random init"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_b = 1
+            masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()
+            sd_np = {k: v.detach().cpu().numpy() for k, v in surrogate.state_dict().items()}
+            cpu_v, cpu_rows, cpu_reps = cpu_baseline(kind, params, xs_np[:sample_b], masks_np, sd_np)
+            line["cpu_baseline"] = {"value": round(cpu_v, 2), "unit": "masked-forwards/s", "cores": os.cpu_count(),
+                                    "kind": "port",
+                                    "sample": f"numpy fp32 oracle, {cpu_rows} rows (1 input x K={K}) of the same workload, best of {cpu_reps}"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

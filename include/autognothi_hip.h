@@ -191,6 +191,17 @@ int ag_encoder_forward(const ag_encoder_desc* desc, const float* d_h0, int R, in
                        const uint32_t* d_mask_bits, float* d_h, int cls_only_last,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * In-library kernel timing (used by bench.py for the roofline block): when enabled, every launch of
+ * an instrumented kernel class is bracketed by hipEvents on the launch stream.  ag_profile_collect
+ * synchronises those events, returns the totals of one class since the last collect and clears it.
+ * Classes: 0..4 = ag_gemm by epilogue (AG_EPI_*), 8 = ag_masked_attention, 9 = ag_layernorm.
+ * ---------------------------------------------------------------------------------------------- */
+#define AG_PROF_ATTENTION 8
+#define AG_PROF_LAYERNORM 9
+int ag_profile_enable(int on);
+int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,9 +276,33 @@ def gen_models():
     gen_model_fixture("froyo_bert_base_l2", r_fbert.froyo_bert_recipe, fbert, "bert", B=2, K=4, mask_seed=3407, froyo=True)
 
 
+def gen_state_keys():
+    """state-dict key -> shape of every reference class on the path (names + shapes only)."""
+    import reference.recipes.duo_vanilla_vit, reference.recipes.froyo_vit  # noqa: F401
+    tiny = hparams("vit_tiny_imagenette_vanilla")
+    bert = dict(hparams("bert_base_tayp_vanilla"), num_hidden_layers=1, max_position_embeddings=128)
+    table = {"vanilla_vit": (r_vvit.vanilla_vit_recipe, tiny), "duo_vanilla_vit": (r_dvit.duo_vanilla_vit_recipe, tiny),
+             "froyo_vit": (r_fvit.froyo_vit_recipe, tiny), "vanilla_bert": (r_vbert.vanilla_bert_recipe, bert),
+             "duo_vanilla_bert": (r_dbert.duo_vanilla_bert_recipe, bert), "froyo_bert": (r_fbert.froyo_bert_recipe, bert)}
+    out = {}
+    for kind, (fn, params) in table.items():
+        rec = fn()
+        cfg = rec.t_config(**params)
+        out[kind] = {"params": params, "roles": {
+            role: {k: list(v.shape) for k, v in getattr(rec, "t_" + role)(cfg).state_dict().items()}
+            for role in ("classifier", "surrogate", "explainer", "final")}}
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote state_keys.json")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "state_keys":
+        gen_state_keys()
+        sys.exit(0)
     seeds = gen_seeds()
     gen_masks(seeds)
     gen_shapley_fns()
     gen_perturbed()
     gen_models()
+    gen_state_keys()

@@ -1,0 +1,81 @@
+"""CPU: host-side logic that needs no GPU — state-dict converters, seeding, recipe registry, the state-dict
+layout contract and FLOP accounting."""
+import os
+
+import pytest
+import torch
+
+from util import golden_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_iterative_seed_matches_reference_fixture():
+    from autognothi_amd.utils.tools import derive_seed, set_iterative_seed
+    g = golden_json("iterative_seeds.json")
+    for key, val in g["derived"].items():
+        assert derive_seed(g["master"], key) == val
+    s = set_iterative_seed(3407, "train_explainer[epoch=1]")
+    assert s == torch.initial_seed()
+
+
+def test_merge_rules():
+    from autognothi_amd.utils.nnmodel import New, merge_items
+    src = {"a.0.w": 1, "a.1.w": 2, "b.x": 3, "c": 4}
+    out = merge_items([({"a.{i}.w": "z.{i}.weight", "b.{_}": None, "c": [..., "c2"]}, src)],
+                      {"z.0.weight": 0}, duplicate_action=lambda v: v * 10)
+    assert out == {"z.0.weight": 1, "z.1.weight": 2, "c": 4, "c2": 40}
+    with pytest.raises(ValueError):  # destination key neither produced nor declared New
+        merge_items([({"a.{i}.w": ..., "b.{_}": None, "c": ...}, src)], {"fresh.k": 9}, lambda v: v)
+    out = merge_items([({"a.{i}.w": ..., "b.{_}": None, "c": ..., New(): "fresh.{_}"}, src)], {"fresh.k": 9}, lambda v: v)
+    assert out["fresh.k"] == 9 and out["a.1.w"] == 2 and "b.x" not in out
+    with pytest.raises(ValueError):  # unmatched source key
+        merge_items([({"a.{i}.w": ...}, src)], {}, lambda v: v)
+
+
+def test_state_dict_layout_contract():
+    """Key names/shapes recorded from the reference classes (tests/golden/state_keys.json)."""
+    from autognothi_amd.recipes import get_recipe
+    g = golden_json("state_keys.json")
+    for kind, entry in g.items():
+        recipe = get_recipe(kind)
+        cfg = recipe.t_config(**entry["params"])
+        for role, want in entry["roles"].items():
+            mod = getattr(recipe, "t_" + role)(cfg)
+            got = {k: list(v.shape) for k, v in mod.state_dict().items()}
+            assert got == want, (kind, role)
+
+
+def test_converters_round_trip_on_cpu_weights():
+    """conv_classifier_surrogate / conv_surrogate_explainer keep the backbone and add fresh heads."""
+    from autognothi_amd.recipes import get_recipe
+    g = golden_json("state_keys.json")
+    for kind in ("vanilla_vit", "froyo_vit", "duo_vanilla_vit"):
+        recipe = get_recipe(kind)
+        cfg = recipe.t_config(**g[kind]["params"])
+        cls = recipe.t_classifier(cfg)
+        srg = recipe.conv_classifier_surrogate(cfg, None, cls)
+        exp = recipe.conv_surrogate_explainer(cfg, None, srg)
+        a, b, c = cls.state_dict(), srg.state_dict(), exp.state_dict()
+        for k in a:
+            assert torch.equal(a[k], b[k])
+            if k.startswith("vit."):
+                assert torch.equal(a[k], c[k])
+        with pytest.raises(RuntimeError):  # forward has no CPU path
+            with torch.no_grad():
+                recipe.fw_surrogate(srg, torch.zeros(1, 3, cfg.img_px_size, cfg.img_px_size), torch.ones(1, recipe.n_players(cfg), dtype=torch.long))
+
+
+def test_recipe_registry():
+    from autognothi_amd.recipes import get_recipe
+    assert get_recipe("vanilla_vit").id == "vanilla_bert"  # the reference's own copy-paste id (recipes/vanilla_vit.py:37)
+    with pytest.raises(ValueError):
+        get_recipe("ltt_vit")
+
+
+def test_flop_accounting_matches_survey():
+    import bench
+    for name, want in (("vit_base", 35.13e9), ("vit_tiny", 2.507e9), ("vit_large", 123.1e9), ("bert_base", 22.35e9)):
+        kind, params, _ = bench.WORKLOADS[name]
+        t = 197 if "vit" in name else 128
+        assert abs(bench.flops_per_forward(kind, params, t) - want) / want < 2e-3
