@@ -50,6 +50,17 @@ template <> struct Store<bf16_t> {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+__device__ __forceinline__ float fast_gelu(float x) {
+    // GELU with erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): cheap enough not to dominate the epilogue
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f); p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -71,3 +82,9 @@ struct AgProfScope {
     AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s);
     ~AgProfScope();
 };
+
+// gemm_big.hip
+bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
+int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                const float* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
+                hipStream_t s);

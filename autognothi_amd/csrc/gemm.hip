@@ -19,6 +19,7 @@
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs get contiguous tile ranges, N-tiles fastest,
 //     so the blocks that share one A row-panel run on one XCD and hit its L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
             }
             if (EPI == AG_EPI_BIAS_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? fast_gelu(v[j]) : gelu_erf(v[j]);  // bf16 mode: |erf err| <= 1.5e-7
             }
             if (EPI == AG_EPI_BIAS_TANH) {
 #pragma unroll
@@ -248,5 +249,8 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     const double out_es = (epilogue == AG_EPI_BIAS_RESID || epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * 4 : 0.0), s);
+    static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
+    if (dtype == AG_BF16 && !force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue))
+        return ag_gemm_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue, s);
     return dtype == AG_BF16 ? dispatch<bf16_t>(epilogue, a, s) : dispatch<float>(epilogue, a, s);
 }
