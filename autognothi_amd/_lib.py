@@ -46,7 +46,7 @@ SIGNATURES = {
     "ag_pack_mask": (i32, [vp, i32, i32, vp, vp]),
     "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
-    "ag_layernorm": (i32, [vp, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
+    "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
     "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),

@@ -48,6 +48,13 @@ template <> struct Store<bf16_t> {
     static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// 4 consecutive stream elements -> fp32
+__device__ __forceinline__ float4 load4_as_f32(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4_as_f32(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float fast_gelu(float x) {
@@ -86,5 +93,5 @@ struct AgProfScope {
 // gemm_big.hip
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
-                const float* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
+                const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
                 hipStream_t s);

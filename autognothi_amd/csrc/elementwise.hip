@@ -19,22 +19,22 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
 // torch.nn.LayerNorm: biased variance, y = (x-mean)*rsqrt(var+eps)*g + b.  One wave per row; the row
 // is held in registers (H <= 64*4*MAXV floats) so x is read from HBM exactly once.
 constexpr int LN_MAXV = 8;  // supports H up to 2048
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int rows, int H,
+template <typename XT, typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, int64_t ldx, int rows, int H,
                                                         const float* __restrict__ g, const float* __restrict__ b,
                                                         float eps, T* __restrict__ ys, float* __restrict__ yf) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (int64_t)row * ldx;
+    const XT* xr = x + (int64_t)row * ldx;
     float4 v[LN_MAXV];
     float sum = 0.f;
-    const int nv = H >> 2;  // float4 per row
+    const int nv = H >> 2;  // 4-element groups per row
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            v[i] = load4_as_f32(xr + c * 4);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -192,17 +192,25 @@ extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype
     return AG_OK;
 }
 
-extern "C" int ag_layernorm(const float* d_x, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
+extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
                             float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream) {
     AG_REQUIRE(d_x && d_gamma && d_beta && (d_y_store || d_y_f32), "ag_layernorm: null pointer");
     AG_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAXV && ldx % 4 == 0, "ag_layernorm: H=%d unsupported (multiple of 4, <= %d)", H, 64 * 4 * LN_MAXV);
     if (rows == 0) return AG_OK;
     const int blocks = ceil_div(rows, 4);
     hipStream_t s = (hipStream_t)stream;
-    AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * (4.0 + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s);
-    if (dtype == AG_BF16) hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
-    else if (dtype == AG_F32) hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, s, d_x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
-    else return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
+    AG_REQUIRE(x_dtype == AG_F32 || x_dtype == AG_BF16, "ag_layernorm: bad x_dtype %d", x_dtype);
+    AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * ((double)dtype_size(x_dtype) + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s);
+    if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
+    if (x_dtype == AG_F32) {
+        const float* x = (const float*)d_x;
+        if (dtype == AG_BF16) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
+        else hipLaunchKernelGGL((layernorm_kernel<float, float>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
+    } else {
+        const bf16_t* x = (const bf16_t*)d_x;
+        if (dtype == AG_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
+        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
+    }
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -9,20 +9,21 @@
 //     embeddings, layer 0's LayerNorm + QKV projection (computed for B rows, not R) and its
 //     residual; divergence starts at layer 0's masked soft-max.
 //   * q/k/v are one [3H,H] GEMM; bias+GELU, bias+residual are GEMM epilogues; the score tensor is
-//     never materialised.
-//   * with cls_only_last the last layer's out-projection / MLP run on the CLS token only (the only
-//     row the surrogate/classifier heads read, models/vanilla_vit.py:54).
+//     never materialised; the residual stream lives in the storage dtype so a LayerNorm output is at
+//     once the next GEMM's operand and (BERT) the next residual.
+//   * with cls_only_last the last layer's attention / out-projection / MLP run on the CLS token only
+//     (the only row the surrogate/classifier heads read, models/vanilla_vit.py:54).
 #include "common.h"
 
 namespace {
 
 struct Ws {
-    char* xs;      // storage [M, H]
-    char* qkv;     // storage [M, 3H]
-    char* ctx;     // storage [M, H]
-    char* inter;   // storage [M, I]
-    float* hx;     // fp32 [M, H]
-    float* ha;     // fp32 [M, H]  (BERT: post-attention LN output)
+    char* xs;      // [M, H]   LayerNorm output (GEMM operand)
+    char* qkv;     // [M, 3H]
+    char* ctx;     // [M, H]
+    char* inter;   // [M, I]
+    char* hx;      // [M, H]   residual stream after the attention block
+    char* ha;      // [M, H]   BERT: post-attention LayerNorm output
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -36,9 +37,9 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* qkv = take(M * 3 * d->H * es);
     char* ctx = take(M * d->H * es);
     char* inter = take(M * d->I * es);
-    char* hx = take(M * d->H * 4);
-    char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * 4) : nullptr;
-    if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = (float*)hx; ws->ha = (float*)ha; }
+    char* hx = take(M * d->H * es);
+    char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * es) : nullptr;
+    if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; }
     return off;
 }
 
@@ -51,8 +52,8 @@ extern "C" size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R)
     return carve(desc, R, nullptr, nullptr);
 }
 
-extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const float* d_h0, int R, int share,
-                                  const uint32_t* d_mask_bits, float* d_h, int cls_only_last,
+extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, int R, int share,
+                                  const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
                                   void* d_workspace, size_t workspace_bytes, void* stream) {
     AG_REQUIRE(d && d_h0 && d_mask_bits && d_h && d_workspace, "ag_encoder_forward: null pointer");
     AG_REQUIRE(d->kind == AG_MASK_VIT_MUL || d->kind == AG_MASK_BERT_ADD, "ag_encoder_forward: bad kind %d", d->kind);
@@ -64,63 +65,57 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const float* d_h0, i
     Ws ws;
     carve(d, R, (char*)d_workspace, &ws);
     const int T = d->T, H = d->H, I = d->I, dt = d->dtype;
+    const size_t es = dtype_size(dt);
     const int M = R * T;
     const bool vit = d->kind == AG_MASK_VIT_MUL;
 
-    const float* h_in = d_h0;  // fp32 residual stream entering the layer
-    int in_share = share;      // how many rows share one h_in sequence
-    bool xs_ready = false;     // ws.xs already holds the storage-dtype copy of h_in (BERT, written by the previous LN2)
+    const char* h_in = (const char*)d_h0;  // residual stream entering the layer (storage dtype)
+    int in_share = share;                  // how many rows share one h_in sequence
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         const bool last_cls = cls_only_last && (l == d->n_layers - 1);
         const int Min = (R / in_share) * T;  // distinct rows entering this layer
-        // -- attention input: ViT LN1(h_in) (pre-LN) / BERT h_in itself --
-        if (vit && w.ln1_g) TRY(ag_layernorm(h_in, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, stream));
-        else if (!xs_ready) TRY(ag_cast_f32(h_in, ws.xs, (int64_t)Min * H, dt, stream));
-        xs_ready = false;
-        TRY(ag_gemm(ws.xs, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt, stream));
+        // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
+        const char* att_in = h_in;
+        if (vit && w.ln1_g) {
+            TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+            att_in = ws.xs;
+        }
+        TRY(ag_gemm(att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt, stream));
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
         // rows processed after attention: all tokens, or only token 0 of each row
         const int Mo = last_cls ? R : M;
-        const int Tq = last_cls ? 1 : T;                 // tokens per sequence in the compact view
-        const int64_t ld_tok = last_cls ? (int64_t)T * H : H;  // stride between consecutive processed rows in [R,T,H] buffers
-        // -- out-projection + residual(h_in) --
+        const int Tq = last_cls ? 1 : T;                         // tokens per sequence in the processed view
+        const int64_t ld_tok = last_cls ? (int64_t)T * H : H;    // stride between processed rows inside [R,T,H] buffers
+        // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
         TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt, stream));
-        const float* mlp_resid;
         if (vit) {
-            TRY(ag_layernorm(ws.hx, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, stream));
-            mlp_resid = ws.hx;
+            TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+            TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, stream));
+            // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
+            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
         } else {
+            const char* a = ws.hx;  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
             if (w.ln1_g) {
-                TRY(ag_layernorm(ws.hx, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, ws.ha, dt, stream));
-                mlp_resid = ws.ha;
-            } else {  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
-                TRY(ag_cast_f32(ws.hx, ws.xs, (int64_t)Mo * H, dt, stream));
-                mlp_resid = ws.hx;
+                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+                a = ws.ha;
             }
-        }
-        TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, stream));
-        if (vit) {
-            // h_out = fc2(inter) + h_mid  -> d_h (strided to token 0 when cls-only)
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, mlp_resid, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
-        } else {
-            float* pre = (mlp_resid == ws.hx) ? ws.ha : ws.hx;  // must not alias the residual being read by other rows' tiles
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, mlp_resid, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
+            TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, stream));
+            char* pre = (a == ws.hx) ? ws.ha : ws.hx;
+            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
             AG_REQUIRE(w.ln2_g, "ag_encoder_forward: BERT output.LayerNorm missing in layer %d", l);
             if (last_cls) {
-                // LN rows are compact [R,H]; write fp32 into token 0 of d_h via a compact temp then strided copy
-                TRY(ag_layernorm(pre, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, nullptr, (float*)ws.ctx, dt, stream));
-                hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * 4, ws.ctx, (size_t)H * 4, (size_t)H * 4, (size_t)R,
+                // LayerNorm the compact [R,H] rows, then scatter them to token 0 of d_h
+                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
+                hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R,
                                                 hipMemcpyDeviceToDevice, (hipStream_t)stream);
                 if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
             } else {
-                // also leave the storage-dtype copy in ws.xs: it is the next layer's QKV operand
-                TRY(ag_layernorm(pre, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, d_h, dt, stream));
-                xs_ready = true;
+                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, d_h, nullptr, dt, stream));
             }
         }
-        h_in = d_h;
+        h_in = (const char*)d_h;
         in_share = 1;
     }
     return AG_OK;

@@ -32,7 +32,7 @@ struct GemmArgs {
     const char* W; long ldw_b;
     const float* bias;
     char* C; long ldc;          // element stride
-    const float* R; long ldr;
+    const void* R; long ldr;  // residual, storage dtype
     int T, share;
     int M, N, K;
 };
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15) per sub-tile ----
-    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_F32 || sizeof(T) == 4);
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32 || sizeof(T) == 4);
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (EPI != AG_EPI_BIAS_RESID || (p.ldr & 3) == 0);
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
                 if (EPI == AG_EPI_BIAS_RESID) {
-                    const float4 rv = *reinterpret_cast<const float4*>(p.R + rrow * p.ldr + n);
+                    const float4 rv = load4_as_f32(reinterpret_cast<const T*>(p.R) + rrow * p.ldr + n);
                     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
                 }
             } else {
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     if (n + j < p.N) {
                         if (p.bias) v[j] += p.bias[n + j];
-                        if (EPI == AG_EPI_BIAS_RESID) v[j] += p.R[rrow * p.ldr + n + j];
+                        if (EPI == AG_EPI_BIAS_RESID) v[j] += Store<T>::load(reinterpret_cast<const T*>(p.R) + rrow * p.ldr + n + j);
                     }
                 }
             }
@@ -227,7 +227,7 @@ int dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
-                       const float* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
+                       const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
                        int epilogue, int dtype, void* stream) {
     AG_REQUIRE(d_A && d_W && d_C, "ag_gemm: null pointer");
     AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
@@ -246,9 +246,9 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     a.M = M; a.N = N; a.K = K;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic work of this launch: 2*M*N*K flops; bytes = A + W + C (+R) each touched once
-    const double out_es = (epilogue == AG_EPI_BIAS_RESID || epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
+    const double out_es = (epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
-                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * 4 : 0.0), s);
+                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * es : 0.0), s);
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
     if (dtype == AG_BF16 && !force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue))
         return ag_gemm_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue, s);

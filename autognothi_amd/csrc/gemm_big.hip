@@ -31,7 +31,7 @@ struct BigArgs {
     const char* W; long ldw_b;
     const float* bias;
     char* C; long ldc;
-    const float* R; long ldr;
+    const bf16_t* R; long ldr;
     int T, share;
     int M, N, K;
 };
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
 
     // ---- epilogue (same lane -> (n, m) map as gemm.hip) ----
     const int frow = lane & 15, fq = lane >> 4;
-    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_F32);
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
 #pragma unroll
     for (int sm = 0; sm < 8; ++sm) {
         const int m = m0 + wm * 128 + sm * 16 + frow;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             }
             if (EPI == AG_EPI_BIAS_RESID) {
-                const float4 rv = *reinterpret_cast<const float4*>(p.R + rrow * p.ldr + n);
+                const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
                 v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
             }
             if (EPI == AG_EPI_BIAS_GELU) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tile_kernel(BigArgs p) {
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
-    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_F32);
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
 #pragma unroll
     for (int sm = 0; sm < SM_; ++sm) {
         const int m = m0 + wm * TM + sm * 16 + frow;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_tile_kernel(BigArgs p) {
                 v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
             }
             if (EPI == AG_EPI_BIAS_RESID) {
-                const float4 rv = *reinterpret_cast<const float4*>(p.R + rrow * p.ldr + n);
+                const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
                 v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
             }
             if (EPI == AG_EPI_BIAS_GELU) {
@@ -357,12 +357,12 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 }
 
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
-                const float* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
+                const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
                 hipStream_t s) {
     BigArgs a;
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
     a.W = (const char*)d_W; a.ldw_b = (long)K * 2;
-    a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = d_R; a.ldr = ldr;
+    a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = (const bf16_t*)d_R; a.ldr = ldr;
     a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
     static const int env_variant = getenv("AG_GEMM_VARIANT") ? atoi(getenv("AG_GEMM_VARIANT")) : 0;

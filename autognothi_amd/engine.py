@@ -123,11 +123,13 @@ class PackedEncoder:
         return d
 
     def forward(self, h0: Tensor, rows: int, share: int, mask_bits: Tensor, cls_only_last: bool, dtype: int) -> Tensor:
-        """h0 fp32 [rows/share, T, H] -> hidden fp32 [rows, T, H]."""
+        """h0 [rows/share, T, H] -> hidden [rows, T, H], both in the storage dtype (the residual stream)."""
         L.require_gpu(h0, mask_bits)
-        assert h0.dtype == torch.float32 and h0.is_contiguous()
+        if h0.dtype != ops.storage_dtype(dtype):
+            h0 = ops.cast(h0, dtype)
+        h0 = h0.contiguous()
         d = self.desc(dtype)
-        out = torch.empty((rows, self.T, self.H), dtype=torch.float32, device=h0.device)
+        out = torch.empty((rows, self.T, self.H), dtype=ops.storage_dtype(dtype), device=h0.device)
         with torch.cuda.device(h0.device):
             need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
             ws = WORKSPACE.get(h0.device, need)

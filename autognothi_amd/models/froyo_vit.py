@@ -80,9 +80,9 @@ class FroyoViTFinal(_ExplainerHead, ObservableModuleMixin):
         dtype = engine.get_precision()
         bits = engine.to_mask_bits(attention_mask, self.vit.n_players)
         hidden, rows = self.vit.run(x, bits, cls_only=False)
-        zs, zf = self.vit.final_norm(hidden, rows, False, dtype, want_f32=True)
+        zs, _ = self.vit.final_norm(hidden, rows, False, dtype, want_f32=False)
         t, h = self.vit.n_players + 1, self.config.hidden_size
-        z = zf.view(rows, t, h)
+        z = zs.view(rows, t, h)
         self.om_record_features(repr_cls=z, repr_srg=z, repr_exp=z)
         if self._heads is None:
             self._heads = (engine.PackedLinear([self.classifier.weight], [self.classifier.bias]),

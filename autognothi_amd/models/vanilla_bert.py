@@ -202,8 +202,8 @@ class _BertHead:
                                  engine.PackedLinear([classifier.weight], [classifier.bias]))
         pl, cl = cache[cache_name]
         h = hidden.shape[-1]
-        x = ops.cast(hidden.view(rows, t, h)[:, 0, :], dtype)  # CLS rows -> storage dtype [R,H]
-        pooled = engine.linear_head(x, h, rows, pl, L.AG_EPI_BIAS_TANH, dtype)
+        # CLS rows of the [R,T,H] stream read in place (row stride T*H)
+        pooled = engine.linear_head(hidden, t * h, rows, pl, L.AG_EPI_BIAS_TANH, dtype)
         logits = engine.linear_head(pooled, h, rows, cl, L.AG_EPI_BIAS_F32, dtype)
         return ops.softmax_rows(logits) if act else logits
 
@@ -268,8 +268,7 @@ class _BertExplainerHead(nn.Module):
             m = self.explainer_mlp
             self._mlp_packed = [engine.PackedLinear([m[i].weight], [m[i].bias]) for i in (0, 2, 4)]
         o = self._attn_packed[t].forward(z.contiguous(), rows, 1, bits, False, dtype) if len(self.explainer_attn) else z
-        xs = ops.cast(o, dtype).view(rows * t, h)
-        xs = engine.linear_head(xs, h, rows * t, self._mlp_packed[0], L.AG_EPI_BIAS_GELU, dtype)
+        xs = engine.linear_head(o, h, rows * t, self._mlp_packed[0], L.AG_EPI_BIAS_GELU, dtype)
         xs = engine.linear_head(xs, xs.shape[1], rows * t, self._mlp_packed[1], L.AG_EPI_BIAS_GELU, dtype)
         pred = engine.linear_head(xs, xs.shape[1], rows * t, self._mlp_packed[2], L.AG_EPI_BIAS_F32, dtype)
         pred = pred.view(rows, t, config.num_labels)

@@ -196,9 +196,9 @@ class VanillaViTModel(nn.Module):
         return ops.layernorm(hidden, g, bta, self.config.layer_norm_eps, dtype, rows=rows * t, ldx=h, want_f32=want_f32)
 
     def forward(self, pixel_values: Tensor, attention_mask: Tensor) -> Tensor:
-        """reference :207-214 -> LN_final(hidden) fp32 [R,T,H]."""
+        """reference :207-214 -> LN_final(hidden) [R,T,H] in the storage dtype."""
         hidden, rows = self.run(pixel_values, attention_mask, cls_only=False)
-        _, z = self.final_norm(hidden, rows, False, engine.get_precision(), want_f32=True)
+        z, _ = self.final_norm(hidden, rows, False, engine.get_precision(), want_f32=False)
         return z.view(rows, self.n_players + 1, self.config.hidden_size)
 
 
@@ -233,9 +233,9 @@ class VanillaViTClassifier(nn.Module, ObservableModuleMixin):
         observing = self.om_is_observing()
         hidden, rows = self.vit.run(x, attention_mask, cls_only=not observing)
         if observing:
-            zs, zf = self.vit.final_norm(hidden, rows, False, dtype, want_f32=True)
+            zs, _ = self.vit.final_norm(hidden, rows, False, dtype, want_f32=False)
             t, h = self.vit.n_players + 1, self.config.hidden_size
-            self.om_record_features(repr_cls=zf.view(rows, t, h))
+            self.om_record_features(repr_cls=zs.view(rows, t, h))
             z_cls, lda = zs, t * h
         else:
             z_cls, _ = self.vit.final_norm(hidden, rows, True, dtype, want_f32=False)
@@ -269,7 +269,7 @@ class _ExplainerHead(nn.Module):
         self._mlp_packed: Optional[List[engine.PackedLinear]] = None
 
     def _run_head(self, z: Tensor, bits: Tensor, rows: int, surrogate_grand, surrogate_null, config, dtype: int) -> Tensor:
-        """z = LN_final(backbone) fp32 [rows,T,H] -> phi [rows, C, P]  (reference :120-129)."""
+        """z = LN_final(backbone) [rows,T,H] (storage dtype) -> phi [rows, C, P]  (reference :120-129)."""
         t, h = z.shape[1], z.shape[2]
         if self._attn_packed is None:
             self._attn_packed = engine.PackedEncoder(self.explainer_attn, L.AG_MASK_VIT_MUL, t, h, config.intermediate_size,

@@ -161,15 +161,18 @@ def cast(src: Tensor, dtype: int) -> Tensor:
 
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, rows: Optional[int] = None,
               ldx: Optional[int] = None, want_store: bool = True, want_f32: bool = False):
-    """x fp32 [..., H] (or a strided view described by rows/ldx)."""
+    """x [..., H] fp32 or bf16 (or a strided view described by rows/ldx); statistics in fp32."""
     L.require_gpu(x, gamma, beta)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"layernorm: unsupported input dtype {x.dtype}")
+    x_dtype = F32 if x.dtype == torch.float32 else BF16
     h = gamma.numel()
     rows = x.numel() // h if rows is None else rows
     ldx = h if ldx is None else ldx
     ys = torch.empty((rows, h), dtype=storage_dtype(dtype), device=x.device) if want_store else None
     yf = torch.empty((rows, h), dtype=torch.float32, device=x.device) if want_f32 else None
     with torch.cuda.device(x.device):
-        L.check(L.lib().ag_layernorm(L.ptr(x), ldx, rows, h, L.ptr(gamma), L.ptr(beta), eps, L.ptr(ys), L.ptr(yf),
+        L.check(L.lib().ag_layernorm(L.ptr(x), x_dtype, ldx, rows, h, L.ptr(gamma), L.ptr(beta), eps, L.ptr(ys), L.ptr(yf),
                                      dtype, L.stream()))
     return ys, yf
 
@@ -177,12 +180,16 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, ro
 def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int, m: Optional[int] = None,
          lda: Optional[int] = None, resid: Optional[Tensor] = None, ldr: Optional[int] = None,
          rows_per_seq: int = 1, resid_share: int = 1, out: Optional[Tensor] = None, ldc: Optional[int] = None) -> Tensor:
-    """epilogue(A[M,K] @ W[N,K]^T + bias).  a, w in the storage dtype; bias / resid fp32."""
+    """epilogue(A[M,K] @ W[N,K]^T + bias).  a, w, resid in the storage dtype; bias fp32.  Output: fp32 for
+    AG_EPI_BIAS_F32, else the storage dtype."""
     L.require_gpu(a, w, bias, resid, out)
     n, k = w.shape
     m = a.numel() // k if m is None else m
     lda = k if lda is None else lda
-    out_f32 = epilogue in (L.AG_EPI_BIAS_RESID, L.AG_EPI_BIAS_F32) or dtype == F32
+    out_f32 = epilogue == L.AG_EPI_BIAS_F32 or dtype == F32
+    for t_ in (a, w, resid):
+        if t_ is not None and t_.dtype != storage_dtype(dtype):
+            raise TypeError(f"gemm: operand dtype {t_.dtype} does not match storage dtype {storage_dtype(dtype)}")
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32 if out_f32 else storage_dtype(dtype), device=a.device)
     ldc = n if ldc is None else ldc

@@ -12,8 +12,8 @@
  * maintainer would add to call them from recipes/<kind>.py / models/shapley.py.
  *
  * Storage dtypes (AG_BF16 / AG_F32) select what GEMM operands and inter-kernel activations are
- * stored in; accumulation, LayerNorm statistics, soft-max and the residual stream are fp32 in
- * both modes.  AG_F32 runs the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) and is the mode the
+ * stored in; accumulation, LayerNorm statistics and soft-max are fp32 in
+ * both modes; the residual stream itself is kept in the storage dtype.  AG_F32 runs the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) and is the mode the
  * 1e-4 Shapley-value parity criterion is checked in; AG_BF16 is the throughput mode.
  */
 #ifndef AUTOGNOTHI_HIP_H_
@@ -37,7 +37,7 @@ enum { AG_MASK_VIT_MUL = 0, AG_MASK_BERT_ADD = 1 };
 enum {
     AG_EPI_BIAS = 0,        /* C = A·Wᵀ + b                     -> storage dtype            */
     AG_EPI_BIAS_GELU = 1,   /* C = gelu_erf(A·Wᵀ + b)           -> storage dtype            */
-    AG_EPI_BIAS_RESID = 2,  /* C = A·Wᵀ + b + R                 -> fp32 (residual stream)   */
+    AG_EPI_BIAS_RESID = 2,  /* C = A·Wᵀ + b + R   (R, C: storage dtype = the residual stream) */
     AG_EPI_BIAS_F32 = 3,    /* C = A·Wᵀ + b                     -> fp32                     */
     AG_EPI_BIAS_TANH = 4,   /* C = tanh(A·Wᵀ + b)               -> storage dtype (pooler)   */
     AG_EPI_BIAS_GELU_F32 = 5 /* reserved */
@@ -91,19 +91,20 @@ int ag_perturbed_masks(const float* d_attr, int n_attr, int n_players, int steps
 int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream);
 
 /* torch.nn.LayerNorm over the last dim (reference call sites models/vanilla_vit.py:353-362,:205;
- * models/vanilla_bert.py:323,:559,:603).  x fp32 [rows, H] with row stride ldx (elements);
- * y_store (storage dtype, stride H) and/or y_f32 (stride H) may be NULL. */
-int ag_layernorm(const float* d_x, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
+ * models/vanilla_bert.py:323,:559,:603).  x [rows, H] of dtype x_dtype (AG_F32 / AG_BF16) with row
+ * stride ldx (elements); statistics in fp32; y_store (storage dtype, stride H) and/or y_f32
+ * (stride H) may be NULL. */
+int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
                  float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream);
 
 /* C[M,N] = epilogue(A[M,K] · W[N,K]ᵀ + bias[N]) — every nn.Linear on the path (q/k/v fused into
  * one [3H,H] weight: models/vanilla_vit.py:422-424; :477; :491; :510).  A, W in storage dtype
- * (A row stride lda, W dense [N,K]); bias fp32.  For AG_EPI_BIAS_RESID, R is fp32 with row stride
- * ldr and row index ((m / T) / resid_share) * T + m % T  (T = rows_per_seq; resid_share > 1 lets
+ * (A row stride lda, W dense [N,K]); bias fp32.  For AG_EPI_BIAS_RESID, R is in the storage dtype with
+ * row stride ldr and row index ((m / T) / resid_share) * T + m % T  (T = rows_per_seq; resid_share > 1 lets
  * the K masked copies of one input share the layer-0 residual).  K % 64 == 0 (bf16) / K % 32 == 0
  * (fp32) required; N, M arbitrary. */
 int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
-            const float* d_R, int64_t ldr, int rows_per_seq, int resid_share,
+            const void* d_R, int64_t ldr, int rows_per_seq, int resid_share,
             int M, int N, int K, int epilogue, int dtype, void* stream);
 
 /* Fused masked multi-head attention (reference models/vanilla_vit.py:436-465,
@@ -182,13 +183,14 @@ typedef struct ag_encoder_desc {
 /* bytes of workspace ag_encoder_forward needs for R rows. */
 size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R);
 /* Run the encoder stack (reference models/vanilla_vit.py:315-320 / models/vanilla_bert.py:362-367)
- * over R rows that share B = R / share distinct inputs: d_h0 fp32 [B,T,H] are the embeddings of the
- * distinct inputs (layer 0's LN/QKV are computed once per input and its residual is shared);
- * d_mask_bits [R, ceil(T/32)].  Output d_h fp32 [R,T,H] = last layer's hidden states (before any
- * final LN).  cls_only_last != 0 computes the last layer's out-proj/MLP for token 0 only (legal when
- * only h[:,0] is consumed: surrogate/classifier heads) — then only d_h[r,0,:] is defined. */
-int ag_encoder_forward(const ag_encoder_desc* desc, const float* d_h0, int R, int share,
-                       const uint32_t* d_mask_bits, float* d_h, int cls_only_last,
+ * over R rows that share B = R / share distinct inputs: d_h0 (storage dtype, [B,T,H]) are the
+ * embeddings of the distinct inputs (layer 0's LN/QKV are computed once per input and its residual is
+ * shared); d_mask_bits [R, ceil(T/32)].  Output d_h (storage dtype, [R,T,H]) = last layer's hidden
+ * states (before any final LN).  cls_only_last != 0 computes the last layer's attention/out-proj/MLP
+ * for token 0 only (legal when only h[:,0] is consumed: surrogate/classifier heads) — then only
+ * d_h[r,0,:] is defined. */
+int ag_encoder_forward(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
+                       const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

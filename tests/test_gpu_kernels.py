@@ -34,7 +34,9 @@ def test_gemm_epilogues(cuda_device, dtype, m, n, k):
         a, w = _bf16_round(a), _bf16_round(w)
     ref = a.astype(np.float64) @ w.astype(np.float64).T + b
     A, W = _to_store(a, dtype, cuda_device), _to_store(w, dtype, cuda_device)
-    B, R = torch.from_numpy(b).to(cuda_device), torch.from_numpy(r).to(cuda_device)
+    if dtype == BF16:
+        r = _bf16_round(r)
+    B, R = torch.from_numpy(b).to(cuda_device), _to_store(r, dtype, cuda_device)
     tol = dict(rtol=1e-5, atol=2e-5) if dtype == F32 else dict(rtol=1e-2, atol=2e-2)
     out = ops.gemm(A, W, B, L.AG_EPI_BIAS_F32, dtype).cpu().numpy()
     np.testing.assert_allclose(out, ref, **(dict(rtol=1e-5, atol=2e-5)))  # fp32 accumulate of exact inputs in both modes
@@ -44,8 +46,8 @@ def test_gemm_epilogues(cuda_device, dtype, m, n, k):
     np.testing.assert_allclose(out, otr.gelu(ref.astype(np.float32)), **tol)
     out = ops.gemm(A, W, B, L.AG_EPI_BIAS_TANH, dtype).float().cpu().numpy()
     np.testing.assert_allclose(out, np.tanh(ref), **tol)
-    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, dtype, resid=R).cpu().numpy()
-    np.testing.assert_allclose(out, ref + r, rtol=1e-5, atol=3e-5)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, dtype, resid=R).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref + r, **(dict(rtol=1e-5, atol=3e-5) if dtype == F32 else tol))
 
 
 def test_gemm_strided_rows_and_shared_residual(cuda_device):
@@ -91,6 +93,10 @@ def test_layernorm(cuda_device, dtype, h):
         ys, yf = ops.layernorm(torch.from_numpy(x).to(cuda_device), torch.from_numpy(sd["ln.weight"]).to(cuda_device),
                                torch.from_numpy(sd["ln.bias"]).to(cuda_device), eps, dtype, want_f32=True)
         np.testing.assert_allclose(yf.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+        xb = _bf16_round(x)  # bf16 residual stream as LayerNorm input
+        _, yb = ops.layernorm(torch.from_numpy(xb).to(cuda_device).to(torch.bfloat16), torch.from_numpy(sd["ln.weight"]).to(cuda_device),
+                              torch.from_numpy(sd["ln.bias"]).to(cuda_device), eps, dtype, want_f32=True)
+        np.testing.assert_allclose(yb.cpu().numpy(), otr.layer_norm(xb, sd, "ln", eps), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(ys.float().cpu().numpy(), ref, rtol=1e-2 if dtype == BF16 else 1e-5, atol=2e-2 if dtype == BF16 else 1e-5)
 
 
