@@ -58,15 +58,18 @@ __device__ __forceinline__ float4 load4_as_f32(const bf16_t* p) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float fast_gelu(float x) {
-    // GELU with erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): cheap enough not to dominate the epilogue
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    float p = 1.061405429f;
-    p = fmaf(p, t, -1.453152027f); p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    // bf16-mode GELU: erf(z) ~= clamp(z * Q(min(z^2, 9)), -1, 1), Q = degree-8 minimax-style fit on [0, 9]
+    // (|erf err| <= 4e-5, |gelu err| <= 9.3e-5: below bf16 resolution of the O(1) activations).  Pure FMA
+    // chain: no transcendental, packs into v_pk_fma_f32.
+    const float z = x * 0.70710678118654752440f;
+    const float u = fminf(z * z, 9.0f);
+    float q = 4.817588014e-08f;
+    q = fmaf(q, u, -2.219400514e-06f); q = fmaf(q, u, 4.523251628e-05f); q = fmaf(q, u, -5.446516761e-04f);
+    q = fmaf(q, u, 4.389698035e-03f); q = fmaf(q, u, -2.550513516e-02f); q = fmaf(q, u, 1.116382379e-01f);
+    q = fmaf(q, u, -3.756677550e-01f); q = fmaf(q, u, 1.128335659e+00f);
+    const float e = fminf(fmaxf(z * q, -1.0f), 1.0f);
+    return 0.5f * x * (1.0f + e);
 }
-
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -34,6 +34,7 @@ struct BigArgs {
     const bf16_t* R; long ldr;
     int T, share;
     int M, N, K;
+    int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
 };
 
 __device__ __forceinline__ void glds16b(const char* gsrc, char* lds_wave_base) {
@@ -62,7 +63,7 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
     return *reinterpret_cast<const uint4*>(lds_half + (row16base + r) * HROWB + ((c ^ swz4((r >> 2) & 3)) << 4));
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>  // ABL (dev ablations): 1 = no epilogue stores, 2 = no refill loads, 3 = no MFMA
 __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,11 +111,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
         for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-        if (j >= 1 && j + 3 < nh) {
+        if (ABL != 2 && j >= 1 && j + 3 < nh) {
             char* dst = smem + ((j + 3) & 3) * SLOT_BYTES;
             stage_half(p.A, p.lda_b, m0, p.M, (long)(j + 3) * HROWB, dst, wave, lane);
             stage_half(p.W, p.ldw_b, n0, p.N, (long)(j + 3) * HROWB, dst + HALF_OP_BYTES, wave, lane);
         }
+        if (ABL == 3) {
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn) asm volatile("" ::"v"(fw[sn].x), "v"(fw[sn].y), "v"(fw[sn].z), "v"(fw[sn].w));
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm) asm volatile("" ::"v"(fx[sm].x), "v"(fx[sm].y), "v"(fx[sm].z), "v"(fx[sm].w));
+        } else {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn)
@@ -123,32 +130,50 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
                 acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
                                                                       __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    if (ABL == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j2 = 0; j2 < 8; ++j2) asm volatile("" ::"v"(acc[i][j2][0]), "v"(acc[i][j2][1]), "v"(acc[i][j2][2]), "v"(acc[i][j2][3]));
+        return;
     }
 
-    // ---- epilogue (same lane -> (n, m) map as gemm.hip) ----
+    // ---- epilogue ----
+    // The accumulator layout gives a lane 4 consecutive output features of one token (8 bytes of bf16),
+    // i.e. 32-byte row segments per store instruction.  Instead each wave transposes its 128x64 tile
+    // through its private 16 KiB of the (now idle) ring, 32 rows at a time, and stores whole 128-byte
+    // rows: 8 lanes x 16 B per row, 8 rows (1 KiB of full cache lines) per store instruction.
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
+    constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
+    if (!OUT_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
+    char* stg = smem + wave * 16384;
+    const int nw0 = n0 + wn * 64;               // first output column of this wave
+    const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
 #pragma unroll
     for (int sm = 0; sm < 8; ++sm) {
         const int m = m0 + wm * 128 + sm * 16 + frow;
-        if (m >= p.M) continue;
         long rrow = 0;
-        if (EPI == AG_EPI_BIAS_RESID) {
+        if (EPI == AG_EPI_BIAS_RESID && m < p.M) {
             const int seq = m / p.T, t = m - seq * p.T;
             rrow = (long)(seq / p.share) * p.T + t;
         }
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn) {
-            const int n = n0 + wn * 64 + sn * 16 + fq * 4;
-            if (n >= p.N) continue;
+            const int n = nw0 + sn * 16 + fq * 4;
             float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (EPI == AG_EPI_BIAS_RESID) {
-                const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            const bool inb = (m < p.M) && (n < p.N);
+            if (inb) {
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (EPI == AG_EPI_BIAS_RESID) {
+                    const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
             }
             if (EPI == AG_EPI_BIAS_GELU) {
 #pragma unroll
@@ -159,10 +184,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
                 for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
             }
             if (OUT_F32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                if (inb) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
+                *reinterpret_cast<uint2*>(stg + ((sm & 1) * 16 + frow) * SROW + sn * 32 + fq * 8) =
                     make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+        if (!OUT_F32 && (sm & 1)) {
+            // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = i * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
+                const int mm = m0 + wm * 128 + (sm - 1) * 16 + rr;
+                if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+                    uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
+                    if (p.nt_store) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dstp));
+                    } else *dstp = val;
+                }
             }
         }
     }
@@ -178,6 +219,23 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    static const int abl = getenv("AG_GEMM_ABL") ? atoi(getenv("AG_GEMM_ABL")) : 0;
+    if (abl && EPI == AG_EPI_BIAS) {  // dev ablations (timing only; results are wrong)
+        static bool aset = false;
+        if (!aset) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+            aset = true;
+        }
+        if (abl == 1) hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 1>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        else if (abl == 2) hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 2>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        else if (abl == 4) hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 4>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        else hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 3>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        AG_LAUNCH_CHECK();
+        return AG_OK;
+    }
     hipLaunchKernelGGL((gemm_ring_kernel<EPI>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
@@ -337,11 +395,169 @@ int launch_tile(const BigArgs& a, hipStream_t s) {
     return AG_OK;
 }
 
+
+// =================================================================================================
+// Variant RING2 (software-pipelined ring): as RING, but the fragments of half-step j+1 are read into a
+// second register set while the MFMAs of half-step j run, and the 4 LDS-DMA refills are spread between
+// MFMA groups — so after each barrier the matrix pipe restarts immediately instead of waiting for
+// 12 ds_read_b128 + 4 LDS-DMA issues per wave (the two waves of a SIMD run in lockstep behind the shared
+// barrier, so nothing else hides that bubble).  K must be a multiple of 64 (even number of half-steps).
+// =================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_ring2_kernel(BigArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nh = p.K / 32;
+    // per-lane source rows of this wave's 4 pieces (A: 2, W: 2) and the swizzled source chunk
+    const int r_in = lane >> 2;
+    const int chunkb = ((lane & 3) ^ swz4((lane >> 4) & 3)) * 16;
+    const char* srcA[2];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int ga = m0 + (wave * 2 + i) * 16 + r_in; ga = ga < p.M ? ga : p.M - 1;
+        int gw = n0 + (wave * 2 + i) * 16 + r_in; gw = gw < p.N ? gw : p.N - 1;
+        srcA[i] = p.A + (long)ga * p.lda_b + chunkb;
+        srcW[i] = p.W + (long)gw * p.ldw_b + chunkb;
+    }
+    auto stage_piece = [&](int j, int which) {  // which: 0,1 = A pieces, 2,3 = W pieces
+        char* dst = smem + (j & 3) * SLOT_BYTES + (which >= 2 ? HALF_OP_BYTES : 0) + (wave * 2 + (which & 1)) * 1024;
+        const char* src = (which >= 2 ? srcW[which & 1] : srcA[which & 1]) + (long)j * HROWB;
+        glds16b(src, dst);
+    };
+    // fragment read offsets inside a slot (constant per lane)
+    const int fr = lane & 15, fc = lane >> 4;
+    const int foff = fr * HROWB + ((fc ^ swz4((fr >> 2) & 3)) << 4);
+    const int offW = HALF_OP_BYTES + (wn * 64) * HROWB + foff;
+    const int offA = (wm * 128) * HROWB + foff;
+    auto read_frags = [&](int j, uint4 (&fw)[4], uint4 (&fx)[8]) {
+        const char* slot = smem + (j & 3) * SLOT_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fw[s] = *reinterpret_cast<const uint4*>(slot + offW + s * 16 * HROWB);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fx[s] = *reinterpret_cast<const uint4*>(slot + offA + s * 16 * HROWB);
+    };
+
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+        if (j < nh) { stage_piece(j, 0); stage_piece(j, 1); stage_piece(j, 2); stage_piece(j, 3); }
+
+    uint4 fwA[4], fxA[8], fwB[4], fxB[8];
+    // half-step 0 landed (12 younger loads may be in flight) -> publish -> first fragment set
+    if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    read_frags(0, fwA, fxA);
+
+    // one pipelined half-step: wait for j+1, barrier, prefetch its fragments into (fwN,fxN), refill slot
+    // (j-1)&3 with half-step j+3 (its readers all passed this barrier), MFMAs of j on (fwC,fxC).
+#define AG_RING2_STEP(J, fwC, fxC, fwN, fxN)                                                                   \
+    {                                                                                                          \
+        const int j_ = (J);                                                                                    \
+        if (j_ + 1 < nh) {                                                                                     \
+            /* issued so far: 0..3 and j'+3 for j' in [1, j_) -> younger than j_+1: j_+2 (and j_+3 when j_==0) */ \
+            const int ahead = min(nh - 2 - j_, j_ == 0 ? 2 : 1);                                               \
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                   \
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                              \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              \
+            asm volatile("s_barrier" ::: "memory");                                                            \
+            read_frags(j_ + 1, fwN, fxN);                                                                      \
+        }                                                                                                      \
+        const bool refill = (j_ >= 1) && (j_ + 3 < nh);                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int sn = 0; sn < 4; ++sn) {                                                     \
+            _Pragma("unroll") for (int sm = 0; sm < 8; ++sm)                                                   \
+                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fwC[sn]),  \
+                                                                      __builtin_bit_cast(bf16x8_t, fxC[sm]), acc[sn][sm], 0, 0, 0); \
+            if (refill) stage_piece(j_ + 3, sn);                                                               \
+        }                                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    }
+
+    for (int j = 0; j < nh; j += 2) {
+        AG_RING2_STEP(j, fwA, fxA, fwB, fxB)
+        AG_RING2_STEP(j + 1, fwB, fxB, fwA, fxA)
+    }
+#undef AG_RING2_STEP
+
+    // ---- epilogue ----
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
+#pragma unroll
+    for (int sm = 0; sm < 8; ++sm) {
+        const int m = m0 + wm * 128 + sm * 16 + frow;
+        if (m >= p.M) continue;
+        long rrow = 0;
+        if (EPI == AG_EPI_BIAS_RESID) {
+            const int seq = m / p.T, t = m - seq * p.T;
+            rrow = (long)(seq / p.share) * p.T + t;
+        }
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+            const int n = n0 + wn * 64 + sn * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (EPI == AG_EPI_BIAS_RESID) {
+                const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            }
+            if (EPI == AG_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fast_gelu(v[e]);
+            }
+            if (EPI == AG_EPI_BIAS_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            }
+            if (OUT_F32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
+                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_ring2(const BigArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring2_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_ring2): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    hipLaunchKernelGGL((gemm_ring2_kernel<EPI>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 template <int EPI>
 int launch_variant(int variant, const BigArgs& a, hipStream_t s) {
     switch (variant) {
         case 1: return launch_tile<256, 256, 2, 4, 2, EPI>(a, s);
         case 2: return launch_tile<256, 128, 4, 2, 3, EPI>(a, s);
+        case 3: return launch_ring2<EPI>(a, s);
         default: return launch_ring<EPI>(a, s);
     }
 }
@@ -352,7 +568,7 @@ namespace {
 
 // Eligibility: bf16, vectorisable epilogue, K a multiple of 32 with at least 4 half-steps.
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue) {
-    return M >= 1024 && N >= 256 && (N % 4) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 4) == 0 &&
+    return M >= 1024 && N >= 256 && (N % 8) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);
 }
 
@@ -365,6 +581,8 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = (const bf16_t*)d_R; a.ldr = ldr;
     a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
+    static const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
+    a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
     static const int env_variant = getenv("AG_GEMM_VARIANT") ? atoi(getenv("AG_GEMM_VARIANT")) : 0;
     const int variant = (K % 64 == 0) ? env_variant : 0;
     switch (epilogue) {

@@ -7,20 +7,22 @@ from autognothi_amd import _lib as L, ops
 
 dev = torch.device("cuda:0")
 M = int(os.environ.get("GB_M", 100864))
+only = os.environ.get("GB_ONLY")
 shapes = [("qkv", 2304, 768, L.AG_EPI_BIAS), ("out", 768, 768, L.AG_EPI_BIAS_RESID), ("fc1", 3072, 768, L.AG_EPI_BIAS_GELU),
           ("fc2", 768, 3072, L.AG_EPI_BIAS_RESID)]
+if only: shapes = [x for x in shapes if x[0] == only]
 g = torch.Generator(device=dev); g.manual_seed(0)
 for name, n, k, epi in shapes:
     a = (torch.rand((M, k), device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     w = ((torch.rand((n, k), device=dev, generator=g) * 2 - 1) / k ** 0.5).to(torch.bfloat16)
     b = torch.rand(n, device=dev, generator=g)
-    r = torch.rand((M, n), device=dev, generator=g) if epi == L.AG_EPI_BIAS_RESID else None
+    r = torch.rand((M, n), device=dev, generator=g).to(torch.bfloat16) if epi == L.AG_EPI_BIAS_RESID else None
     out = ops.gemm(a, w, b, epi, L.AG_BF16, resid=r)
     ref = a[:4096].float() @ w.float().T + b
-    if epi == L.AG_EPI_BIAS_RESID: ref = ref + r[:4096]
+    if epi == L.AG_EPI_BIAS_RESID: ref = ref + r[:4096].float()
     if epi == L.AG_EPI_BIAS_GELU: ref = torch.nn.functional.gelu(ref)
     err = (out[:4096].float() - ref).abs().max().item()
-    tail = (out[-300:].float() - ((a[-300:].float() @ w.float().T + b) + (r[-300:] if r is not None else 0) if epi != L.AG_EPI_BIAS_GELU
+    tail = (out[-300:].float() - ((a[-300:].float() @ w.float().T + b) + (r[-300:].float() if r is not None else 0) if epi != L.AG_EPI_BIAS_GELU
             else torch.nn.functional.gelu(a[-300:].float() @ w.float().T + b))).abs().max().item()
     for _ in range(3): ops.gemm(a, w, b, epi, L.AG_BF16, resid=r, out=out)
     torch.cuda.synchronize()
