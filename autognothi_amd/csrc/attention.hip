@@ -17,12 +17,14 @@
 //     ds_read_b64_tr_b16.
 // fp32 path (AG_F32 parity mode): plain VALU kernel, one query per thread, K/V tiles broadcast from LDS.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int HD = 64;        // head dim (all shipped configs: 192/3, 768/12, 1024/16)
 constexpr int ROWB = 128;     // bytes per K/V row in bf16
 constexpr float NEG_BIG = -3.0e38f;
+constexpr uint32_t NEG_BIG_BITS = 0xFF61B1E6u;  // bit pattern of -3.0e38f
 
 // 16-B chunk slot swizzle: bijective on 8 consecutive same-parity rows (row reads) and sends rows
 // r, r+2 to different 64-B halves (transposed reads) — see DESIGN.md "attention LDS image".
@@ -38,6 +40,7 @@ struct AttnArgs {
     int R, T, H, heads, share, mode, Tw, Tp, nq;
 };
 
+template <int MODE>
 __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ldsK = smem;
@@ -52,32 +55,60 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     const char* kbase = qbase + (long)p.H * 2;
     const char* vbase = qbase + (long)2 * p.H * 2;
 
-    // ---- stage K, V (zero-fill padded keys so 0-weight x garbage can never make a NaN) ----
-    for (int c = tid; c < p.Tp * 8; c += blockDim.x) {
-        const int r = c >> 3, ch = c & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (r < p.T) {
-            kv = *reinterpret_cast<const uint4*>(kbase + (long)r * rowstride + ch * 16);
-            vv = *reinterpret_cast<const uint4*>(vbase + (long)r * rowstride + ch * 16);
+    // ---- stage K, V by LDS-DMA: 8-row x 128-B pieces (whole cache lines), the slot swizzle applied on the
+    // per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= T are clamped to row T-1 (finite
+    // data; those keys get weight exactly 0 below), never out-of-bounds.
+    {
+        const int npieces = p.Tp >> 3;
+        const int r_in = lane >> 3, slot = lane & 7;
+        for (int pc = wave; pc < npieces; pc += nwaves) {
+            const int r = pc * 8 + r_in;
+            const int rc = r < p.T ? r : p.T - 1;
+            const long src = (long)rc * rowstride + ((slot ^ swz(r)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + src),
+                                             (__attribute__((address_space(3))) void*)(ldsK + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + src),
+                                             (__attribute__((address_space(3))) void*)(ldsV + pc * 1024), 16, 0, 0);
         }
-        const int off = r * ROWB + ((ch ^ swz(r)) << 4);
-        *reinterpret_cast<uint4*>(ldsK + off) = kv;
-        *reinterpret_cast<uint4*>(ldsV + off) = vv;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nkb = p.Tp >> 5;           // 32-key blocks
     const int nqb = (p.nq + 31) >> 5;    // 32-query blocks
     const int lr = lane & 31, lh = lane >> 5;
+    // this row's mask words: lane w holds word w (Tw <= 16), fetched once; v_readlane per key block
     const uint32_t* mrow = p.mask + (long)row * p.Tw;
-    const float scale = 0.125f;          // 1/sqrt(64), exact
+    const uint32_t mwords = lane < p.Tw ? mrow[lane] : 0u;
+    // soft-max in base 2 on the raw scores: p = exp2(s*c - m*c), c = log2(e)/sqrt(64); the 1/sqrt(d) scale
+    // (exact power of two) is order-preserving, so the running max is tracked on the raw scores.
+    const float c2 = 0.125f * 1.4426950408889634f;
+
+    // per-lane LDS offsets that do not depend on the key block (swz only looks at key bits 1..3)
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = lr * ROWB + (((2 * ks + lh) ^ swz(lr)) << 4);
+    int voff[2][2][2];  // [k-step][d tile][first/second 4-key group]
+    {
+        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int k0 = 16 * st + 4 * (g >> 1) + tq, k1 = k0 + 8;
+                const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
+                voff[st][dt][0] = k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
+                voff[st][dt][1] = k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
+            }
+    }
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
 
     for (int qb = wave; qb < nqb; qb += nwaves) {
         int q = qb * 32 + lr;
         const bool qvalid = q < p.nq;
         const int qc = qvalid ? q : p.T - 1;
-        // Q fragments (B operand): lane holds Q[q][16ks + 8lh .. +8]
-        uint4 qf[4];
+        uint4 qf[4];  // Q fragments (B operand): lane holds Q[q][16ks + 8lh .. +8]
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             qf[ks] = *reinterpret_cast<const uint4*>(qbase + (long)qc * rowstride + (2 * ks + lh) * 16);
@@ -88,41 +119,62 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
         float m_run = NEG_BIG, l_run = 0.f;
 
         for (int kb = 0; kb < nkb; ++kb) {
+            const char* kblk = ldsK + kb * (32 * ROWB);
+            const char* vblk = ldsV + kb * (32 * ROWB);
             f32x16_t s;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
-            const int krow = kb * 32 + lr;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(ldsK + krow * ROWB + (((2 * ks + lh) ^ swz(krow)) << 4));
+                const uint4 kf = *reinterpret_cast<const uint4*>(kblk + koff[ks]);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
                                                             __builtin_bit_cast(bf16x8_t, qf[ks]), s, 0, 0, 0);
             }
-            // lane holds keys kb*32 + (i&3) + 8*(i>>2) + 4*lh for query lr
-            const uint32_t mw = mrow[kb];
-            const int kvalid = p.T - kb * 32;  // keys [0,kvalid) of this block exist
+            // Key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh — it depends on the lane only through lh, so
+            // the mask select uses a scalar-built 64-bit lane mask (low half: bit kk, high half: bit kk+4):
+            // one v_cndmask per score.  ViT: masked logit := 0 (still competes in the soft-max);
+            // BERT: masked logit := -inf.  Keys >= T (last block only): -inf in both modes.
+            // Key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh.  The row's mask word is shifted per lane half
+            // once, then each score takes two VALU ops: v_bfe_i32 (bit -> 0 / ~0) and a bitwise select.
+            // ViT: masked logit := +0.0 (it still competes in the soft-max); BERT: masked logit := -inf;
+            // keys >= T (ragged last block only): -inf in both modes.
+            const uint32_t mw = __builtin_amdgcn_readlane(mwords, kb);
+            const uint32_t mwl = mw >> (4 * lh);
+            const int kvalid = p.T - kb * 32;
             float bmax = NEG_BIG;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int kk = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                const bool on = (mw >> kk) & 1u;
-                float v = s[i] * scale;
-                if (p.mode == AG_MASK_VIT_MUL) v = on ? v : 0.f; else v = on ? v : NEG_BIG;
-                v = kk < kvalid ? v : NEG_BIG;
-                s[i] = v;
-                bmax = fmaxf(bmax, v);
+                const int kk = (i & 3) + 8 * (i >> 2);
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
+                const uint32_t sb = __float_as_uint(s[i]);
+                s[i] = __uint_as_float(MODE == AG_MASK_VIT_MUL ? (sb & m) : ((sb & m) | (NEG_BIG_BITS & ~m)));
             }
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            if (kvalid < 32) {  // wave-uniform
+                const uint32_t vwl = ((1u << kvalid) - 1u) >> (4 * lh);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kk = (i & 3) + 8 * (i >> 2);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vwl, kk, 1);
+                    s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bmax = fmaxf(bmax, s[i]);
+            {   // both lane halves hold the same query: combine their maxima (VALU half-swap, no LDS)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+                bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             const float m_new = fmaxf(m_run, bmax);
-            const float alpha = __expf(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            const float mc = -m_new * c2;
             float psum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pv = s[i] > -1.0e38f ? __expf(s[i] - m_new) : 0.f;
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c2, mc));  // raw v_exp_f32; -inf logits give exactly 0
                 s[i] = pv;
                 psum += pv;
             }
-            l_run = l_run * alpha + psum;
+            l_run = fmaf(l_run, alpha, psum);
             m_run = m_new;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
@@ -135,26 +187,22 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
                 pf.y = pack_bf16x2(s[8 * st + 2], s[8 * st + 3]);
                 pf.z = pack_bf16x2(s[8 * st + 4], s[8 * st + 5]);
                 pf.w = pack_bf16x2(s[8 * st + 6], s[8 * st + 7]);
-                // V^T fragments via transposed reads: 16-lane group g: d cols 16(g&1)+i, half h=g>>1
-                const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int k0 = kb * 32 + 16 * st + 4 * (g >> 1) + tq;   // row for first read
-                    const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
-                    const int a0 = k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
-                    const int k1 = k0 + 8;
-                    const int a1 = k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
-                    typedef __attribute__((ext_vector_type(4))) short s16x4;
-                    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + a0));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + a1));
+                    // V^T fragments via transposed reads (16-lane group g: d cols 16(g&1)+i, key half g>>1)
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + voff[st][dt][0]));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + voff[st][dt][1]));
                     const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
                     if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
                     else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o1, 0, 0, 0);
                 }
             }
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float l_tot;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+            l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
         const float inv = 1.0f / l_tot;
         if (qvalid) {
             char* out = p.ctx + ((long)row * p.T + q) * p.H * 2 + (long)head * HD * 2;
@@ -267,13 +315,17 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
         AG_REQUIRE(lds <= 160 * 1024, "ag_masked_attention: T=%d too long for the single-pass LDS image", T);
         const int nqb = (a.nq + 31) / 32;
         int nwaves = nqb < 8 ? nqb : 8;
+        if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
         static size_t lds_set = 0;
         if (lds > lds_set) {
-            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel),
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_VIT_MUL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_BERT_ADD>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set = lds;
         }
-        hipLaunchKernelGGL(attn_bf16_kernel, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
+        if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_VIT_MUL>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
+        else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
     } else if (dtype == AG_F32) {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(R * heads), dim3(256), 0, s, a);
     } else {
