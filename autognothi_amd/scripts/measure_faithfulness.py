@@ -1,0 +1,92 @@
+"""Insertion / deletion faithfulness curves (reference scripts/measure_faithfulness.py:41-251) on the HIP path.
+
+Per test sample the reference runs 2*C masked-forward batches of `steps` rows each through a Python loop
+(:195-218).  Here all 2*C*steps perturbation masks of a sample are built by one ranking kernel and
+evaluated in ONE masked forward whose rows all share the sample's embeddings / layer-0 projections.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..recipes.types import ModelRecipe
+from .common import Log
+
+CurvePoint = Dict[int, Dict[int, float]]  # class -> stop -> metric
+
+
+def auc(curve: Dict[int, float]) -> float:
+    """reference :143-146."""
+    vals = np.array(list(curve.values()))
+    return float(((vals[1:] + vals[:-1]) / 2).mean())
+
+
+def explain(recipe: ModelRecipe, m_final, xs: Tensor) -> Tensor:
+    """reference _explain (:174-180) -> attributions [1, C, P]."""
+    m_final.eval()
+    with torch.no_grad():
+        _logits, attr = recipe.fw_final(m_final, xs)
+    return attr
+
+
+def infer_perturbed(recipe: ModelRecipe, m_surrogate, xs: Tensor, explanation: Tensor, steps: int) -> Tuple[CurvePoint, CurvePoint]:
+    """reference _infer (:183-221) for mask_base 0 (insertion) and 1 (deletion) at once.
+    xs [1, ...]; explanation [1, C, P] -> (insertion curves, deletion curves)."""
+    _, n_classes, n_players = explanation.shape
+    attr = explanation[0].contiguous().float()                       # [C, P]
+    stops, m_ins = ops.perturbed_masks(attr, steps, 0)               # [S], [C, S, P]
+    _, m_del = ops.perturbed_masks(attr, steps, 1)
+    s = stops.shape[0]
+    masks = torch.cat([m_ins.reshape(n_classes * s, n_players), m_del.reshape(n_classes * s, n_players)], dim=0)
+    m_surrogate.eval()
+    with torch.no_grad():
+        ys, _ = recipe.fw_surrogate(m_surrogate, xs, masks)          # one input, 2*C*S mask rows
+    ys = ys.reshape(2, n_classes, s, -1).cpu().numpy()
+    stops_l = stops.cpu().numpy().tolist()
+    out: List[CurvePoint] = []
+    for base in (0, 1):
+        res: CurvePoint = {}
+        for c in range(n_classes):
+            # duplicate stops collapse because the reference keys results by stop (:205-218)
+            res[c] = {int(st): float(ys[base, c, i, c]) for i, st in enumerate(stops_l)}
+        out.append(res)
+    return out[0], out[1]
+
+
+def measure_faithfulness(env: Any, device: torch.device, recipe: ModelRecipe, m_surrogate, m_final,
+                         samples: Iterable[Tuple[Any, Any]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
+                         resolution: int) -> Dict[str, Any]:
+    """reference measure_faithfulness (:41-140) given loaded models and a test iterator of single samples.
+    Returns the report fields (insertion / deletion AUC for target and non-target classes + raw curves)."""
+    env = env or Log()
+    ok_cls_l: List[int] = []
+    ins_curves: List[CurvePoint] = []
+    del_curves: List[CurvePoint] = []
+    for i, (_inputs, _targets) in enumerate(samples):
+        xs, zs = gen_input(_inputs, _targets)
+        ok_cls = int(zs.item())
+        explanation = explain(recipe, m_final, xs)
+        ins_curve, del_curve = infer_perturbed(recipe, m_surrogate, xs, explanation, resolution)
+        ok_cls_l.append(ok_cls)
+        ins_curves.append(ins_curve)
+        del_curves.append(del_curve)
+        env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
+
+    def paint(curves: List[Dict[int, float]]) -> Dict[str, Any]:
+        items: Dict[int, List[float]] = {}
+        for curve in curves:
+            for st, point in curve.items():
+                items.setdefault(st, []).append(point)
+        avg = {st: float(np.mean(v)) for st, v in items.items()}
+        std = {st: float(np.std(v)) for st, v in items.items()}
+        a = np.array(list(avg.values()))
+        return {"auc": float(((a[1:] + a[:-1]) / 2).mean()) if len(a) > 1 else float("nan"), "avg": avg, "std": std}
+
+    sel = lambda curves, ok: [c[cl] for c, k in zip(curves, ok_cls_l) for cl in c if (cl == k) == ok]  # noqa: E731
+    return {"insertion": paint(sel(ins_curves, True)), "deletion": paint(sel(del_curves, True)),
+            "insertion_non_ok": paint(sel(ins_curves, False)), "deletion_non_ok": paint(sel(del_curves, False)),
+            "data_cls": ok_cls_l, "data_ins": ins_curves, "data_del": del_curves}

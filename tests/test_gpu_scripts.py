@@ -1,0 +1,90 @@
+"""GPU: the pipeline bodies (train_explainer eval, faithfulness, surrogate KL) against oracle restatements of the
+reference loops (scripts/train_explainer.py:210-281, scripts/measure_faithfulness.py:183-251)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import shapley as osh
+from oracle import transformer as otr
+from oracle.mt19937 import MT19937
+from util import build_case, golden, state_dict_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_explainer_eval_epoch_matches_reference_loop(cuda_device):
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import train_explainer as te
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    dev = cuda_device
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    k, p, b = 4, c["P"], c["B"]
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    v0 = torch.from_numpy(c["g"]["v_0"]).to(dev)
+    items = [(None, None), (None, None)]  # two batches: the mask stream continues across them
+    got = te.explainer_epoch_eval(None, dev, k, p, v0, items, c["recipe"], srg, exp, 1, lambda a, b_: (xs, None), seed=3407)
+    # oracle restatement of the same loop
+    gen = MT19937(3407)
+    prefix = golden("prefix_tables.npz")["prefix_196"]
+    sd_s, sd_e, prm = state_dict_numpy(c["surrogate"]), state_dict_numpy(c["explainer"]), c["meta"]["params"]
+    tot = 0.0
+    for _ in items:
+        masks = osh.mask_shapley_new(b * k, p, gen, prefix)
+        v_s = otr.vit_surrogate(np.repeat(c["xs"], k, axis=0), masks, sd_s, prm)
+        v_1 = otr.vit_surrogate(c["xs"], np.ones((b, p), dtype=np.int64), sd_s, prm)
+        phi = otr.vit_explainer(c["xs"], np.ones((b, p), dtype=np.int64), v_1, c["g"]["v_0"], sd_e, prm)
+        loss, _ = osh.loss_shapley_new(b, k, p, masks, c["g"]["v_0"], v_s, v_1, phi)
+        tot += float(loss)
+    np.testing.assert_allclose(got, tot / (2 * b), rtol=2e-4)
+
+
+def test_faithfulness_curves_match_reference_loop(cuda_device):
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import measure_faithfulness as mf
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    dev = cuda_device
+    srg = c["surrogate"].to(dev)
+    xs = torch.from_numpy(c["xs"][:1]).to(dev)
+    attr = np.random.default_rng(5).standard_normal((1, 10, c["P"])).astype(np.float32)
+    ins, dele = mf.infer_perturbed(c["recipe"], srg, xs, torch.from_numpy(attr).to(dev), steps=6)
+    sd_s, prm = state_dict_numpy(c["surrogate"]), c["meta"]["params"]
+    for base, got in ((0, ins), (1, dele)):
+        for cls in (0, 7):
+            stops, masks = osh.get_perturbed_samples(attr[0, cls], c["P"], 6, base)
+            ys = otr.vit_surrogate(np.repeat(c["xs"][:1], len(stops), axis=0), masks, sd_s, prm)
+            want = {int(s): float(ys[i, cls]) for i, s in enumerate(stops)}
+            assert sorted(got[cls]) == sorted(want)
+            for s in want:
+                assert abs(got[cls][s] - want[s]) <= 1e-4
+    assert abs(mf.auc(ins[0]) - osh.auc(np.array(list(ins[0].values())))) < 1e-12
+
+
+def test_surrogate_kl_batch(cuda_device):
+    from autognothi_amd import engine, ops
+    from autognothi_amd.scripts import train_surrogate as ts
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    dev = cuda_device
+    srg = c["surrogate"].to(dev)
+    cls = c["recipe"].t_classifier(c["cfg"]); cls.load_state_dict(c["surrogate"].state_dict()); cls = cls.to(dev).eval()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    rng = ops.DeviceMT19937(dev, 11)
+    loss, dcur, orig, adapt = ts.surrogate_batch_loss(c["recipe"], cls, srg, xs, c["P"], rng)
+    masks = osh.mask_purely_uniform(c["B"], c["P"], MT19937(11))
+    sd_s, prm = state_dict_numpy(c["surrogate"]), c["meta"]["params"]
+    o = otr.vit_surrogate(c["xs"], np.ones((c["B"], c["P"]), dtype=np.int64), sd_s, prm)
+    a = otr.vit_surrogate(c["xs"], masks, sd_s, prm)
+    np.testing.assert_allclose(orig.cpu().numpy(), o, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(adapt.cpu().numpy(), a, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy()[0], osh.loss_logits_kl_divergence(o, a), rtol=1e-3, atol=1e-7)
+    assert dcur.shape == adapt.shape
+
+
+def test_training_entry_points_fail_loudly():
+    from autognothi_amd.scripts import train_explainer as te, train_surrogate as ts
+    with pytest.raises(NotImplementedError):
+        te.explainer_epoch_train()
+    with pytest.raises(NotImplementedError):
+        ts.surrogate_epoch_train()
