@@ -1,0 +1,79 @@
+"""Oracle / CPU baseline (test infrastructure): the masked surrogate forward restated with torch *CPU* ops
+(fp32, multi-threaded) — the same arithmetic library the reference itself runs on, so this is the fair
+"reference CPU path" stand-in that bench.py times on the GPU box's host cores (the reference's Python cannot
+travel there).  Checked against the reference-generated fixtures in tests/test_oracle_models.py.
+Follows reference models/vanilla_vit.py:207-214,:242-253,:364-377,:436-465,:51-56 and
+models/vanilla_bert.py:307-325,:410-427,:503-537,:61-77.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+def _lin(x, sd: SD, p: str):
+    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def _ln(x, sd: SD, p: str, eps: float):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _attention(u, mask_t, sd: SD, p: str, nh: int, mode: str):
+    r, t, h = u.shape
+    d = h // nh
+    q = _lin(u, sd, p + ".query").view(r, t, nh, d).permute(0, 2, 1, 3)
+    k = _lin(u, sd, p + ".key").view(r, t, nh, d).permute(0, 2, 1, 3)
+    v = _lin(u, sd, p + ".value").view(r, t, nh, d).permute(0, 2, 1, 3)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    m = mask_t.to(torch.float32).reshape(r, 1, 1, t)
+    s = s * m if mode == "vit" else s + (1.0 - m) * torch.finfo(torch.float32).min
+    ctx = torch.matmul(F.softmax(s, dim=-1), v)
+    return ctx.permute(0, 2, 1, 3).reshape(r, t, h)
+
+
+def _prepend_cls(mask_p):
+    return torch.cat([torch.ones((mask_p.shape[0], 1), dtype=mask_p.dtype), mask_p], dim=1)
+
+
+@torch.no_grad()
+def vit_surrogate(x, mask_p, sd: SD, cfg: dict):
+    """x [R,3,px,px] fp32, mask_p [R,P] int64 -> probabilities [R,C]."""
+    mask_t = _prepend_cls(mask_p)
+    pr = "vit.embeddings"
+    e = F.conv2d(x, sd[pr + ".patch_embeddings.projection.weight"], sd[pr + ".patch_embeddings.projection.bias"],
+                 stride=cfg["img_patch_size"]).flatten(2).transpose(1, 2)
+    h = torch.cat([sd[pr + ".cls_token"].expand(x.shape[0], -1, -1), e], dim=1) + sd[pr + ".position_embeddings"]
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"vit.encoder.layers.{i}"
+        a = _attention(_ln(h, sd, p + ".layernorm_before", eps), mask_t, sd, p + ".attention.self", nh, "vit")
+        h = h + _lin(a, sd, p + ".attention.output.dense")
+        w = _ln(h, sd, p + ".layernorm_after", eps)
+        h = _lin(F.gelu(_lin(w, sd, p + ".intermediate.dense")), sd, p + ".output.dense") + h
+    z = _ln(h, sd, "vit.layernorm", eps)
+    return F.softmax(_lin(z[:, 0, :], sd, "classifier"), dim=-1)
+
+
+@torch.no_grad()
+def bert_surrogate(ids, mask_p, sd: SD, cfg: dict):
+    """ids [R,T] int64, mask_p [R,T-1] int64 -> probabilities [R,C]."""
+    mask_t = _prepend_cls(mask_p)
+    t = ids.shape[1]
+    pr = "bert.embeddings"
+    e = sd[pr + ".word_embeddings.weight"][ids] + sd[pr + ".token_type_embeddings.weight"][0]
+    e = e + sd[pr + ".position_embeddings.weight"][:t][None]
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    h = _ln(e, sd, pr + ".LayerNorm", eps)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"bert.encoder.layers.{i}"
+        ctx = _attention(h, mask_t, sd, p + ".attention.self", nh, "bert")
+        a = _ln(_lin(ctx, sd, p + ".attention.output.dense") + h, sd, p + ".attention.output.LayerNorm", eps)
+        h = _ln(_lin(F.gelu(_lin(a, sd, p + ".intermediate.dense")), sd, p + ".output.dense") + a, sd, p + ".output.LayerNorm", eps)
+    pooled = torch.tanh(_lin(h[:, 0], sd, "bert_pooler.dense"))
+    return F.softmax(_lin(pooled, sd, "classifier"), dim=-1)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import shapley as osh
+from oracle import torch_port as otp
 from oracle import transformer as otr
 from util import MODEL_TAGS, build_case, state_dict_numpy
 
@@ -35,6 +36,12 @@ def test_oracle_matches_reference(tag):
     np.testing.assert_allclose(v_s, g["v_s"], rtol=0, atol=ATOL)
     np.testing.assert_allclose(v_0, g["v_0"], rtol=0, atol=ATOL)
     np.testing.assert_allclose(v_1, g["v_1"], rtol=0, atol=ATOL)
+    # the torch-CPU port used as bench.py's cpu_baseline must agree with the reference too
+    import torch
+    sd_t = {k: torch.from_numpy(v) for k, v in sd_s.items()}
+    srg_t = otp.vit_surrogate if kind == "vit" else otp.bert_surrogate
+    v_s_t = srg_t(torch.from_numpy(xs_ext), torch.from_numpy(c["masks"]), sd_t, prm).numpy()
+    np.testing.assert_allclose(v_s_t, g["v_s"], rtol=0, atol=ATOL)
     # per-layer hidden-state checksums (layer outputs; trace[0] is the embedding output)
     for li in range(prm["num_hidden_layers"]):
         got, want = checks(trace[li + 1]), g["layer_trace"][li]
