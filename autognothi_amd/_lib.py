@@ -57,6 +57,17 @@ SIGNATURES = {
     "ag_shapley_normalize_bwd": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "ag_shapley_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "ag_transpose_f32": (i32, [vp, i32, i32, i64, vp, i64, vp]),
+    "ag_colsum_f32": (i32, [vp, i32, i32, i64, vp, i32, vp]),
+    "ag_gelu_f32": (i32, [vp, vp, i64, vp]),
+    "ag_gelu_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
+    "ag_tanh_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
+    "ag_add_f32": (i32, [vp, vp, vp, i64, vp]),
+    "ag_dropout_f32": (i32, [vp, vp, i64, f32, u32, vp]),
+    "ag_softmax_rows_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "ag_layernorm_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, vp]),
+    "ag_masked_attention_train": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
+    "ag_masked_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_profile_enable": (i32, [i32]),
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),

@@ -38,6 +38,7 @@ struct AttnArgs {
     const uint32_t* mask;  // [R, Tw]
     char* ctx;        // [R, T, H]
     int R, T, H, heads, share, mode, Tw, Tp, nq;
+    float pdrop; uint32_t seed;  // fp32 training forward only
 };
 
 template <int MODE>
@@ -271,9 +272,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
                 else if (!on) continue;  // exactly zero weight
                 const float m_new = fmaxf(m_run, s);
                 const float alpha = expf(m_run - m_new);
-                const float pv = expf(s - m_new);
+                float pv = expf(s - m_new);
                 l_run = l_run * alpha + pv;
                 m_run = m_new;
+                if (p.pdrop > 0.f)  // dropout on the normalised probabilities: dropped weights still count in l
+                    pv = keep_elem(p.seed, ((uint64_t)blockIdx.x * p.T + q) * p.T + key, p.pdrop) ? pv / (1.0f - p.pdrop) : 0.f;
 #pragma unroll
                 for (int d = 0; d < HD; d += 4) {
                     const float4 t = *reinterpret_cast<const float4*>(sV + kk * HD + d);
@@ -306,6 +309,7 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = qkv_share; a.mode = mask_mode;
     a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32;
     a.nq = (n_query > 0 && n_query < T) ? n_query : T;
+    a.pdrop = 0.f; a.seed = 0;
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == AG_BF16 ? 2.0 : 4.0;
     AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)a.nq * T * H,
@@ -331,6 +335,20 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     } else {
         return ag_fail(AG_ERR_INVALID, "ag_masked_attention: bad dtype %d", dtype);
     }
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H,
+                                         int heads, int mask_mode, float p_drop, uint32_t seed, void* stream) {
+    AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention_train: null pointer");
+    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H == heads * HD && p_drop >= 0.f && p_drop < 1.f, "ag_masked_attention_train: bad arguments");
+    if (R == 0) return AG_OK;
+    AttnArgs a;
+    a.qkv = (const char*)d_qkv; a.mask = d_mask_bits; a.ctx = (char*)d_ctx;
+    a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = 1; a.mode = mask_mode;
+    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed;
+    hipLaunchKernelGGL(attn_f32_kernel, dim3(R * heads), dim3(256), 0, (hipStream_t)stream, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -59,6 +59,13 @@ __device__ __forceinline__ float4 load4_as_f32(const bf16_t* p) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
 }
 
+// counter-based dropout keep decision shared by forward and backward (murmur3 finaliser of (seed, index))
+__device__ __forceinline__ bool keep_elem(uint32_t seed, uint64_t idx, float p) {
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u ^ seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (float)(h >> 8) * 5.9604644775390625e-08f >= p;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float fast_gelu(float x) {

@@ -270,3 +270,111 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
     with torch.cuda.device(ref.device):
         L.check(L.lib().ag_kl_loss(L.ptr(ref), L.ptr(cur), ref.shape[0], ref.shape[1], L.ptr(loss), L.ptr(d), L.stream()))
     return loss, d
+
+
+# ----------------------------------------------------------------------------- training building blocks (fp32)
+def _f32c(t: Tensor) -> Tensor:
+    L.require_gpu(t)
+    if t.dtype != torch.float32:
+        raise TypeError(f"training kernels are fp32; got {t.dtype}")
+    return t.contiguous()
+
+
+def transpose(src: Tensor, pad_cols_to: int = 1) -> Tensor:
+    """[R,C] -> [C, Rp] with Rp = R rounded up to `pad_cols_to` (zero padded) — the K-dim padding ag_gemm needs."""
+    s = _f32c(src)
+    r, c = s.shape
+    rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    dst = torch.zeros((c, rp), dtype=torch.float32, device=s.device) if rp != r else torch.empty((c, rp), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        L.check(L.lib().ag_transpose_f32(L.ptr(s), r, c, c, L.ptr(dst), rp, L.stream()))
+    return dst
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    x = _f32c(x)
+    m, n = x.shape
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        accumulate = False
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_colsum_f32(L.ptr(x), m, n, n, L.ptr(out), 1 if accumulate else 0, L.stream()))
+    return out
+
+
+def _unary(name: str, *tensors: Tensor) -> Tensor:
+    ts = [_f32c(t) for t in tensors]
+    out = torch.empty_like(ts[0])
+    with torch.cuda.device(out.device):
+        L.check(getattr(L.lib(), name)(*[L.ptr(t) for t in ts], L.ptr(out), out.numel(), L.stream()))
+    return out
+
+
+def gelu(u: Tensor) -> Tensor:
+    return _unary("ag_gelu_f32", u)
+
+
+def gelu_bwd(u: Tensor, dy: Tensor) -> Tensor:
+    return _unary("ag_gelu_bwd_f32", u, dy)
+
+
+def tanh_bwd(y: Tensor, dy: Tensor) -> Tensor:
+    return _unary("ag_tanh_bwd_f32", y, dy)
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    return _unary("ag_add_f32", a, b)
+
+
+def dropout(x: Tensor, p: float, seed: int) -> Tensor:
+    """y = keep(seed, i) ? x/(1-p) : 0.  The same call on dy is the backward."""
+    if p <= 0.0:
+        return x
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_dropout_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), seed & 0xFFFFFFFF, L.stream()))
+    return y
+
+
+def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
+    y, dy = _f32c(y), _f32c(dy)
+    dx = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        L.check(L.lib().ag_softmax_rows_bwd(L.ptr(y), L.ptr(dy), L.ptr(dx), y.shape[0], y.shape[1], L.stream()))
+    return dx
+
+
+def layernorm_bwd(x: Tensor, gamma: Optional[Tensor], dy: Tensor, eps: float, dgamma: Optional[Tensor] = None,
+                  dbeta: Optional[Tensor] = None, accumulate: bool = True) -> Tensor:
+    """x, dy [rows, H] fp32 -> dx; dgamma / dbeta ([H]) accumulated in place when given."""
+    x, dy = _f32c(x), _f32c(dy)
+    h = x.shape[-1]
+    rows = x.numel() // h
+    dx = torch.empty_like(x)
+    scratch = torch.empty(128 * 2 * h, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_layernorm_bwd(L.ptr(x), L.ptr(gamma), L.ptr(dy), rows, h, eps, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
+                                         1 if accumulate else 0, L.ptr(scratch), L.stream()))
+    return dx
+
+
+def masked_attention_train(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, heads: int, mask_mode: int,
+                           p_drop: float = 0.0, seed: int = 0) -> Tensor:
+    qkv = _f32c(qkv)
+    ctx = torch.empty((rows, t, h), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        L.check(L.lib().ag_masked_attention_train(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, mask_mode,
+                                                  float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+    return ctx
+
+
+def masked_attention_bwd(qkv: Tensor, mask_bits: Tensor, ctx: Tensor, dctx: Tensor, rows: int, t: int, h: int, heads: int,
+                         mask_mode: int, p_drop: float = 0.0, seed: int = 0) -> Tensor:
+    qkv, ctx, dctx = _f32c(qkv), _f32c(ctx), _f32c(dctx)
+    dqkv = torch.empty_like(qkv)
+    stats = torch.empty(rows * heads * t * 3, dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        L.check(L.lib().ag_masked_attention_bwd(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), L.ptr(dctx), L.ptr(dqkv), L.ptr(stats),
+                                                rows, t, h, heads, mask_mode, float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+    return dqkv

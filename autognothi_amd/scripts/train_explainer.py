@@ -5,9 +5,8 @@
 ``explainer_epoch_eval``  = :210-281 (no grad): targets + explainer forward + Shapley loss.
 ``explainer_batch_loss``  = :184-196 forward part; returns the loss AND d loss / d phi from the HIP loss kernel.
 
-The optimiser step of :197-198 needs the explainer's backward through the transformer, which this
-round's kernel set does not contain yet; ``explainer_epoch_train`` therefore raises instead of
-falling back to eager PyTorch.
+``explainer_epoch_train`` = :128-207: the same targets, then explainer forward + loss + backward on the HIP
+training kernels (``autognothi_amd/training.py``) and the reference's own ``torch.optim`` step.
 """
 from __future__ import annotations
 
@@ -73,8 +72,29 @@ def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_
     return reg_loss / max(total, 1)
 
 
-def explainer_epoch_train(*args, **kwargs):
-    raise NotImplementedError(
-        "explainer training needs the backward kernels of the masked transformer, which are not built in this "
-        "round; the hot K-mask target loop (surrogate_targets) and the loss/gradient kernel (explainer_batch_loss) "
-        "are available. There is deliberately no eager-PyTorch fallback.")
+def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
+                          d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
+                          optimizer: torch.optim.Optimizer, epoch: int,
+                          gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None) -> float:
+    """reference _explainer_epoch_train (:128-207) / _duo_explainer_epoch_train: per batch — K-mask surrogate
+    targets (no grad, HIP inference path), explainer forward + Shapley loss + backward (HIP training kernels,
+    autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean)."""
+    from ..training import ExplainerTrainer
+    env = env or Log()
+    rng = device_rng(m_surrogate, device, seed)
+    trainer = m_explainer.__dict__.get("_ag_trainer") or ExplainerTrainer(m_recipe, m_explainer)
+    m_explainer.__dict__["_ag_trainer"] = trainer
+    reg_loss, total = 0.0, 0
+    m_explainer.train()
+    for batch_idx, (_inputs, _targets) in enumerate(d_items):
+        xs, zs = gen_input(_inputs, _targets)
+        optimizer.zero_grad()
+        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
+        loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
+                                            seed=(seed or 0) + epoch)
+        optimizer.step()
+        lv = float(loss.item())
+        reg_loss += lv
+        total += xs.shape[0]
+        env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
+    return reg_loss / max(total, 1)

@@ -1,7 +1,7 @@
 """Per-batch pieces of reference scripts/train_surrogate.py (:112-211) available on the HIP path:
 the uniform mask sampler, the frozen-classifier target forward, the masked surrogate forward and the
-KL loss with its gradient w.r.t. the surrogate's output.  The optimiser step needs the backward kernels
-(next round); ``surrogate_epoch_train`` raises rather than fall back to eager PyTorch."""
+KL loss with its gradient w.r.t. the surrogate's output, and the training epoch built on them
+(``surrogate_epoch_train``: HIP forward + backward, reference optimiser)."""
 from __future__ import annotations
 
 from typing import Any, Callable, Iterable, Optional, Tuple
@@ -45,6 +45,30 @@ def surrogate_epoch_eval(env: Any, device: torch.device, n_players: int, d_items
     return tot / max(n, 1)
 
 
-def surrogate_epoch_train(*args, **kwargs):
-    raise NotImplementedError("surrogate training needs the backward kernels of the masked transformer (next round); "
-                              "no eager-PyTorch fallback is provided")
+def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe,
+                          m_classifier, m_surrogate, optimizer: torch.optim.Optimizer, epoch: int,
+                          gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None) -> float:
+    """reference _surrogate_epoch_train (:112-160): uniform masks, frozen-classifier targets (no grad), masked
+    surrogate forward + KL + backward on the HIP training kernels, reference optimiser step.  -> mean KL."""
+    from ..training import SurrogateTrainer
+    env = env or Log()
+    rng = device_rng(m_surrogate, device, seed)
+    trainer = m_surrogate.__dict__.get("_ag_trainer") or SurrogateTrainer(m_recipe, m_surrogate)
+    m_surrogate.__dict__["_ag_trainer"] = trainer
+    m_classifier.eval()
+    m_surrogate.train()
+    tot, n = 0.0, 0
+    for batch_idx, (_inputs, _targets) in enumerate(d_items):
+        xs, _ = gen_input(_inputs, _targets)
+        b = xs.shape[0]
+        optimizer.zero_grad()
+        _, bits = ops.mask_purely_uniform(rng, b, n_players, want_i64=False, want_bits=True)
+        ones = torch.ones((b, n_players), dtype=torch.long, device=xs.device)
+        with torch.no_grad():
+            orig, _ = m_recipe.fw_classifier(m_classifier, xs, ones)
+        loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
+        optimizer.step()
+        tot += float(loss.item()) * b
+        n += b
+        env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: kl {tot / n:.6f}")
+    return tot / max(n, 1)

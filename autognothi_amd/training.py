@@ -1,0 +1,450 @@
+"""Training forward/backward of the masked transformers on the HIP kernels (fp32).
+
+Replaces what torch.autograd does for the reference in scripts/train_explainer.py:184-198
+(explainer: backbone with all-ones mask -> explainer_attn -> MLP -> normalise -> Shapley loss) and
+scripts/train_surrogate.py:145-147 (surrogate: masked forward -> KL against the frozen classifier).
+Gradients are accumulated into the modules' ``param.grad`` (fp32, on the device) so the reference's
+``torch.optim.AdamW`` + ``CosineAnnealingLR`` drive the update unchanged; frozen parameters
+(``requires_grad == False``, e.g. the froyo backbone) are skipped, and a fully frozen backbone is run through
+the fast inference path without saving activations.
+
+All arithmetic is libautognothi_hip kernels: Linear forward/backward = ag_gemm (dX against the transposed
+weight, dW against transposed activations), plus the train.hip blocks.  Activations are kept in fp32.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from . import engine, ops
+
+F32 = L.AG_F32
+PAD = 32  # ag_gemm fp32 needs its K dimension to be a multiple of 32
+
+
+def _grad(p: Tensor) -> Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, dtype=torch.float32)
+    return p.grad
+
+
+def _acc(dst: Tensor, src: Tensor) -> None:
+    """dst += src through the add kernel (no torch arithmetic)."""
+    with torch.cuda.device(dst.device):
+        L.check(L.lib().ag_add_f32(L.ptr(dst), L.ptr(src.contiguous()), L.ptr(dst), dst.numel(), L.stream()))
+
+
+class Seeds:
+    """Fresh dropout seed per site per step (train mode); p == 0 disables everything."""
+
+    def __init__(self, base: int):
+        self.base, self.n = base & 0x7FFFFFFF, 0
+
+    def next(self) -> int:
+        self.n += 1
+        return (self.base * 2654435761 + self.n * 40503) & 0xFFFFFFFF
+
+
+class Lin:
+    """y = x Wᵀ + b over one or more nn.Linear modules fused along the output dim (q|k|v)."""
+
+    def __init__(self, mods: Sequence[nn.Module]):
+        self.mods = list(mods)
+        self.x: Optional[Tensor] = None
+
+    def _w(self) -> Tuple[Tensor, Tensor]:
+        if len(self.mods) == 1:
+            m = self.mods[0]
+            return m.weight.detach().reshape(m.weight.shape[0], -1).float().contiguous(), m.bias.detach().float().contiguous()
+        return (torch.cat([m.weight.detach() for m in self.mods], 0).float().contiguous(),
+                torch.cat([m.bias.detach() for m in self.mods], 0).float().contiguous())
+
+    def trainable(self) -> bool:
+        return any(p.requires_grad for m in self.mods for p in (m.weight, m.bias))
+
+    def forward(self, x: Tensor, epilogue: int = L.AG_EPI_BIAS, save: bool = True) -> Tensor:
+        w, b = self._w()
+        if save:
+            self.x = x
+        return ops.gemm(x, w, b, epilogue, F32, m=x.shape[0])
+
+    def backward(self, dy: Tensor, need_dx: bool = True) -> Optional[Tensor]:
+        w, _ = self._w()
+        n, k = w.shape
+        m = dy.shape[0]
+        dx = None
+        if need_dx:
+            # dX[M,K] = dY[M,N] · W[N,K]  ==  NT GEMM against Wᵀ [K, N]; pad N (the contraction) to 32
+            if n % PAD:
+                npad = (n + PAD - 1) // PAD * PAD
+                dyp = torch.zeros((m, npad), dtype=torch.float32, device=dy.device)
+                dyp[:, :n].copy_(dy)
+                wt = ops.transpose(w, pad_cols_to=PAD)  # [K, Np]
+                dx = ops.gemm(dyp, wt, None, L.AG_EPI_BIAS, F32, m=m)
+            else:
+                dx = ops.gemm(dy, ops.transpose(w), None, L.AG_EPI_BIAS, F32, m=m)
+        if self.trainable():
+            # dW[N,K] = dYᵀ[N,M] · X[M,K]  ==  NT GEMM of dYᵀ [N,Mp] against Xᵀ [K,Mp]
+            dyt = ops.transpose(dy, pad_cols_to=PAD)
+            xt = ops.transpose(self.x, pad_cols_to=PAD)
+            dw = ops.gemm(dyt, xt, None, L.AG_EPI_BIAS, F32, m=n)
+            db = ops.colsum(dy)
+            off = 0
+            for mod in self.mods:
+                rows = mod.weight.shape[0]
+                if mod.weight.requires_grad:
+                    _acc(_grad(mod.weight), dw[off:off + rows].reshape(mod.weight.shape))
+                if mod.bias.requires_grad:
+                    _acc(_grad(mod.bias), db[off:off + rows])
+                off += rows
+        self.x = None
+        return dx
+
+
+class Norm:
+    def __init__(self, mod: nn.Module, eps: float):
+        self.mod, self.eps = mod, eps
+        self.identity = isinstance(mod, nn.Identity)
+        self.x: Optional[Tensor] = None
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.identity:
+            return x
+        self.x = x
+        _, y = ops.layernorm(x, self.mod.weight.detach().float(), self.mod.bias.detach().float(), self.eps, F32,
+                             want_store=False, want_f32=True)
+        return y
+
+    def backward(self, dy: Tensor) -> Tensor:
+        if self.identity:
+            return dy
+        train = self.mod.weight.requires_grad
+        dx = ops.layernorm_bwd(self.x, self.mod.weight.detach().float(), dy, self.eps,
+                               _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=True)
+        self.x = None
+        return dx
+
+
+class Block:
+    """One transformer layer (reference VanillaViTLayer :364-377 pre-LN / VanillaBertLayer :410-427 post-LN)."""
+
+    def __init__(self, layer: nn.Module, kind: int, heads: int, eps: float, p_hidden: float, p_attn: float):
+        self.kind, self.heads, self.p_hidden, self.p_attn = kind, heads, p_hidden, p_attn
+        att = layer.attention
+        self.qkv = Lin([att.self.query, att.self.key, att.self.value])
+        self.o, self.fc1, self.fc2 = Lin([att.output.dense]), Lin([layer.intermediate.dense]), Lin([layer.output.dense])
+        if kind == L.AG_MASK_VIT_MUL:
+            self.n1, self.n2 = Norm(layer.layernorm_before, eps), Norm(layer.layernorm_after, eps)
+        else:
+            self.n1, self.n2 = Norm(att.output.LayerNorm, eps), Norm(layer.output.LayerNorm, eps)
+        self.saved = None
+
+    def forward(self, h: Tensor, bits: Tensor, rows: int, t: int, seeds: Seeds, train: bool) -> Tensor:
+        hdim = h.shape[-1]
+        ph, pa = (self.p_hidden, self.p_attn) if train else (0.0, 0.0)
+        s_att, s_o, s_f = seeds.next(), seeds.next(), seeds.next()
+        vit = self.kind == L.AG_MASK_VIT_MUL
+        u1 = self.n1.forward(h) if vit else h
+        qkv = self.qkv.forward(u1)
+        ctx = ops.masked_attention_train(qkv, bits, rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, hdim)
+        ao = ops.dropout(self.o.forward(ctx), ph, s_o)
+        hx = ops.add(h, ao)
+        u2 = self.n2.forward(hx) if vit else self.n1.forward(hx)
+        f1 = self.fc1.forward(u2)
+        g = ops.gelu(f1)
+        f2 = ops.dropout(self.fc2.forward(g), ph, s_f)
+        out = ops.add(hx if vit else u2, f2)
+        if not vit:
+            out = self.n2.forward(out)
+        self.saved = (qkv, ctx, f1, bits, rows, t, hdim, ph, pa, s_att, s_o, s_f)
+        return out
+
+    def backward(self, dout: Tensor) -> Tensor:
+        qkv, ctx, f1, bits, rows, t, hdim, ph, pa, s_att, s_o, s_f = self.saved
+        vit = self.kind == L.AG_MASK_VIT_MUL
+        if vit:
+            dhx = dout
+            du2 = self.fc1.backward(ops.gelu_bwd(f1, self.fc2.backward(ops.dropout(dout, ph, s_f))))
+            dhx = ops.add(dhx, self.n2.backward(du2))
+            dctx = self.o.backward(ops.dropout(dhx, ph, s_o))
+            dqkv = ops.masked_attention_bwd(qkv.view(rows, t, 3 * hdim), bits, ctx.view(rows, t, hdim), dctx.view(rows, t, hdim),
+                                            rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, 3 * hdim)
+            du1 = self.qkv.backward(dqkv)
+            dh = ops.add(dhx, self.n1.backward(du1))
+        else:
+            dsum = self.n2.backward(dout)                       # d(f2 + a)
+            da = self.fc1.backward(ops.gelu_bwd(f1, self.fc2.backward(ops.dropout(dsum, ph, s_f))))
+            da = ops.add(da, dsum)
+            dpre = self.n1.backward(da)                         # d(ao + h)
+            dctx = self.o.backward(ops.dropout(dpre, ph, s_o))
+            dqkv = ops.masked_attention_bwd(qkv.view(rows, t, 3 * hdim), bits, ctx.view(rows, t, hdim), dctx.view(rows, t, hdim),
+                                            rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, 3 * hdim)
+            dh = ops.add(dpre, self.qkv.backward(dqkv))
+        self.saved = None
+        return dh
+
+
+def _any_trainable(mod: nn.Module) -> bool:
+    return any(p.requires_grad for p in mod.parameters())
+
+
+class ViTBackboneTrainer:
+    """VanillaViTModel (embeddings + encoder + final LN), reference models/vanilla_vit.py:207-214."""
+
+    def __init__(self, vit: nn.Module):
+        self.vit, c = vit, vit.config
+        self.frozen = not _any_trainable(vit)
+        self.blocks = [Block(ly, L.AG_MASK_VIT_MUL, c.num_attention_heads, c.layer_norm_eps, c.hidden_dropout_prob,
+                             c.attention_probs_dropout_prob) for ly in vit.encoder.layers]
+        self.ln_f = Norm(vit.layernorm, c.layer_norm_eps)
+        self.proj = Lin([vit.embeddings.patch_embeddings.projection])
+        self.saved = None
+
+    def forward(self, x: Tensor, bits: Tensor, seeds: Seeds, train: bool) -> Tensor:
+        """-> LN_final(hidden) fp32 [B*T, H]."""
+        c = self.vit.config
+        b, p, h = x.shape[0], self.vit.n_players, c.hidden_size
+        t = p + 1
+        if self.frozen:
+            # eval()-equivalent: a frozen backbone has no dropout-free requirement in the reference, but its
+            # activations need no saving; keep dropout semantics by using the training path only when p > 0
+            pass
+        x = x.contiguous().float()
+        cols = torch.empty((b * p, c.img_channels * c.img_patch_size ** 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().ag_vit_im2col(L.ptr(x), b, c.img_channels, c.img_px_size, c.img_patch_size, L.ptr(cols), F32, L.stream()))
+            pe = self.proj.forward(cols, L.AG_EPI_BIAS_F32)
+            h0 = torch.empty((b, t, h), dtype=torch.float32, device=x.device)
+            e = self.vit.embeddings
+            L.check(L.lib().ag_vit_assemble(L.ptr(pe), L.ptr(e.cls_token.detach().float().contiguous()),
+                                            L.ptr(e.position_embeddings.detach().float().contiguous()), b, p, h, L.ptr(h0), L.stream()))
+        s_emb = seeds.next()
+        ph = c.hidden_dropout_prob if train else 0.0
+        hid = ops.dropout(h0.view(b * t, h), ph, s_emb)
+        for blk in self.blocks:
+            hid = blk.forward(hid, bits, b, t, seeds, train)
+        self.saved = (b, p, h, ph, s_emb)
+        return self.ln_f.forward(hid)
+
+    def backward(self, dz: Tensor) -> None:
+        b, p, h, ph, s_emb = self.saved
+        t = p + 1
+        d = self.ln_f.backward(dz)
+        for blk in reversed(self.blocks):
+            d = blk.backward(d)
+        d = ops.dropout(d, ph, s_emb).view(b, t, h)
+        e = self.vit.embeddings
+        if e.position_embeddings.requires_grad:
+            _acc(_grad(e.position_embeddings), ops.colsum(d.reshape(b, t * h)).view(1, t, h))
+        if e.cls_token.requires_grad:
+            _acc(_grad(e.cls_token), ops.colsum(d[:, 0, :].contiguous()).view(1, 1, h))
+        if self.proj.trainable():
+            self.proj.backward(d[:, 1:, :].contiguous().view(b * p, h), need_dx=False)
+        self.saved = None
+
+
+class BertBackboneTrainer:
+    """VanillaBertModel (embeddings + LN + encoder), reference models/vanilla_bert.py:248-268."""
+
+    def __init__(self, bert: nn.Module):
+        self.bert, c = bert, bert.config
+        self.blocks = [Block(ly, L.AG_MASK_BERT_ADD, c.num_attention_heads, c.layer_norm_eps, c.hidden_dropout_prob,
+                             c.attention_probs_dropout_prob) for ly in bert.encoder.layers]
+        self.ln_e = Norm(bert.embeddings.LayerNorm, c.layer_norm_eps)
+        self.saved = None
+
+    def forward(self, ids: Tensor, bits: Tensor, seeds: Seeds, train: bool) -> Tensor:
+        c, e = self.bert.config, self.bert.embeddings
+        ids = ids.contiguous().to(torch.int64)
+        b, t = ids.shape
+        h = c.hidden_size
+        # gather (index plumbing) + add through the add kernel, then LayerNorm
+        emb = e.word_embeddings.weight.detach().float()[ids].view(b * t, h).contiguous()
+        pos_type = ops.add(e.position_embeddings.weight.detach().float()[:t].contiguous(),
+                           e.token_type_embeddings.weight.detach().float()[0:1].expand(t, h).contiguous())
+        emb = ops.add(emb, pos_type.repeat(b, 1).contiguous())
+        s_emb = seeds.next()
+        ph = c.hidden_dropout_prob if train else 0.0
+        hid = ops.dropout(self.ln_e.forward(emb), ph, s_emb)
+        for blk in self.blocks:
+            hid = blk.forward(hid, bits, b, t, seeds, train)
+        self.saved = (ids, b, t, h, ph, s_emb)
+        return hid
+
+    def backward(self, dh: Tensor) -> None:
+        ids, b, t, h, ph, s_emb = self.saved
+        d = dh
+        for blk in reversed(self.blocks):
+            d = blk.backward(d)
+        d = self.ln_e.backward(ops.dropout(d, ph, s_emb))
+        e = self.bert.embeddings
+        if e.position_embeddings.weight.requires_grad:
+            g = _grad(e.position_embeddings.weight)
+            _acc(g[:t], ops.colsum(d.view(b, t * h)).view(t, h))
+        if e.token_type_embeddings.weight.requires_grad:
+            g = _grad(e.token_type_embeddings.weight)
+            _acc(g[0], ops.colsum(d))
+        if e.word_embeddings.weight.requires_grad:
+            # scatter-add of B*T rows into the vocabulary table: index plumbing (torch), no arithmetic beyond the adds
+            _grad(e.word_embeddings.weight).index_add_(0, ids.view(-1), d)
+        self.saved = None
+
+
+class MLPHead:
+    """explainer_mlp: ViT [LN, Linear, GELU, Linear, GELU, Linear] (:92-100) / BERT without the LN (:114-121)."""
+
+    def __init__(self, seq: nn.Sequential):
+        mods = list(seq)
+        self.ln = Norm(mods[0], mods[0].eps) if isinstance(mods[0], nn.LayerNorm) else None
+        lins = [m for m in mods if isinstance(m, nn.Linear)]
+        self.l1, self.l2, self.l3 = Lin([lins[0]]), Lin([lins[1]]), Lin([lins[2]])
+        self.saved = None
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.ln is not None:
+            x = self.ln.forward(x)
+        a = self.l1.forward(x)
+        ga = ops.gelu(a)
+        bb = self.l2.forward(ga)
+        gb = ops.gelu(bb)
+        self.saved = (a, bb)
+        return self.l3.forward(gb, L.AG_EPI_BIAS_F32)
+
+    def backward(self, dpred: Tensor) -> Tensor:
+        a, bb = self.saved
+        d = self.l3.backward(dpred)
+        d = self.l2.backward(ops.gelu_bwd(bb, d))
+        d = self.l1.backward(ops.gelu_bwd(a, d))
+        if self.ln is not None:
+            d = self.ln.backward(d)
+        self.saved = None
+        return d
+
+
+def _cross_entropy(logits: Tensor, labels: Tensor) -> Tuple[Tensor, Tensor]:
+    """F.cross_entropy(x, labels) (mean) and its gradient wrt x, from the soft-max kernel; the one-hot
+    subtraction is index plumbing on a [B,C] tensor."""
+    s = ops.softmax_rows(logits)
+    b = logits.shape[0]
+    picked = s.gather(1, labels.view(-1, 1).to(torch.int64))
+    loss = -(picked.log()).mean()
+    g = s.clone()
+    g.scatter_add_(1, labels.view(-1, 1).to(torch.int64), torch.full((b, 1), -1.0, device=s.device))
+    return loss, g / b
+
+
+class ExplainerTrainer:
+    """fw_explainer + loss_shapley_new with gradients (vanilla / froyo / duo; ViT or BERT)."""
+
+    def __init__(self, recipe, m_explainer: nn.Module):
+        self.recipe, self.m = recipe, m_explainer
+        cfg = m_explainer.config
+        self.is_vit = hasattr(m_explainer, "vit")
+        self.duo = bool(recipe.training.exp_variant_duo)
+        self.kind = L.AG_MASK_VIT_MUL if self.is_vit else L.AG_MASK_BERT_ADD
+        self.backbone = ViTBackboneTrainer(m_explainer.vit) if self.is_vit else BertBackboneTrainer(m_explainer.bert)
+        self.backbone_frozen = not _any_trainable(m_explainer.vit if self.is_vit else m_explainer.bert)
+        self.attn = [Block(ly, self.kind, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob,
+                           cfg.attention_probs_dropout_prob) for ly in m_explainer.explainer_attn]
+        self.mlp = MLPHead(m_explainer.explainer_mlp)
+        self.cls = Lin([m_explainer.classifier]) if self.duo else None
+        self.pool = Lin([m_explainer.bert_pooler.dense]) if (self.duo and not self.is_vit) else None
+        self.step = 0
+
+    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
+                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+        """One reference training-step body (scripts/train_explainer.py:182-196 / train_duo_explainer.py:180-196):
+        explainer forward (all-ones mask), loss, backward into param.grad.  -> (loss tensor [1], phi)."""
+        cfg = self.m.config
+        engine.set_precision("fp32")
+        self.step += 1
+        seeds = Seeds(seed * 7919 + self.step)
+        b = xs.shape[0]
+        p = self.recipe.n_players(cfg)
+        t, h, c = p + 1, cfg.hidden_size, cfg.num_labels
+        ones_bits = engine.ones_mask_bits(b, p, xs.device)
+        z = self.backbone.forward(xs, ones_bits, seeds, train)          # [B*T, H] (ViT: after the final LN)
+        o = z
+        for blk in self.attn:
+            o = blk.forward(o, ones_bits, b, t, seeds, train)
+        s_exp = seeds.next()
+        ph = cfg.hidden_dropout_prob if (train and not self.is_vit) else 0.0   # BERT explainer_dropout (:152)
+        o = ops.dropout(o, ph, s_exp)
+        pred = self.mlp.forward(o).view(b, t, c)
+        phi = ops.shapley_normalize(pred, v_1, v_0, normalize=bool(cfg.explainer_normalize))
+        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
+        total = loss
+        dz_extra = None
+        if self.duo:
+            zc = z.view(b, t, h)[:, 0, :].contiguous()
+            if self.is_vit:
+                logits = self.cls.forward(zc, L.AG_EPI_BIAS_F32)
+                probs = ops.softmax_rows(logits)                          # duo-ViT: CE on probabilities (:121-122, A.5)
+                ce, dprobs = _cross_entropy(probs, labels)
+                dz_cls = self.cls.backward(ops.softmax_rows_bwd(probs, dprobs))
+            else:
+                pooled = self.pool.forward(zc, L.AG_EPI_BIAS_TANH)
+                s_pool = seeds.next()
+                pooled_d = ops.dropout(pooled, cfg.hidden_dropout_prob if train else 0.0, s_pool)
+                logits = self.cls.forward(pooled_d, L.AG_EPI_BIAS_F32)   # duo-BERT: raw logits (:142-144)
+                ce, dlogits = _cross_entropy(logits, labels)
+                dp = ops.dropout(self.cls.backward(dlogits), cfg.hidden_dropout_prob if train else 0.0, s_pool)
+                dz_cls = self.pool.backward(ops.tanh_bwd(pooled, dp))
+            total = loss + ce
+            dz_extra = torch.zeros((b, t, h), dtype=torch.float32, device=xs.device)
+            dz_extra[:, 0, :].copy_(dz_cls)
+        # ---- backward ----
+        dpred = ops.shapley_normalize_bwd(dphi, t, normalize=bool(cfg.explainer_normalize)).view(b * t, c)
+        d = ops.dropout(self.mlp.backward(dpred), ph, s_exp)
+        for blk in reversed(self.attn):
+            d = blk.backward(d)
+        if dz_extra is not None:
+            d = ops.add(d, dz_extra.view(b * t, h))
+        if not self.backbone_frozen:
+            self.backbone.backward(d)
+        return total, phi
+
+
+class SurrogateTrainer:
+    """fw_surrogate on masked inputs + loss_logits_kl_divergence with gradients (scripts/train_surrogate.py:133-147)."""
+
+    def __init__(self, recipe, m_surrogate: nn.Module):
+        self.recipe, self.m = recipe, m_surrogate
+        self.is_vit = hasattr(m_surrogate, "vit")
+        self.backbone = ViTBackboneTrainer(m_surrogate.vit) if self.is_vit else BertBackboneTrainer(m_surrogate.bert)
+        self.cls = Lin([m_surrogate.classifier])
+        self.pool = None if self.is_vit else Lin([m_surrogate.bert_pooler.dense])
+        self.step = 0
+
+    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+        cfg = self.m.config
+        engine.set_precision("fp32")
+        self.step += 1
+        seeds = Seeds(seed * 104729 + self.step)
+        b = xs.shape[0]
+        p = self.recipe.n_players(cfg)
+        t, h = p + 1, cfg.hidden_size
+        z = self.backbone.forward(xs, bits, seeds, train)
+        zc = z.view(b, t, h)[:, 0, :].contiguous()
+        if self.is_vit:
+            logits = self.cls.forward(zc, L.AG_EPI_BIAS_F32)
+        else:
+            pooled = self.pool.forward(zc, L.AG_EPI_BIAS_TANH)
+            s_pool = seeds.next()
+            ph = cfg.hidden_dropout_prob if train else 0.0
+            logits = self.cls.forward(ops.dropout(pooled, ph, s_pool), L.AG_EPI_BIAS_F32)
+        probs = ops.softmax_rows(logits)
+        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
+        dlogits = ops.softmax_rows_bwd(probs, dprobs)
+        if self.is_vit:
+            dzc = self.cls.backward(dlogits)
+        else:
+            dp = ops.dropout(self.cls.backward(dlogits), ph, s_pool)
+            dzc = self.pool.backward(ops.tanh_bwd(pooled, dp))
+        dz = torch.zeros((b, t, h), dtype=torch.float32, device=xs.device)
+        dz[:, 0, :].copy_(dzc)
+        self.backbone.backward(dz.view(b * t, h))
+        return loss, probs

@@ -194,6 +194,41 @@ int ag_encoder_forward(const ag_encoder_desc* desc, const void* d_h0, int R, int
                        void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward-pass building blocks (fp32) for explainer / surrogate training — what torch.autograd does
+ * for the reference in scripts/train_explainer.py:184-198 and scripts/train_surrogate.py:145-147.
+ * Linear backward reuses ag_gemm:  dX = ag_gemm(dY, Wᵀ),  dW = ag_gemm(dYᵀ, Xᵀ)  (K dims zero-padded
+ * to a multiple of 32 by the caller), db = ag_colsum_f32(dY).
+ * ---------------------------------------------------------------------------------------------- */
+/* dst[c, r] = src[r, c]; src row stride lds, dst row stride ldd (>= rows; padding untouched). */
+int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t lds, float* d_dst, int64_t ldd, void* stream);
+/* out[n] (+)= sum_m x[m, n]  (bias gradients). */
+int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream);
+/* exact-erf GELU (nn.GELU default) and its derivative: du = dy * gelu'(u). */
+int ag_gelu_f32(const float* d_u, float* d_y, int64_t n, void* stream);
+int ag_gelu_bwd_f32(const float* d_u, const float* d_dy, float* d_du, int64_t n, void* stream);
+/* dx = dy * (1 - y^2)  (BERT pooler tanh). */
+int ag_tanh_bwd_f32(const float* d_y, const float* d_dy, float* d_dx, int64_t n, void* stream);
+int ag_add_f32(const float* d_a, const float* d_b, float* d_y, int64_t n, void* stream);
+/* inverted dropout with a counter-based keep decision hash(seed, index): y = keep ? x/(1-p) : 0.
+ * Calling it on dy with the same (p, seed) is the backward (nn.Dropout, p = hidden_dropout_prob). */
+int ag_dropout_f32(const float* d_x, float* d_y, int64_t n, float p, uint32_t seed, void* stream);
+/* dx = y * (dy - sum_c y*dy)  for y = softmax(x) rows. */
+int ag_softmax_rows_bwd(const float* d_y, const float* d_dy, float* d_dx, int rows, int C, void* stream);
+/* LayerNorm backward: dx [rows,H]; dgamma/dbeta [H] (= or += when accumulate); gamma may be NULL (ones).
+ * d_scratch: >= 128*2*H floats. */
+int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const float* d_dy, int rows, int H, float eps,
+                     float* d_dx, float* d_dgamma, float* d_dbeta, int accumulate, float* d_scratch, void* stream);
+/* fp32 masked attention forward WITH attention-probability dropout (training); p_drop = 0 is the plain
+ * forward.  Same layout as ag_masked_attention (AG_F32). */
+int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H,
+                              int heads, int mask_mode, float p_drop, uint32_t seed, void* stream);
+/* its backward: dqkv [R,T,3H] from dctx, recomputing the probabilities (two passes, no atomics).
+ * d_stats: R*heads*T*3 floats of scratch. */
+int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
+                            float* d_dqkv, float* d_stats, int R, int T, int H, int heads, int mask_mode,
+                            float p_drop, uint32_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * In-library kernel timing (used by bench.py for the roofline block): when enabled, every launch of
  * an instrumented kernel class is bracketed by hipEvents on the launch stream.  ag_profile_collect
  * synchronises those events, returns the totals of one class since the last collect and clears it.

@@ -41,6 +41,73 @@ def _prepend_cls(mask_p):
     return torch.cat([torch.ones((mask_p.shape[0], 1), dtype=mask_p.dtype), mask_p], dim=1)
 
 
+def _vit_layer(h, mask_t, sd: SD, p: str, nh: int, eps: float, norm1_identity: bool = False):
+    u = h if norm1_identity else _ln(h, sd, p + ".layernorm_before", eps)
+    a = _attention(u, mask_t, sd, p + ".attention.self", nh, "vit")
+    h = h + _lin(a, sd, p + ".attention.output.dense")
+    w = _ln(h, sd, p + ".layernorm_after", eps)
+    return _lin(F.gelu(_lin(w, sd, p + ".intermediate.dense")), sd, p + ".output.dense") + h
+
+
+def _bert_layer(h, mask_t, sd: SD, p: str, nh: int, eps: float, norm1_identity: bool = False):
+    ctx = _attention(h, mask_t, sd, p + ".attention.self", nh, "bert")
+    a = _lin(ctx, sd, p + ".attention.output.dense") + h
+    if not norm1_identity:
+        a = _ln(a, sd, p + ".attention.output.LayerNorm", eps)
+    return _ln(_lin(F.gelu(_lin(a, sd, p + ".intermediate.dense")), sd, p + ".output.dense") + a, sd, p + ".output.LayerNorm", eps)
+
+
+def vit_backbone(x, mask_t, sd: SD, cfg: dict):
+    pr = "vit.embeddings"
+    e = F.conv2d(x, sd[pr + ".patch_embeddings.projection.weight"], sd[pr + ".patch_embeddings.projection.bias"],
+                 stride=cfg["img_patch_size"]).flatten(2).transpose(1, 2)
+    h = torch.cat([sd[pr + ".cls_token"].expand(x.shape[0], -1, -1), e], dim=1) + sd[pr + ".position_embeddings"]
+    for i in range(cfg["num_hidden_layers"]):
+        h = _vit_layer(h, mask_t, sd, f"vit.encoder.layers.{i}", cfg["num_attention_heads"], cfg["layer_norm_eps"])
+    return _ln(h, sd, "vit.layernorm", cfg["layer_norm_eps"])
+
+
+def bert_backbone(ids, mask_t, sd: SD, cfg: dict):
+    t = ids.shape[1]
+    pr = "bert.embeddings"
+    e = sd[pr + ".word_embeddings.weight"][ids] + sd[pr + ".token_type_embeddings.weight"][0]
+    e = e + sd[pr + ".position_embeddings.weight"][:t][None]
+    h = _ln(e, sd, pr + ".LayerNorm", cfg["layer_norm_eps"])
+    for i in range(cfg["num_hidden_layers"]):
+        h = _bert_layer(h, mask_t, sd, f"bert.encoder.layers.{i}", cfg["num_attention_heads"], cfg["layer_norm_eps"])
+    return h
+
+
+def explainer_phi(x, mask_p, grand, null, sd: SD, cfg: dict, kind: str):
+    """Differentiable fw_explainer (dropout off): reference models/vanilla_vit.py:102-130 / vanilla_bert.py:123-162.
+    Used by the gradient parity tests (torch autograd on the CPU as the checker)."""
+    mask_t = _prepend_cls(mask_p)
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    if kind == "vit":
+        z = vit_backbone(x, mask_t, sd, cfg)
+        o = z
+        for j in range(cfg["explainer_attn_num_layers"]):
+            o = _vit_layer(o, mask_t, sd, f"explainer_attn.{j}", nh, eps, norm1_identity=(j == 0))
+        o = F.layer_norm(o, (o.shape[-1],), sd["explainer_mlp.0.weight"], sd["explainer_mlp.0.bias"], 1e-5)
+        o = _lin(F.gelu(_lin(F.gelu(_lin(o, sd, "explainer_mlp.1")), sd, "explainer_mlp.3")), sd, "explainer_mlp.5")
+    else:
+        z = bert_backbone(x, mask_t, sd, cfg)
+        o = z
+        for j in range(cfg["explainer_attn_num_layers"]):
+            o = _bert_layer(o, mask_t, sd, f"explainer_attn.{j}", nh, eps, norm1_identity=(j == 0))
+        o = _lin(F.gelu(_lin(F.gelu(_lin(o, sd, "explainer_mlp.0")), sd, "explainer_mlp.2")), sd, "explainer_mlp.4")
+    if cfg["explainer_normalize"]:
+        t = o.shape[1]
+        o = o + ((grand.unsqueeze(1) - null.reshape(1, 1, -1)) - o.sum(dim=1, keepdim=True)) / t
+    return o[:, 1:, :].permute(0, 2, 1), z
+
+
+def shapley_loss(mask, v0, vs, phi, n_players: int):
+    b, k, _ = mask.shape
+    pred = v0.reshape(1, 1, -1) + mask.float() @ phi.permute(0, 2, 1)
+    return n_players * F.mse_loss(pred.reshape(b * k, -1), vs, reduction="mean")
+
+
 @torch.no_grad()
 def vit_surrogate(x, mask_p, sd: SD, cfg: dict):
     """x [R,3,px,px] fp32, mask_p [R,P] int64 -> probabilities [R,C]."""

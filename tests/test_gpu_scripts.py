@@ -82,9 +82,3 @@ def test_surrogate_kl_batch(cuda_device):
     assert dcur.shape == adapt.shape
 
 
-def test_training_entry_points_fail_loudly():
-    from autognothi_amd.scripts import train_explainer as te, train_surrogate as ts
-    with pytest.raises(NotImplementedError):
-        te.explainer_epoch_train()
-    with pytest.raises(NotImplementedError):
-        ts.surrogate_epoch_train()

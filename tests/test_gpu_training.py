@@ -1,0 +1,124 @@
+"""GPU: explainer / surrogate training step (HIP forward + backward) against torch autograd on the CPU port
+(oracle/torch_port.py) — gradients of every trainable parameter, dropout off."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_port as otp
+from util import build_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _zero_dropout(meta):
+    prm = dict(meta["params"])
+    prm["attention_probs_dropout_prob"] = 0.0
+    prm["hidden_dropout_prob"] = 0.0
+    return prm
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("tag", ["froyo_vit_tiny_l3", "vit_tiny_c1", "bert_base_l2"])
+def test_explainer_step_gradients_match_autograd(cuda_device, tag):
+    from autognothi_amd.training import ExplainerTrainer
+    from autognothi_amd import ops
+    c = build_case(tag)
+    dev, g, recipe = cuda_device, c["g"], c["recipe"]
+    prm = _zero_dropout(c["meta"])
+    if tag == "vit_tiny_c1":
+        prm["num_hidden_layers"] = 2  # keep the CPU autograd reference quick
+    cfg = recipe.t_config(**prm)
+    exp = recipe.t_explainer(cfg)
+    from autognothi_amd.utils import synth
+    synth.load_synth_weights(exp, seed=1)
+    exp = exp.to(dev)
+    exp.train()                      # froyo: freezes vit.* (models/froyo_vit.py:88-97)
+    kind = c["meta"]["kind"]
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    masks = torch.from_numpy(c["masks"])
+    bits = ops.pack_mask(masks.to(dev))
+    v0, vs, v1 = [torch.from_numpy(g[k]) for k in ("v_0", "v_s", "v_1")]
+    tr = ExplainerTrainer(recipe, exp)
+    loss, phi = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], train=True)
+    # ---- CPU autograd reference on the same weights ----
+    sd = {k: v.detach().cpu().clone().requires_grad_(exp.state_dict(keep_vars=True)[k].requires_grad)
+          for k, v in exp.state_dict(keep_vars=True).items()}
+    ones = torch.ones((c["B"], c["P"]), dtype=torch.long)
+    phi_ref, _ = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
+    loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref, c["P"])
+    loss_ref.backward()
+    np.testing.assert_allclose(loss.cpu().numpy()[0], loss_ref.item(), rtol=2e-4)
+    np.testing.assert_allclose(phi.cpu().numpy(), phi_ref.detach().numpy(), rtol=1e-3, atol=2e-5)
+    checked = 0
+    gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for name, p in exp.named_parameters():
+        ref = sd[name].grad
+        if not p.requires_grad:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert ref is not None and p.grad is not None, name
+        got = p.grad.cpu().numpy()
+        if float(ref.abs().max()) < 1e-5 * gscale:   # structurally zero gradients (e.g. key.bias: soft-max shift invariance)
+            assert float(np.abs(got).max()) < 1e-4 * gscale, name
+            continue
+        assert _rel(got, ref.numpy()) < 2e-3, (name, _rel(got, ref.numpy()))
+        checked += 1
+    assert checked >= 10
+
+
+def test_surrogate_step_gradients_match_autograd(cuda_device):
+    from autognothi_amd.training import SurrogateTrainer
+    from autognothi_amd import ops
+    from autognothi_amd.utils import synth
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    prm = _zero_dropout(c["meta"]); prm["num_hidden_layers"] = 2
+    cfg = recipe.t_config(**prm)
+    srg = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(srg, seed=0)
+    srg = srg.to(dev).train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    masks = torch.from_numpy(c["masks"][:c["B"]])
+    bits = ops.pack_mask(masks.to(dev))
+    orig = torch.softmax(torch.from_numpy(np.random.default_rng(2).standard_normal((c["B"], 10)).astype(np.float32)), -1)
+    tr = SurrogateTrainer(recipe, srg)
+    loss, probs = tr.loss_and_grads(xs, bits, orig.to(dev), train=True)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in srg.state_dict().items()}
+    mask_t = torch.cat([torch.ones((c["B"], 1), dtype=torch.long), masks], 1)
+    z = otp.vit_backbone(torch.from_numpy(c["xs"]), mask_t, sd, prm)
+    p_ref = torch.softmax(torch.nn.functional.linear(z[:, 0], sd["classifier.weight"], sd["classifier.bias"]), -1)
+    l_ref = torch.nn.functional.kl_div(torch.log_softmax(orig, -1), torch.softmax(p_ref, -1), reduction="batchmean")
+    l_ref.backward()
+    np.testing.assert_allclose(loss.cpu().numpy()[0], l_ref.item(), rtol=1e-3, atol=1e-7)
+    gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for name, p in srg.named_parameters():
+        r = sd[name].grad
+        if float(r.abs().max()) < 1e-5 * gscale:
+            assert float(p.grad.abs().max()) < 1e-4 * gscale, name
+            continue
+        assert _rel(p.grad.cpu().numpy(), r.numpy()) < 3e-3, (name, _rel(p.grad.cpu().numpy(), r.numpy()))
+
+
+def test_explainer_train_epoch_reduces_loss(cuda_device):
+    """End-to-end: a few optimiser steps of explainer_epoch_train (dropout on, AdamW) lower the Shapley loss."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import train_explainer as te
+    c = build_case("froyo_vit_tiny_l3")
+    dev, recipe = cuda_device, c["recipe"]
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    engine.set_precision("fp32")
+    v0 = torch.from_numpy(c["g"]["v_0"]).to(dev)
+    opt = torch.optim.AdamW([p for p in exp.parameters()], lr=1e-3)
+    items = [(None, None)] * 3
+    gen = lambda a, b: (xs, torch.zeros(c["B"], dtype=torch.long, device=dev))  # noqa: E731
+    first = te.explainer_epoch_train(None, dev, 4, c["P"], v0, items, recipe, srg, exp, opt, 1, gen, seed=1)
+    for e in range(2, 6):
+        last = te.explainer_epoch_train(None, dev, 4, c["P"], v0, items, recipe, srg, exp, opt, e, gen, seed=1)
+    assert last < first
+    for n, p in exp.named_parameters():
+        if n.startswith("vit."):
+            assert not p.requires_grad
