@@ -15,7 +15,7 @@ from typing import Any, Callable, Iterable, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .. import ops
+from .. import distributed, ops
 from ..recipes.types import ModelRecipe
 from .common import Log, device_rng
 
@@ -92,6 +92,8 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
         loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
                                             seed=(seed or 0) + epoch)
+        # N>1 ranks (rows sharded by input): average gradients over RCCL in a few large buckets (no-op at N=1)
+        distributed.allreduce_grads([p for p in m_explainer.parameters() if p.requires_grad], average=True)
         optimizer.step()
         lv = float(loss.item())
         reg_loss += lv

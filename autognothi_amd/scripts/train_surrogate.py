@@ -9,7 +9,7 @@ from typing import Any, Callable, Iterable, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .. import ops
+from .. import distributed, ops
 from ..recipes.types import ModelRecipe
 from .common import Log, device_rng
 
@@ -67,6 +67,7 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
         with torch.no_grad():
             orig, _ = m_recipe.fw_classifier(m_classifier, xs, ones)
         loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
+        distributed.allreduce_grads([p for p in m_surrogate.parameters() if p.requires_grad], average=True)
         optimizer.step()
         tot += float(loss.item()) * b
         n += b

@@ -21,7 +21,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("tag", ["froyo_vit_tiny_l3", "vit_tiny_c1", "bert_base_l2"])
+@pytest.mark.parametrize("tag", ["froyo_vit_tiny_l3", "vit_tiny_c1", "bert_base_l2", "duo_vit_tiny_l3", "duo_bert_base_l2"])
 def test_explainer_step_gradients_match_autograd(cuda_device, tag):
     from autognothi_amd.training import ExplainerTrainer
     from autognothi_amd import ops
@@ -42,13 +42,23 @@ def test_explainer_step_gradients_match_autograd(cuda_device, tag):
     bits = ops.pack_mask(masks.to(dev))
     v0, vs, v1 = [torch.from_numpy(g[k]) for k in ("v_0", "v_s", "v_1")]
     tr = ExplainerTrainer(recipe, exp)
-    loss, phi = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], train=True)
+    duo = c["meta"]["duo"]
+    labels = torch.tensor([1, 0][:c["B"]], dtype=torch.long)
+    loss, phi = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], labels=labels.to(dev), train=True)
     # ---- CPU autograd reference on the same weights ----
     sd = {k: v.detach().cpu().clone().requires_grad_(exp.state_dict(keep_vars=True)[k].requires_grad)
           for k, v in exp.state_dict(keep_vars=True).items()}
     ones = torch.ones((c["B"], c["P"]), dtype=torch.long)
-    phi_ref, _ = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
+    phi_ref, z_ref = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
     loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref, c["P"])
+    if duo:  # scripts/train_duo_explainer.py:184-195: + cross_entropy(base_Ys, Zs)
+        lin = torch.nn.functional.linear
+        if kind == "vit":   # CE applied on the soft-maxed head output (duo_vanilla_vit.py:121-122)
+            base = torch.softmax(lin(z_ref[:, 0], sd["classifier.weight"], sd["classifier.bias"]), -1)
+        else:               # raw logits through the pooler (duo_vanilla_bert.py:142-144)
+            base = lin(torch.tanh(lin(z_ref[:, 0], sd["bert_pooler.dense.weight"], sd["bert_pooler.dense.bias"])),
+                       sd["classifier.weight"], sd["classifier.bias"])
+        loss_ref = loss_ref + torch.nn.functional.cross_entropy(base, labels)
     loss_ref.backward()
     np.testing.assert_allclose(loss.cpu().numpy()[0], loss_ref.item(), rtol=2e-4)
     np.testing.assert_allclose(phi.cpu().numpy(), phi_ref.detach().numpy(), rtol=1e-3, atol=2e-5)
