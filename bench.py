@@ -211,10 +211,18 @@ def main():
                                      "tflops": round(s[1] / max(s[0], 1e-9) / 1e9, 1),
                                      "algo_gb_s": round(s[2] / max(s[0], 1e-9) / 1e6, 1)}
                       for c, s in stats.items() if s[3]}
+        traffic = None
+        try:  # measured in a separate rocprofv3 --pmc run of this same command (tools/profile_round.sh), committed
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if (tj["workload"], tj["batch"], tj["masks"], tj["precision"]) == (args.workload, B, K, args.precision):
+                traffic = tj["traffic_bytes_per_launch"].get(EPI_NAMES[dom])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             "bound": "mfma", "kernel": EPI_NAMES[dom], "launches": int(n), "avg_launch_us": round(1e3 * ms / max(1, n), 2),
             "achieved": round(fl / max(ms, 1e-9) / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": None,
+            "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(by / max(1, n)),
             "whole_step": {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
                            "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
                            "exec_tflops": round(value / world * f_exec / 1e12, 1),

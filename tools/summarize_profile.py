@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Collapse rocprofv3 counter_collection CSVs (one row per dispatch and counter) into per-kernel means.
+usage: summarize_profile.py <prof_dir> <out.json>"""
+import collections, csv, glob, json, os, re, sys
+
+prof, out = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    m = re.search(r"(gemm_ring_kernel<[^>]*>|gemm_kernel<[^>]*>|attn_[a-z0-9_]+(<[^>]*>)?|layernorm_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
+    return m.group(1) if m else name[:60]
+
+
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("fetch", "write", "sq", "tcc"):
+    for f in glob.glob(os.path.join(prof, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            res[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {}
+for k, counters in res.items():
+    if "at::native" in k or "rocclr" in k:
+        continue
+    summary[k] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in counters.items()}
+    c = summary[k]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # units: KiB per dispatch.  gfx950: FETCH_SIZE reports half the bytes of wide coalesced streaming reads
+        # (MI355X_MICROARCH.md §HBM) -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+        c["traffic_bytes_per_launch"] = c["FETCH_SIZE"]["mean"] * 1024 * 2 + c["WRITE_SIZE"]["mean"] * 1024
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        h, m = c["TCC_HIT_sum"]["mean"], c["TCC_MISS_sum"]["mean"]
+        c["l2_hit_rate"] = h / max(h + m, 1.0)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        # GRBM_GUI_ACTIVE is summed over 8 XCDs; 1024 SIMDs issue MFMAs
+        c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / max(c["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024, 1.0)
+json.dump(summary, open(out, "w"), indent=1)
+for k, c in sorted(summary.items(), key=lambda kv: -kv[1].get("traffic_bytes_per_launch", 0)):
+    print(k, {x: (round(y, 3) if isinstance(y, float) else round(y["mean"], 1)) for x, y in c.items() if x in ("traffic_bytes_per_launch", "l2_hit_rate", "mfma_busy_frac", "FETCH_SIZE", "WRITE_SIZE")})
