@@ -24,7 +24,8 @@ vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_flo
 
 class ag_layer_weights(C.Structure):
     _fields_ = [(n, vp) for n in ("w_qkv", "b_qkv", "w_o", "b_o", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
-                                  "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+                                  "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                                  "w_qkv_ln", "b_qkv_ln", "s_qkv_ln", "w_fc1_ln", "b_fc1_ln", "s_fc1_ln")]
 
 
 class ag_encoder_desc(C.Structure):
@@ -47,7 +48,9 @@ SIGNATURES = {
     "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
     "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
-    "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp]),
+    "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
+    "ag_row_stats_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "ag_vit_assemble": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -108,4 +108,4 @@ struct AgProfScope {
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                 const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
-                hipStream_t s);
+                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s);

@@ -166,6 +166,23 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
     }
 }
 
+// (sum, sumsq) of each row of the bf16 stream — LayerNorm statistics for the folded GEMM epilogue when the
+// producing GEMM did not accumulate them (layer 0's embeddings)
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, int64_t ldx, int rows, int H, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const float4 v = load4_as_f32(xr + c);
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (lane == 0) { stats[2 * (int64_t)row] = s; stats[2 * (int64_t)row + 1] = q; }
+}
+
 __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int C) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -259,6 +276,14 @@ extern "C" int ag_softmax_rows(const float* d_x, float* d_y, int rows, int C, vo
     AG_REQUIRE(d_x && d_y && rows >= 0 && C >= 1, "ag_softmax_rows: bad arguments");
     if (rows == 0) return AG_OK;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, d_x, d_y, rows, C);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream) {
+    AG_REQUIRE(d_x && d_stats && rows >= 0 && H % 4 == 0 && ldx % 4 == 0, "ag_row_stats_bf16: bad arguments");
+    if (rows == 0) return AG_OK;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_x, ldx, rows, H, d_stats);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

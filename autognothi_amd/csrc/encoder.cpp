@@ -24,6 +24,8 @@ struct Ws {
     char* inter;   // [M, I]
     char* hx;      // [M, H]   residual stream after the attention block
     char* ha;      // [M, H]   BERT: post-attention LayerNorm output
+    float* st1;    // [M, 2]   (sum, sumsq) of the rows entering LN1 (folded into the QKV GEMM)
+    float* st2;    // [M, 2]   same for LN2 (folded into fc1)
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -39,7 +41,9 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* inter = take(M * d->I * es);
     char* hx = take(M * d->H * es);
     char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * es) : nullptr;
-    if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; }
+    char* st1 = take(M * 2 * sizeof(float));
+    char* st2 = take(M * 2 * sizeof(float));
+    if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; ws->st1 = (float*)st1; ws->st2 = (float*)st2; }
     return off;
 }
 
@@ -71,45 +75,79 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
 
     const char* h_in = (const char*)d_h0;  // residual stream entering the layer (storage dtype)
     int in_share = share;                  // how many rows share one h_in sequence
+    bool st1_ready = false;                // ws.st1 holds the row statistics of h_in (written by the previous fc2)
+    hipStream_t hs = (hipStream_t)stream;
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         const bool last_cls = cls_only_last && (l == d->n_layers - 1);
         const int Min = (R / in_share) * T;  // distinct rows entering this layer
-        // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
-        const char* att_in = h_in;
-        if (vit && w.ln1_g) {
-            TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, stream));
-            att_in = ws.xs;
+        const int Mo = last_cls ? R : M;     // rows processed after attention: all tokens, or only token 0 of each row
+        const int Tq = last_cls ? 1 : T;
+        const int64_t ld_tok = last_cls ? (int64_t)T * H : H;  // stride between processed rows inside [R,T,H] buffers
+        // LayerNorm folding (ViT, bf16, large GEMMs): the LN kernels disappear; row statistics come from the
+        // producing GEMM's epilogue (or ag_row_stats_bf16 for the embeddings) and are applied in the consumer's.
+        const bool fold1 = vit && w.ln1_g && w.w_qkv_ln && ag_gemm_supports_ln_fold(Min, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt);
+        const bool fold2 = vit && w.w_fc1_ln && ag_gemm_supports_ln_fold(Mo, I, H, H, I, 0, AG_EPI_BIAS_GELU, dt) &&
+                           ag_gemm_supports_ln_fold(Mo, H, H, ld_tok, H, ld_tok, AG_EPI_BIAS_RESID, dt);
+        // will the NEXT layer fold its LN1?  then this layer's fc2 accumulates the statistics of what it writes
+        bool next_fold1 = false;
+        if (vit && l + 1 < d->n_layers && !last_cls) {
+            const ag_layer_weights& wn = d->layers[l + 1];
+            next_fold1 = wn.ln1_g && wn.w_qkv_ln && ag_gemm_supports_ln_fold(M, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt) &&
+                         ag_gemm_supports_ln_fold(Mo, H, I, I, ld_tok, H, AG_EPI_BIAS_RESID, dt);
         }
-        TRY(ag_gemm(att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt, stream));
+        // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
+        if (fold1) {
+            if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
+            TRY(ag_gemm(h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
+                        ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, stream));
+        } else {
+            const char* att_in = h_in;
+            if (vit && w.ln1_g) {
+                TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+                att_in = ws.xs;
+            }
+            TRY(ag_gemm(att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
+                        nullptr, nullptr, 0.f, nullptr, stream));
+        }
+        st1_ready = false;
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
-        // rows processed after attention: all tokens, or only token 0 of each row
-        const int Mo = last_cls ? R : M;
-        const int Tq = last_cls ? 1 : T;                         // tokens per sequence in the processed view
-        const int64_t ld_tok = last_cls ? (int64_t)T * H : H;    // stride between processed rows inside [R,T,H] buffers
         // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
-        TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt, stream));
+        if (fold2) AG_HIP_CHECK(hipMemsetAsync(ws.st2, 0, (size_t)Mo * 2 * sizeof(float), hs));
+        TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
+                    nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, stream));
         if (vit) {
-            TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, stream));
-            TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, stream));
+            if (fold2) {
+                TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
+                            ws.st2, w.s_fc1_ln, d->ln_eps, nullptr, stream));
+            } else {
+                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+                TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
+                            nullptr, nullptr, 0.f, nullptr, stream));
+            }
             // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
+            if (next_fold1) AG_HIP_CHECK(hipMemsetAsync(ws.st1, 0, (size_t)M * 2 * sizeof(float), hs));
+            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
+                        nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, stream));
+            st1_ready = next_fold1;
         } else {
             const char* a = ws.hx;  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
             if (w.ln1_g) {
                 TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
                 a = ws.ha;
             }
-            TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, stream));
+            TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
+                        nullptr, nullptr, 0.f, nullptr, stream));
             char* pre = (a == ws.hx) ? ws.ha : ws.hx;
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, stream));
+            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
+                        nullptr, nullptr, 0.f, nullptr, stream));
             AG_REQUIRE(w.ln2_g, "ag_encoder_forward: BERT output.LayerNorm missing in layer %d", l);
             if (last_cls) {
                 // LayerNorm the compact [R,H] rows, then scatter them to token 0 of d_h
                 TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
                 hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R,
-                                                hipMemcpyDeviceToDevice, (hipStream_t)stream);
+                                                hipMemcpyDeviceToDevice, hs);
                 if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
             } else {
                 TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, d_h, nullptr, dt, stream));

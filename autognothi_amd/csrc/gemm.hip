@@ -228,7 +228,8 @@ int dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 
 extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                        const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
-                       int epilogue, int dtype, void* stream) {
+                       int epilogue, int dtype, const float* d_ln_stats, const float* d_ln_colsum, float ln_eps,
+                       float* d_stats_out, void* stream) {
     AG_REQUIRE(d_A && d_W && d_C, "ag_gemm: null pointer");
     AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gemm: bad dtype %d", dtype);
@@ -250,7 +251,19 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * es : 0.0), s);
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
-    if (dtype == AG_BF16 && !force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue))
-        return ag_gemm_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue, s);
+    const bool big = dtype == AG_BF16 && !force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
+    AG_REQUIRE(big || (!d_ln_stats && !d_stats_out), "ag_gemm: LayerNorm folding is only available on the large-M bf16 path "
+               "(check ag_gemm_supports_ln_fold first)");
+    AG_REQUIRE(!d_ln_stats || d_ln_colsum, "ag_gemm: ln_stats given without ln_colsum");
+    if (big)
+        return ag_gemm_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue,
+                           d_ln_stats, d_ln_colsum, ln_eps, d_stats_out, s);
     return dtype == AG_BF16 ? dispatch<bf16_t>(epilogue, a, s) : dispatch<float>(epilogue, a, s);
+}
+
+extern "C" int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype) {
+    static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
+    // consumer side (ln_stats) exists for the bias / bias+gelu epilogues, producer side (stats_out) for bias+residual
+    const bool epi_ok = epilogue == AG_EPI_BIAS || epilogue == AG_EPI_BIAS_GELU || epilogue == AG_EPI_BIAS_RESID;
+    return (dtype == AG_BF16 && !force_small && epi_ok && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue)) ? 1 : 0;
 }

@@ -34,7 +34,12 @@ struct BigArgs {
     const bf16_t* R; long ldr;
     int T, share;
     int M, N, K;
+    // LayerNorm folding (ViT pre-LN, bf16 mode): consumer side  out = rstd[m]*(acc - mean[m]*ln_s[n]) + bias[n]
+    // with (sum, sumsq) of row m in ln_stats[2m..]; producer side accumulates (sum, sumsq) of the rows it writes.
+    const float* ln_stats; const float* ln_s; float ln_eps; float ln_inv_h;
+    float* stats_out;
     unsigned long long* dbg;  // diagnostic build only
+    int desync;    // first-round start offset unit in shader cycles (0 = off)
     int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
 };
 
@@ -72,7 +77,163 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
     return *reinterpret_cast<const uint4*>(lds_half + (row16base + r) * HROWB + ((c ^ swz4((r >> 2) & 3)) << 4));
 }
 
-template <int EPI, bool DBG = false>
+// ---- epilogue of one wave's 128(M) x 64(N) accumulator tile --------------------------------------------
+// The accumulator layout gives a lane 4 consecutive output features of one token (8 bytes of bf16),
+// i.e. 32-byte row segments per store instruction.  Instead each wave transposes its tile through a private
+// piece of the (now idle) ring, 32 rows at a time, and stores whole 128-byte rows: 8 lanes x 16 B per row,
+// 8 rows (1 KiB of full cache lines) per store instruction.
+// Everything the tile needs from memory besides the residual (bias, LayerNorm column sums, row statistics) is
+// requested up front in one batch and the residual rows are prefetched one 16-row block ahead: the epilogue
+// runs with the matrix cores idle, so every exposed L2 round trip in it is paid in full.
+// Out-of-range rows / columns are clamped for the loads and masked at the stores; no divergent branches.
+template <int EPI, bool LNF, bool STATS>
+__device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
+                                              char* stg, const int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
+    constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
+    constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
+    const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
+
+    // ---- column constants ----
+    float4 bv[4], sv[4];
+    int ncl[4];
+#pragma unroll
+    for (int sn = 0; sn < 4; ++sn) {
+        const int n = nw0 + sn * 16 + fq * 4;
+        ncl[sn] = n < p.N ? n : p.N - 4;
+        bv[sn] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sv[sn] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) bv[sn] = *reinterpret_cast<const float4*>(p.bias + ncl[sn]);
+    }
+    if (LNF) {
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) sv[sn] = *reinterpret_cast<const float4*>(p.ln_s + ncl[sn]);
+    }
+    // ---- row constants ----
+    float2 st[8];
+    if (LNF) {
+#pragma unroll
+        for (int sm = 0; sm < 8; ++sm) {
+            int m = mw0 + sm * 16 + frow;
+            m = m < p.M ? m : p.M - 1;
+            st[sm] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m);
+        }
+    }
+    // residual row of output row m: ((m / T) / share) * T + (m % T); walked incrementally (m advances by 16)
+    int r_t = 0, r_seq_rem = 0;
+    long r_base = 0;  // (seq / share) * T
+    uint2 rnext[4];
+    auto resid_issue = [&](uint2 (&dst)[4], bool valid) {   // rows past M are never stored: read row 0 for them
+        const long row = valid ? r_base + r_t : 0;
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn)
+            dst[sn] = *reinterpret_cast<const uint2*>(p.R + row * p.ldr + ncl[sn]);
+    };
+    auto resid_advance = [&]() {
+        r_t += 16;
+        while (r_t >= p.T) {
+            r_t -= p.T;
+            if (++r_seq_rem == p.share) { r_seq_rem = 0; r_base += p.T; }
+        }
+    };
+    if (RESID) {
+        const int m = mw0 + frow;
+        const int seq = m / p.T;
+        r_t = m - seq * p.T;
+        const int sq = seq / p.share;
+        r_seq_rem = seq - sq * p.share;
+        r_base = (long)sq * p.T;
+        resid_issue(rnext, m < p.M);
+    }
+
+#pragma unroll
+    for (int sm = 0; sm < 8; ++sm) {
+        const int m = mw0 + sm * 16 + frow;
+        uint2 rcur[4];
+        if (RESID) {
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn) rcur[sn] = rnext[sn];
+            if (sm < 7) {
+                resid_advance();
+                resid_issue(rnext, m + 16 < p.M);
+            }
+        }
+        float ln_mean = 0.f, ln_rstd = 1.f;
+        if (LNF) {
+            ln_mean = st[sm].x * p.ln_inv_h;
+            ln_rstd = rsqrtf(fmaxf(st[sm].y * p.ln_inv_h - ln_mean * ln_mean, 0.f) + p.ln_eps);
+        }
+        float row_s = 0.f, row_q = 0.f;  // producer side: stats of the bf16-rounded values this lane writes
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+            const int n = nw0 + sn * 16 + fq * 4;
+            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
+            const bool inb = (m < p.M) && (n < p.N);
+            if (LNF) {  // fold the LayerNorm of the A operand's rows into the result
+                const float nm = -ln_mean;
+                v[0] = ln_rstd * fmaf(nm, sv[sn].x, v[0]); v[1] = ln_rstd * fmaf(nm, sv[sn].y, v[1]);
+                v[2] = ln_rstd * fmaf(nm, sv[sn].z, v[2]); v[3] = ln_rstd * fmaf(nm, sv[sn].w, v[3]);
+            }
+            v[0] += bv[sn].x; v[1] += bv[sn].y; v[2] += bv[sn].z; v[3] += bv[sn].w;
+            if (RESID) {
+                v[0] += __uint_as_float(rcur[sn].x << 16); v[1] += __uint_as_float(rcur[sn].x & 0xFFFF0000u);
+                v[2] += __uint_as_float(rcur[sn].y << 16); v[3] += __uint_as_float(rcur[sn].y & 0xFFFF0000u);
+            }
+            if (EPI == AG_EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fast_gelu(v[e]);
+            }
+            if (EPI == AG_EPI_BIAS_TANH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+            }
+            if (OUT_F32) {
+                if (inb) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                *reinterpret_cast<uint2*>(stg + ((sm & 1) * 16 + frow) * SROW + sn * 32 + fq * 8) = pk;
+                if (STATS) {
+                    const float keep = inb ? 1.f : 0.f;
+                    const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xFFFF0000u);
+                    const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xFFFF0000u);
+                    row_s = fmaf(keep, (r0 + r1) + (r2 + r3), row_s);
+                    row_q = fmaf(keep, (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3), row_q);
+                }
+            }
+        }
+        if (STATS) {  // lanes frow + 16*fq hold parts of row m: combine the 4 column groups, one atomic pair per wave and row
+            row_s += __shfl_xor(row_s, 16, 64); row_q += __shfl_xor(row_q, 16, 64);
+            row_s += __shfl_xor(row_s, 32, 64); row_q += __shfl_xor(row_q, 32, 64);
+            if (fq == 0 && m < p.M) {
+                atomicAdd(p.stats_out + 2 * (long)m, row_s);
+                atomicAdd(p.stats_out + 2 * (long)m + 1, row_q);
+            }
+        }
+        if (!OUT_F32 && (sm & 1)) {
+            // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = i * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
+                const int mm = mw0 + (sm - 1) * 16 + rr;
+                if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+                    uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
+                    if (p.nt_store) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dstp));
+                    } else *dstp = val;
+                }
+            }
+        }
+    }
+}
+
+// VAR: 0 plain, 1 LayerNorm-folded consumer (ln_stats / ln_s), 2 row-statistics producer (stats_out)
+template <int EPI, int VAR = 0, bool DBG = false>
 __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,6 +252,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+#define AG_MARK(idx_)                                                                                     \
+    if (DBG && (blockIdx.x == 0 || blockIdx.x == 777) && lane == 0) {                                          \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        p.dbg[(((blockIdx.x ? 1 : 0) * 8 + wave) * 128 + (idx_)) * 8] = t_;                                    \
+    }
+    // Every CU would otherwise reach its epilogue at the same moment: 256 x 128 KiB of stores in one burst
+    // (HBM-write bound for ~20 % of the kernel while the matrix cores idle), then silence.  The first
+    // workgroup of each CU starts ((b>>3)&7) delay units late; CUs run tiles back to back, so the offsets
+    // persist and the store traffic of the 8 phases interleaves with the other CUs' main loops.
+    if (p.desync && b < 256) {
+        const unsigned long long t_end = __builtin_readcyclecounter() + (unsigned long long)(((b >> 3) & 7) * p.desync);
+        while (__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
+    AG_MARK(120)
     const int nh = p.K / 32;  // half-steps
     // prologue: half-steps 0..3 into slots 0..3 (4 glds per wave per half-step)
 #pragma unroll
@@ -118,7 +294,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    AG_MARK(121)
     wait_ahead(min(nh - 1, 3));                     // slot 0 (this wave's pieces) before barrier #0
+    AG_MARK(122)
     if (grp == 1) asm volatile("s_barrier" ::: "memory");
     // this wave's LDS-DMA pieces: 2 of A, 2 of W per half-step
     auto refill = [&](int jn, int which) {  // which: 0,1 = A pieces, 2,3 = W pieces of half-step jn
@@ -177,93 +355,163 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
 
     // ---- epilogue ----
-    // The accumulator layout gives a lane 4 consecutive output features of one token (8 bytes of bf16),
-    // i.e. 32-byte row segments per store instruction.  Instead each wave transposes its 128x64 tile
-    // through its private 16 KiB of the (now idle) ring, 32 rows at a time, and stores whole 128-byte
-    // rows: 8 lanes x 16 B per row, 8 rows (1 KiB of full cache lines) per store instruction.
-    const int frow = lane & 15, fq = lane >> 4;
-    constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
-    constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
+    AG_MARK(123)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (already true: the last half-step waited for 0)
-    if (!OUT_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
-    char* stg = smem + wave * 16384;
-    const int nw0 = n0 + wn * 64;               // first output column of this wave
-    const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
-#pragma unroll
-    for (int sm = 0; sm < 8; ++sm) {
-        const int m = m0 + wm * 128 + sm * 16 + frow;
-        long rrow = 0;
-        if (EPI == AG_EPI_BIAS_RESID && m < p.M) {
-            const int seq = m / p.T, t = m - seq * p.T;
-            rrow = (long)(seq / p.share) * p.T + t;
-        }
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-            const int n = nw0 + sn * 16 + fq * 4;
-            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
-            const bool inb = (m < p.M) && (n < p.N);
-            if (inb) {
-                if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (EPI == AG_EPI_BIAS_RESID) {
-                    const float4 rv = load4_as_f32(p.R + rrow * p.ldr + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-            }
-            if (EPI == AG_EPI_BIAS_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fast_gelu(v[e]);
-            }
-            if (EPI == AG_EPI_BIAS_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-            }
-            if (OUT_F32) {
-                if (inb) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                *reinterpret_cast<uint2*>(stg + ((sm & 1) * 16 + frow) * SROW + sn * 32 + fq * 8) =
-                    make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            }
-        }
-        if (!OUT_F32 && (sm & 1)) {
-            // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rr = i * 8 + (lane >> 3), ch = lane & 7;
-                const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
-                const int mm = m0 + wm * 128 + (sm - 1) * 16 + rr;
-                if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
-                    uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
-                    if (p.nt_store) {
-                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dstp));
-                    } else *dstp = val;
-                }
-            }
-        }
-    }
+    if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
+    wave_epilogue<EPI, VAR == 1, VAR == 2>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane);
+    AG_MARK(124)
+    if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    AG_MARK(125)
+#undef AG_MARK
 }
 
-template <int EPI>
-int launch_ring(const BigArgs& a, hipStream_t s) {
+template <int EPI, int VAR>
+int launch_ring_var(const BigArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_ring): %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+template <int EPI>
+int launch_ring(const BigArgs& a, hipStream_t s) {
+    constexpr bool CAN_FOLD = (EPI == AG_EPI_BIAS || EPI == AG_EPI_BIAS_GELU);
+    constexpr bool CAN_STATS = (EPI == AG_EPI_BIAS_RESID);
+    if (a.ln_stats) {
+        if constexpr (CAN_FOLD) return launch_ring_var<EPI, 1>(a, s);
+        else return ag_fail(AG_ERR_INVALID, "ag_gemm: LayerNorm folding is built for the bias and bias+gelu epilogues only");
+    }
+    if (a.stats_out) {
+        if constexpr (CAN_STATS) return launch_ring_var<EPI, 2>(a, s);
+        else return ag_fail(AG_ERR_INVALID, "ag_gemm: row statistics are built for the bias+residual epilogue only");
+    }
     if (a.dbg && EPI == AG_EPI_BIAS) {  // diagnostic (stamped) build, tools/gemm_stamps.py
         static bool dset = false;
-        if (!dset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES); dset = true; }
-        hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, true>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        if (!dset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES); dset = true; }
+        const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+        hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 0, true>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
         AG_LAUNCH_CHECK();
         return AG_OK;
     }
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+    return launch_ring_var<EPI, 0>(a, s);
+}
+
+
+// ---- "duo" kernel: 256(M) x 128(N) tile, 4 waves, TWO workgroups per CU ---------------------------------
+// The ring kernel above owns a CU: while its 8 waves run the epilogue (and the next workgroup its prologue)
+// the matrix cores idle, and every CU reaches its store burst at the same moment.  With K = 768 (24
+// half-steps) that is ~30 % of the kernel.  Here two independent 4-wave workgroups share each CU (one wave
+// of each per SIMD, 190 VGPRs): they drift out of phase, so one workgroup's epilogue / prologue / read phase
+// runs under the other's MFMA phase without any hand-built stagger.  Price: (256+128)*64 B of L2->LDS
+// traffic per 2 MFLOP*... i.e. 1.5x the ring kernel's per flop.
+// Ring: 3 slots x (A 16 KiB + W 8 KiB) = 72 KiB per workgroup; half-step j+2 is requested right after the
+// barrier that retires slot j-1; one barrier per half-step.
+constexpr int DUO_BN = 128;
+constexpr int DUO_A_BYTES = BT * HROWB;        // 16 KiB
+constexpr int DUO_W_BYTES = DUO_BN * HROWB;    // 8 KiB
+constexpr int DUO_SLOT = DUO_A_BYTES + DUO_W_BYTES;
+constexpr int DUO_NSLOT = 3;
+constexpr int DUO_NT = 256;
+
+template <int EPI>
+__global__ __launch_bounds__(DUO_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_duo_kernel(BigArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + DUO_BN - 1) / DUO_BN, tiles_m = (p.M + BT - 1) / BT;
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * DUO_BN;
+
+    f32x4_t acc[4][8];  // [n sub-tile][m sub-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // this wave's LDS-DMA pieces of a half-step: A pieces 4w..4w+3, W pieces 2w, 2w+1 (6 loads)
+    const int r_in = lane >> 2, chunk = (lane & 3) ^ swz4((lane >> 4) & 3);
+    const char* srcA[4];
+    const char* srcW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int grow = m0 + (wave * 4 + i) * 16 + r_in;
+        grow = grow < p.M ? grow : p.M - 1;
+        srcA[i] = p.A + (long)grow * p.lda_b + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int grow = n0 + (wave * 2 + i) * 16 + r_in;
+        grow = grow < p.N ? grow : p.N - 1;
+        srcW[i] = p.W + (long)grow * p.ldw_b + chunk * 16;
+    }
+    auto refill = [&](int jn, int slot) {
+        char* dA = smem + slot * DUO_SLOT;
+        char* dW = dA + DUO_A_BYTES;
+        const long kb = (long)jn * HROWB;
+        glds16b(srcA[0] + kb, dA + (wave * 4 + 0) * 1024);
+        glds16b(srcW[0] + kb, dW + (wave * 2 + 0) * 1024);
+        glds16b(srcA[1] + kb, dA + (wave * 4 + 1) * 1024);
+        glds16b(srcA[2] + kb, dA + (wave * 4 + 2) * 1024);
+        glds16b(srcW[1] + kb, dW + (wave * 2 + 1) * 1024);
+        glds16b(srcA[3] + kb, dA + (wave * 4 + 3) * 1024);
+    };
+
+    const int nh = p.K / 32;
+    refill(0, 0);
+    if (nh > 1) refill(1, 1);
+    int slot = 0;
+    for (int j = 0; j < nh; ++j) {
+        // my pieces of half-step j have landed (half-step j+1, 6 loads, may stay in flight)
+        if (j + 1 < nh) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");   // slot j complete for everyone; slot j-1 no longer read
+        const char* sA = smem + slot * DUO_SLOT;
+        const char* sW = sA + DUO_A_BYTES;
+        uint4 fw[4], fx[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
+        if (j + 2 < nh) refill(j + 2, slot == 0 ? 2 : slot - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn)
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm)
+                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
+                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
+    wave_epilogue<EPI, false, false>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane);
+}
+
+template <int EPI>
+int launch_duo(const BigArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_duo_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DUO_NSLOT * DUO_SLOT);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_duo): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, DUO_BN);
+    hipLaunchKernelGGL((gemm_duo_kernel<EPI>), dim3(tiles), dim3(DUO_NT), DUO_NSLOT * DUO_SLOT, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
@@ -279,13 +527,14 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                 const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
-                hipStream_t s) {
+                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s) {
     BigArgs a;
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
     a.W = (const char*)d_W; a.ldw_b = (long)K * 2;
     a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = (const bf16_t*)d_R; a.ldr = ldr;
     a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
+    a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K; a.stats_out = d_stats_out;
     a.dbg = nullptr;
     if (getenv("AG_GEMM_DBG")) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
         static unsigned long long* dbuf = nullptr;
@@ -294,8 +543,21 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
         FILE* f = fopen(getenv("AG_GEMM_DBG"), "w");
         if (f) { fprintf(f, "%p\n", (void*)dbuf); fclose(f); }
     }
+    static const int desync_env = getenv("AG_GEMM_DESYNC") ? atoi(getenv("AG_GEMM_DESYNC")) : 0;
+    a.desync = desync_env;
     static const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
     a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
+    static const int duo_env = getenv("AG_GEMM_DUO") ? atoi(getenv("AG_GEMM_DUO")) : 0;
+    if (duo_env) {
+        switch (epilogue) {
+            case AG_EPI_BIAS: return launch_duo<AG_EPI_BIAS>(a, s);
+            case AG_EPI_BIAS_GELU: return launch_duo<AG_EPI_BIAS_GELU>(a, s);
+            case AG_EPI_BIAS_RESID: return launch_duo<AG_EPI_BIAS_RESID>(a, s);
+            case AG_EPI_BIAS_F32: return launch_duo<AG_EPI_BIAS_F32>(a, s);
+            case AG_EPI_BIAS_TANH: return launch_duo<AG_EPI_BIAS_TANH>(a, s);
+            default: return ag_fail(AG_ERR_INVALID, "ag_gemm_big: unknown epilogue %d", epilogue);
+        }
+    }
     switch (epilogue) {
         case AG_EPI_BIAS: return launch_ring<AG_EPI_BIAS>(a, s);
         case AG_EPI_BIAS_GELU: return launch_ring<AG_EPI_BIAS_GELU>(a, s);

@@ -6,6 +6,7 @@ Nothing here computes: tensors are allocated by torch, every op is a libautognot
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -15,6 +16,7 @@ from . import _lib as L
 from . import ops
 
 _PRECISION = {"dtype": L.AG_BF16}
+FOLD_LAYERNORM = os.environ.get("AG_LN_FOLD", "1") != "0"  # bf16 ViT: fold LayerNorm into the consuming GEMM epilogue
 
 
 def set_precision(name: str) -> None:
@@ -72,6 +74,30 @@ class PackedLinear:
         return self.w, self.b
 
 
+class PackedFoldedLinear:
+    """Linear(LayerNorm(x)) folded for the GEMM epilogue (ViT pre-LN, bf16): W' = gamma ⊙ W (storage dtype),
+    bias' = b + W·beta, colsum[n] = sum_k W'[n,k] (of the rounded W').  Pack-time preprocessing, rebuilt when
+    any of the parameters changes."""
+
+    def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: nn.Module):
+        self.weights, self.biases, self.ln = list(weights), list(biases), ln
+        self.key = None
+        self.w = self.b = self.s = None
+
+    def get(self, dtype: int) -> Tuple[Tensor, Tensor, Tensor]:
+        key = (dtype, _versions(self.weights + self.biases + [self.ln.weight, self.ln.bias]))
+        if key != self.key:
+            with torch.no_grad():
+                w = torch.cat([x.detach() for x in self.weights], dim=0).float()
+                b = torch.cat([x.detach().float() for x in self.biases], dim=0)
+                g, beta = self.ln.weight.detach().float(), self.ln.bias.detach().float()
+                self.w = ops.cast((w * g[None, :]).contiguous(), dtype)
+                self.b = (b + w @ beta).contiguous()
+                self.s = self.w.float().sum(dim=1).contiguous()
+            self.key = key
+        return self.w, self.b, self.s
+
+
 def _f32(p: Optional[Tensor]) -> Optional[Tensor]:
     return None if p is None else p.detach().float().contiguous()
 
@@ -92,6 +118,13 @@ class PackedEncoder:
                 fc1=PackedLinear([ly.intermediate.dense.weight], [ly.intermediate.dense.bias]),
                 fc2=PackedLinear([ly.output.dense.weight], [ly.output.dense.bias]),
             ))
+            if kind == L.AG_MASK_VIT_MUL:  # LN-folded variants of the two projections that consume a LayerNorm
+                if not isinstance(ly.layernorm_before, nn.Identity):
+                    self.lin[-1]["qkv_ln"] = PackedFoldedLinear([att.self.query.weight, att.self.key.weight, att.self.value.weight],
+                                                                [att.self.query.bias, att.self.key.bias, att.self.value.bias],
+                                                                ly.layernorm_before)
+                self.lin[-1]["fc1_ln"] = PackedFoldedLinear([ly.intermediate.dense.weight], [ly.intermediate.dense.bias],
+                                                            ly.layernorm_after)
         self._keep: List = []
 
     def _ln(self, ly: nn.Module, which: int) -> Tuple[Optional[Tensor], Optional[Tensor]]:
@@ -113,6 +146,12 @@ class PackedEncoder:
                 keep += [w, b]
                 setattr(lw, cw, w.data_ptr())
                 setattr(lw, cb, b.data_ptr())
+            if dtype == L.AG_BF16 and FOLD_LAYERNORM:
+                for name, cw, cb, cs in (("qkv_ln", "w_qkv_ln", "b_qkv_ln", "s_qkv_ln"), ("fc1_ln", "w_fc1_ln", "b_fc1_ln", "s_fc1_ln")):
+                    if name in self.lin[i]:
+                        w, b, s_ = self.lin[i][name].get(dtype)
+                        keep += [w, b, s_]
+                        setattr(lw, cw, w.data_ptr()); setattr(lw, cb, b.data_ptr()); setattr(lw, cs, s_.data_ptr())
             g1, b1 = self._ln(ly, 1)
             g2, b2 = self._ln(ly, 2)
             keep += [g1, b1, g2, b2]

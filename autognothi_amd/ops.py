@@ -179,7 +179,9 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, ro
 
 def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int, m: Optional[int] = None,
          lda: Optional[int] = None, resid: Optional[Tensor] = None, ldr: Optional[int] = None,
-         rows_per_seq: int = 1, resid_share: int = 1, out: Optional[Tensor] = None, ldc: Optional[int] = None) -> Tensor:
+         rows_per_seq: int = 1, resid_share: int = 1, out: Optional[Tensor] = None, ldc: Optional[int] = None,
+         ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None, ln_eps: float = 0.0,
+         stats_out: Optional[Tensor] = None) -> Tensor:
     """epilogue(A[M,K] @ W[N,K]^T + bias).  a, w, resid in the storage dtype; bias fp32.  Output: fp32 for
     AG_EPI_BIAS_F32, else the storage dtype."""
     L.require_gpu(a, w, bias, resid, out)
@@ -196,8 +198,20 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     ldr = (n if ldr is None else ldr) if resid is not None else 0
     with torch.cuda.device(a.device):
         L.check(L.lib().ag_gemm(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr,
-                                rows_per_seq, resid_share, m, n, k, epilogue, dtype, L.stream()))
+                                rows_per_seq, resid_share, m, n, k, epilogue, dtype, L.ptr(ln_stats), L.ptr(ln_colsum),
+                                float(ln_eps), L.ptr(stats_out), L.stream()))
     return out
+
+
+def row_stats(x: Tensor) -> Tensor:
+    """(sum, sum of squares) per row of a bf16 [rows, H] tensor -> fp32 [rows, 2]."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    rows, h = x.shape
+    st = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().ag_row_stats_bf16(L.ptr(x), h, rows, h, L.ptr(st), L.stream()))
+    return st
 
 
 def masked_attention(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, heads: int, share: int,

@@ -102,10 +102,20 @@ int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, con
  * (A row stride lda, W dense [N,K]); bias fp32.  For AG_EPI_BIAS_RESID, R is in the storage dtype with
  * row stride ldr and row index ((m / T) / resid_share) * T + m % T  (T = rows_per_seq; resid_share > 1 lets
  * the K masked copies of one input share the layer-0 residual).  K % 64 == 0 (bf16) / K % 32 == 0
- * (fp32) required; N, M arbitrary. */
+ * (fp32) required; N, M arbitrary.
+ * LayerNorm folding (optional; only where ag_gemm_supports_ln_fold() says so — the large-M bf16 kernel):
+ *   d_ln_stats [M,2] = (sum, sum of squares) over the K features of each A row, d_ln_colsum [N] =
+ *   sum_k W[n,k]: the result becomes rstd[m]*(A·Wᵀ - mean[m]*colsum[n]) + bias[n], i.e. Linear(LayerNorm(A))
+ *   when W is pre-scaled by gamma and bias carries beta·Wᵀ (reference models/vanilla_vit.py:369,373 feed
+ *   LayerNorm outputs straight into Linear layers).  d_stats_out [M,2] (pre-zeroed) receives the same
+ *   statistics of the rows this call writes (float atomics), for the next folded consumer. */
 int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
             const void* d_R, int64_t ldr, int rows_per_seq, int resid_share,
-            int M, int N, int K, int epilogue, int dtype, void* stream);
+            int M, int N, int K, int epilogue, int dtype,
+            const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, void* stream);
+int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype);
+/* (sum, sum of squares) of each row of a bf16 [rows,H] tensor -> d_stats [rows,2]. */
+int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream);
 
 /* Fused masked multi-head attention (reference models/vanilla_vit.py:436-465,
  * models/vanilla_bert.py:503-537): per row r and head h, softmax(mask_op(Q·Kᵀ/sqrt(d)))·V.
@@ -169,6 +179,10 @@ typedef struct ag_layer_weights {
     const float* ln1_b;
     const float* ln2_g;  /* ViT layernorm_after  / BERT output.LayerNorm                     */
     const float* ln2_b;
+    /* optional (ViT, bf16): LayerNorm-folded projections — weights pre-scaled by gamma, bias' = b + W·beta,
+     * colsum[n] = sum_k W'[n,k].  NULL = run the LayerNorm kernel.                                         */
+    const void* w_qkv_ln; const float* b_qkv_ln; const float* s_qkv_ln;
+    const void* w_fc1_ln; const float* b_fc1_ln; const float* s_fc1_ln;
 } ag_layer_weights;
 
 typedef struct ag_encoder_desc {

@@ -180,3 +180,39 @@ def test_cpu_tensors_rejected():
     from autognothi_amd import _lib as L, ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(torch.zeros(4, 64), torch.zeros(4, 64), None, L.AG_EPI_BIAS_F32, F32)
+
+
+def test_gemm_layernorm_fold(cuda_device):
+    """Linear(LayerNorm(x)) through the folded epilogue (row statistics + gamma-scaled weights) vs the oracle, and
+    the producer side (statistics accumulated by the epilogue that writes the rows)."""
+    from autognothi_amd import _lib as L, ops
+    g = np.random.default_rng(21)
+    m, h, n = 2048, 768, 2304
+    x = _bf16_round((g.standard_normal((m, h)) * 1.5 + 0.3).astype(np.float32))
+    w = (g.standard_normal((n, h)) / np.sqrt(h)).astype(np.float32)
+    b = g.standard_normal(n).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(h)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(h)).astype(np.float32)
+    eps = 1e-12
+    ref = otr.layer_norm(x, {"ln.weight": gamma, "ln.bias": beta}, "ln", eps).astype(np.float64) @ w.astype(np.float64).T + b
+    dev = cuda_device
+    X = torch.from_numpy(x).to(dev).to(torch.bfloat16)
+    wf = torch.from_numpy(w * gamma[None, :]).to(dev).to(torch.bfloat16)
+    bias_f = torch.from_numpy((b + w @ beta).astype(np.float32)).to(dev)
+    colsum = wf.float().sum(dim=1).contiguous()
+    stats = ops.row_stats(X)
+    np.testing.assert_allclose(stats.cpu().numpy()[:, 0], x.sum(1), rtol=1e-5, atol=1e-3)
+    out = ops.gemm(X, wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=stats, ln_colsum=colsum, ln_eps=eps).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-2, atol=3e-2)
+    # producer: a residual GEMM that writes rows and accumulates their (sum, sumsq)
+    a = _bf16_round(g.standard_normal((m, h)).astype(np.float32))
+    w2 = _bf16_round((g.standard_normal((h, h)) / np.sqrt(h)).astype(np.float32))
+    st_out = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    hx = ops.gemm(torch.from_numpy(a).to(dev).to(torch.bfloat16), torch.from_numpy(w2).to(dev).to(torch.bfloat16), None,
+                  L.AG_EPI_BIAS_RESID, BF16, resid=X, stats_out=st_out)
+    hxf = hx.float().cpu().numpy()
+    np.testing.assert_allclose(st_out.cpu().numpy()[:, 0], hxf.sum(1), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(st_out.cpu().numpy()[:, 1], (hxf.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    # the folded path is refused where it is not implemented (small / fp32 GEMMs) instead of silently ignored
+    with pytest.raises(RuntimeError, match="folding"):
+        ops.gemm(X[:64], wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=stats[:64], ln_colsum=colsum)

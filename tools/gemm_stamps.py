@@ -32,3 +32,10 @@ for blk in (0, 1):
             seg[5] += s[j + 1, 0] - s[j, 5]
         cnt = hi - lo
         print(f"blk{blk} wave{wave}: " + " ".join(f"{n} {v/cnt:5.0f}" for n, v in zip(names, seg)) + f" | total/iter {(s[hi,0]-s[lo,0])/cnt:6.0f}")
+
+for blk in (0, 1):
+    for wave in (0, 4):
+        s = d[blk, wave]
+        t0 = s[120, 0]
+        print(f"blk{blk} wave{wave}: entry 0 | prologue issued {s[121,0]-t0} | slot0 landed {s[122,0]-t0} | loop end {s[123,0]-t0} "
+              f"| epilogue issued {s[124,0]-t0} | stores acked {s[125,0]-t0}")
