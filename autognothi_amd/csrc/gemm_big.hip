@@ -39,7 +39,6 @@ struct BigArgs {
     const float* ln_stats; const float* ln_s; float ln_eps; float ln_inv_h;
     float* stats_out;
     unsigned long long* dbg;  // diagnostic build only
-    int desync;    // first-round start offset unit in shader cycles (0 = off)
     int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
 };
 
@@ -258,14 +257,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
         p.dbg[(((blockIdx.x ? 1 : 0) * 8 + wave) * 128 + (idx_)) * 8] = t_;                                    \
     }
-    // Every CU would otherwise reach its epilogue at the same moment: 256 x 128 KiB of stores in one burst
-    // (HBM-write bound for ~20 % of the kernel while the matrix cores idle), then silence.  The first
-    // workgroup of each CU starts ((b>>3)&7) delay units late; CUs run tiles back to back, so the offsets
-    // persist and the store traffic of the 8 phases interleaves with the other CUs' main loops.
-    if (p.desync && b < 256) {
-        const unsigned long long t_end = __builtin_readcyclecounter() + (unsigned long long)(((b >> 3) & 7) * p.desync);
-        while (__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
-    }
     AG_MARK(120)
     const int nh = p.K / 32;  // half-steps
     // prologue: half-steps 0..3 into slots 0..3 (4 glds per wave per half-step)
@@ -404,119 +395,6 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
 }
 
 
-// ---- "duo" kernel: 256(M) x 128(N) tile, 4 waves, TWO workgroups per CU ---------------------------------
-// The ring kernel above owns a CU: while its 8 waves run the epilogue (and the next workgroup its prologue)
-// the matrix cores idle, and every CU reaches its store burst at the same moment.  With K = 768 (24
-// half-steps) that is ~30 % of the kernel.  Here two independent 4-wave workgroups share each CU (one wave
-// of each per SIMD, 190 VGPRs): they drift out of phase, so one workgroup's epilogue / prologue / read phase
-// runs under the other's MFMA phase without any hand-built stagger.  Price: (256+128)*64 B of L2->LDS
-// traffic per 2 MFLOP*... i.e. 1.5x the ring kernel's per flop.
-// Ring: 3 slots x (A 16 KiB + W 8 KiB) = 72 KiB per workgroup; half-step j+2 is requested right after the
-// barrier that retires slot j-1; one barrier per half-step.
-constexpr int DUO_BN = 128;
-constexpr int DUO_A_BYTES = BT * HROWB;        // 16 KiB
-constexpr int DUO_W_BYTES = DUO_BN * HROWB;    // 8 KiB
-constexpr int DUO_SLOT = DUO_A_BYTES + DUO_W_BYTES;
-constexpr int DUO_NSLOT = 3;
-constexpr int DUO_NT = 256;
-
-template <int EPI>
-__global__ __launch_bounds__(DUO_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_duo_kernel(BigArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles_n = (p.N + DUO_BN - 1) / DUO_BN, tiles_m = (p.M + BT - 1) / BT;
-    const int nwg = tiles_m * tiles_n;
-    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * DUO_BN;
-
-    f32x4_t acc[4][8];  // [n sub-tile][m sub-tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // this wave's LDS-DMA pieces of a half-step: A pieces 4w..4w+3, W pieces 2w, 2w+1 (6 loads)
-    const int r_in = lane >> 2, chunk = (lane & 3) ^ swz4((lane >> 4) & 3);
-    const char* srcA[4];
-    const char* srcW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int grow = m0 + (wave * 4 + i) * 16 + r_in;
-        grow = grow < p.M ? grow : p.M - 1;
-        srcA[i] = p.A + (long)grow * p.lda_b + chunk * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int grow = n0 + (wave * 2 + i) * 16 + r_in;
-        grow = grow < p.N ? grow : p.N - 1;
-        srcW[i] = p.W + (long)grow * p.ldw_b + chunk * 16;
-    }
-    auto refill = [&](int jn, int slot) {
-        char* dA = smem + slot * DUO_SLOT;
-        char* dW = dA + DUO_A_BYTES;
-        const long kb = (long)jn * HROWB;
-        glds16b(srcA[0] + kb, dA + (wave * 4 + 0) * 1024);
-        glds16b(srcW[0] + kb, dW + (wave * 2 + 0) * 1024);
-        glds16b(srcA[1] + kb, dA + (wave * 4 + 1) * 1024);
-        glds16b(srcA[2] + kb, dA + (wave * 4 + 2) * 1024);
-        glds16b(srcW[1] + kb, dW + (wave * 2 + 1) * 1024);
-        glds16b(srcA[3] + kb, dA + (wave * 4 + 3) * 1024);
-    };
-
-    const int nh = p.K / 32;
-    refill(0, 0);
-    if (nh > 1) refill(1, 1);
-    int slot = 0;
-    for (int j = 0; j < nh; ++j) {
-        // my pieces of half-step j have landed (half-step j+1, 6 loads, may stay in flight)
-        if (j + 1 < nh) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");   // slot j complete for everyone; slot j-1 no longer read
-        const char* sA = smem + slot * DUO_SLOT;
-        const char* sW = sA + DUO_A_BYTES;
-        uint4 fw[4], fx[8];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-        if (j + 2 < nh) refill(j + 2, slot == 0 ? 2 : slot - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn)
-#pragma unroll
-            for (int sm = 0; sm < 8; ++sm)
-                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
-                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
-    wave_epilogue<EPI, false, false>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane);
-}
-
-template <int EPI>
-int launch_duo(const BigArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_duo_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DUO_NSLOT * DUO_SLOT);
-        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_duo): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, DUO_BN);
-    hipLaunchKernelGGL((gemm_duo_kernel<EPI>), dim3(tiles), dim3(DUO_NT), DUO_NSLOT * DUO_SLOT, s, a);
-    AG_LAUNCH_CHECK();
-    return AG_OK;
-}
-
-
 }  // namespace
 
 // Eligibility: bf16, vectorisable epilogue, K a multiple of 32 with at least 4 half-steps.
@@ -543,21 +421,8 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
         FILE* f = fopen(getenv("AG_GEMM_DBG"), "w");
         if (f) { fprintf(f, "%p\n", (void*)dbuf); fclose(f); }
     }
-    static const int desync_env = getenv("AG_GEMM_DESYNC") ? atoi(getenv("AG_GEMM_DESYNC")) : 0;
-    a.desync = desync_env;
     static const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
     a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
-    static const int duo_env = getenv("AG_GEMM_DUO") ? atoi(getenv("AG_GEMM_DUO")) : 0;
-    if (duo_env) {
-        switch (epilogue) {
-            case AG_EPI_BIAS: return launch_duo<AG_EPI_BIAS>(a, s);
-            case AG_EPI_BIAS_GELU: return launch_duo<AG_EPI_BIAS_GELU>(a, s);
-            case AG_EPI_BIAS_RESID: return launch_duo<AG_EPI_BIAS_RESID>(a, s);
-            case AG_EPI_BIAS_F32: return launch_duo<AG_EPI_BIAS_F32>(a, s);
-            case AG_EPI_BIAS_TANH: return launch_duo<AG_EPI_BIAS_TANH>(a, s);
-            default: return ag_fail(AG_ERR_INVALID, "ag_gemm_big: unknown epilogue %d", epilogue);
-        }
-    }
     switch (epilogue) {
         case AG_EPI_BIAS: return launch_ring<AG_EPI_BIAS>(a, s);
         case AG_EPI_BIAS_GELU: return launch_ring<AG_EPI_BIAS_GELU>(a, s);

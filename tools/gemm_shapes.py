@@ -4,10 +4,11 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autognothi_amd import _lib as L, ops
 dev = torch.device("cuda:0"); M = int(os.environ.get("GB_M", 100864))
-def mk(n, k): return ((torch.rand((n, k), device=dev) * 2 - 1) / k ** 0.5).to(torch.bfloat16)
-x768 = (torch.rand((M, 768), device=dev) * 2 - 1).to(torch.bfloat16)
-x3072 = (torch.rand((M, 3072), device=dev) * 2 - 1).to(torch.bfloat16)
-r = (torch.rand((M, 768), device=dev) * 2 - 1).to(torch.bfloat16)
+ZERO = os.environ.get("GB_ZERO") == "1"
+def mk(n, k): return ((torch.rand((n, k), device=dev) * 2 - 1) / k ** 0.5).to(torch.bfloat16) * (0 if ZERO else 1)
+x768 = (torch.rand((M, 768), device=dev) * 2 - 1).to(torch.bfloat16) * (0 if ZERO else 1)
+x3072 = (torch.rand((M, 3072), device=dev) * 2 - 1).to(torch.bfloat16) * (0 if ZERO else 1)
+r = (torch.rand((M, 768), device=dev) * 2 - 1).to(torch.bfloat16) * (0 if ZERO else 1)
 shapes = [("qkv", x768, mk(2304, 768), L.AG_EPI_BIAS, None), ("proj", x768, mk(768, 768), L.AG_EPI_BIAS_RESID, r),
           ("fc1", x768, mk(3072, 768), L.AG_EPI_BIAS_GELU, None), ("fc2", x3072, mk(768, 3072), L.AG_EPI_BIAS_RESID, r)]
 outs = {n: torch.empty((M, w.shape[0]), dtype=torch.bfloat16, device=dev) for n, _, w, _, _ in shapes}
