@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--attr-batch", type=int, default=128, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +200,40 @@ def main():
     assert bool(torch.isfinite(out).all())
 
     stats = {c: collect(c) for c in EPI_NAMES}
+
+    # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +
+    # surrogate + explainer forwards on all-ones masks -> phi [B, C, P]); untimed by the contract's K steps.
+    attrs_per_s = None
+    if args.attr_batch > 0:
+        final = recipe.t_final(cfg)
+        synth.load_synth_weights(final, seed=1)
+        final = final.to(dev).eval()
+        if kind == "vanilla_vit":
+            fx_np = synth.synth_images(args.attr_batch, params["img_px_size"], params["img_channels"], seed=100 + rank)
+        else:
+            fx_np = synth.synth_token_ids(args.attr_batch, params["max_position_embeddings"], params["vocab_size"], seed=100 + rank)
+        fx = torch.from_numpy(fx_np).to(dev)
+        with torch.no_grad():
+            for _ in range(2):
+                _, phi = recipe.fw_final(final, fx)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            ta = time.perf_counter()
+            n_attr = 4
+            for _ in range(n_attr):
+                _, phi = recipe.fw_final(final, fx)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            el = time.perf_counter() - ta
+        assert phi.shape == (args.attr_batch, cfg.num_labels, P) and bool(torch.isfinite(phi).all())
+        if dist is not None:
+            tm = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        attrs_per_s = args.attr_batch * world * n_attr / el
+        del final, fx, phi
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
@@ -229,6 +264,13 @@ def main():
                            "exec_frac_of_peak": round(value / world * f_exec / 1e12 / peak, 4)},
             "kernels": per_kernel,
         }
+        if args.precision == "bf16":
+            # what the matrix cores of this board sustain on random operands with nothing else running (power cap):
+            # context for `frac`, which stays priced against the 2.4 GHz datasheet peak
+            tf, ghz = C.c_double(), C.c_double()
+            L.check(L.lib().ag_probe_mfma(100000, 0, C.byref(tf), C.byref(ghz), None))
+            roofline["power_capped_mfma_probe"] = {"tflops": round(tf.value, 1), "shader_ghz": round(ghz.value, 3),
+                                                   "frac_of_probe": round(fl / max(ms, 1e-9) / 1e9 / max(tf.value, 1e-9), 4)}
         line = {
             "metric": "masked-forwards/sec (K=%d)" % K, "value": round(value, 2), "unit": "masked-forwards/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -240,6 +282,10 @@ def main():
                        "sharding": "rows by input, no data-path collective", "weights": "seeded random init"},
             "roofline": roofline,
         }
+        if attrs_per_s is not None:
+            line["secondary"] = {"metric": "Shapley-attrs/sec/image", "value": round(attrs_per_s, 1), "unit": "images/s",
+                                 "path": "fw_final (classifier + surrogate + explainer forward -> phi[B,C,P])",
+                                 "images_per_gpu_per_pass": args.attr_batch, "passes": 4}
         if world == 1 and not args.no_cpu_baseline:
             sample_b = 1
             masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()

@@ -253,6 +253,13 @@ int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, con
 int ag_profile_enable(int on);
 int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 
+/* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
+ * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per
+ * wave — the power-capped MFMA ceiling — and the effective shader clock during it (s_memtime ticks against
+ * the constant 100 MHz s_memrealtime).  zero_operands != 0 runs the same loop on all-zero operands (no
+ * data-dependent switching power).  Synchronous.  No reference counterpart. */
+int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
