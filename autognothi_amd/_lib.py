@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libautognothi_hip.so")
 AG_OK = 0
 AG_F32, AG_BF16 = 0, 1
 AG_MASK_VIT_MUL, AG_MASK_BERT_ADD = 0, 1
-AG_EPI_BIAS, AG_EPI_BIAS_GELU, AG_EPI_BIAS_RESID, AG_EPI_BIAS_F32, AG_EPI_BIAS_TANH = 0, 1, 2, 3, 4
+AG_EPI_BIAS, AG_EPI_BIAS_GELU, AG_EPI_BIAS_RESID, AG_EPI_BIAS_F32, AG_EPI_BIAS_TANH, AG_EPI_BIAS_GELU_ADD = 0, 1, 2, 3, 4, 5
 AG_MT_STATE_BYTES = 2560
 
 vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t

@@ -15,13 +15,14 @@
 //   * the S^T accumulator tile, converted to bf16, is directly the B operand of the PV product
 //     O^T += V^T·P^T (no LDS round trip); V^T fragments come from the row-major V image through
 //     ds_read_b64_tr_b16.
-// fp32 path (AG_F32 parity mode): plain VALU kernel, one query per thread, K/V tiles broadcast from LDS.
+// fp32 path (AG_F32 parity mode) and every head dim other than 64: plain VALU kernel, one query per thread,
+// K/V tiles broadcast from LDS (attn_valu_kernel<T, D>).
 #include "common.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int HD = 64;        // head dim (all shipped configs: 192/3, 768/12, 1024/16)
+constexpr int HD = 64;        // head dim of the MFMA kernel (backbones: 192/3, 768/12, 1024/16)
 constexpr int ROWB = 128;     // bytes per K/V row in bf16
 constexpr float NEG_BIG = -3.0e38f;
 constexpr uint32_t NEG_BIG_BITS = 0xFF61B1E6u;  // bit pattern of -3.0e38f
@@ -219,50 +220,54 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     }
 }
 
-// ---- fp32 parity-mode kernel: one query per thread, 64-key K/V tiles broadcast from LDS ----------
+// ---- VALU kernel: one query per thread, 64-key K/V tiles (fp32) broadcast from LDS ----------------------
+// T = float, D = 64: AG_F32 parity mode and the training forward (optional dropout).
+// Any other head dim (the 8-wide heads of the LTT side network, reference models/ltt_vit.py:383-394: hidden 96
+// over 12 heads) in either storage dtype: the contraction is too short for a matrix-core tile to pay.
 constexpr int FKT = 64;
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) float sK[FKT * HD];
-    __shared__ __attribute__((aligned(16))) float sV[FKT * HD];
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float sK[FKT * D];
+    __shared__ __attribute__((aligned(16))) float sV[FKT * D];
     const int tid = threadIdx.x;
     const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
     const int src = row / p.share;
-    const long ts = (long)3 * p.H;  // floats per token
-    const float* base = reinterpret_cast<const float*>(p.qkv) + (long)src * p.T * ts + (long)head * HD;
+    const long ts = (long)3 * p.H;  // elements per token
+    const T* base = reinterpret_cast<const T*>(p.qkv) + (long)src * p.T * ts + (long)head * D;
     const uint32_t* mrow = p.mask + (long)row * p.Tw;
-    const float inv_sqrt_d = 1.0f / sqrtf((float)HD);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)D);
 
     for (int q0 = 0; q0 < p.nq; q0 += blockDim.x) {
         const int q = q0 + tid;
         const bool qvalid = q < p.nq;
-        float qv[HD], o[HD];
-        const float* qp = base + (long)(qvalid ? q : 0) * ts;
+        float qv[D], o[D];
+        const T* qp = base + (long)(qvalid ? q : 0) * ts;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(qp + d);
+        for (int d = 0; d < D; d += 4) {
+            const float4 t = load4_as_f32(qp + d);
             qv[d] = t.x; qv[d + 1] = t.y; qv[d + 2] = t.z; qv[d + 3] = t.w;
             o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
         }
         float m_run = NEG_BIG, l_run = 0.f;
         for (int k0 = 0; k0 < p.T; k0 += FKT) {
             __syncthreads();
-            for (int c = tid; c < FKT * (HD / 4); c += blockDim.x) {
-                const int r = c / (HD / 4), ch = c % (HD / 4);
+            for (int c = tid; c < FKT * (D / 4); c += blockDim.x) {
+                const int r = c / (D / 4), ch = c % (D / 4);
                 float4 kv = make_float4(0, 0, 0, 0), vv = kv;
                 if (k0 + r < p.T) {
-                    kv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * ts + p.H + ch * 4);
-                    vv = *reinterpret_cast<const float4*>(base + (long)(k0 + r) * ts + 2 * p.H + ch * 4);
+                    kv = load4_as_f32(base + (long)(k0 + r) * ts + p.H + ch * 4);
+                    vv = load4_as_f32(base + (long)(k0 + r) * ts + 2 * p.H + ch * 4);
                 }
-                *reinterpret_cast<float4*>(sK + r * HD + ch * 4) = kv;
-                *reinterpret_cast<float4*>(sV + r * HD + ch * 4) = vv;
+                *reinterpret_cast<float4*>(sK + r * D + ch * 4) = kv;
+                *reinterpret_cast<float4*>(sV + r * D + ch * 4) = vv;
             }
             __syncthreads();
             const int kn = min(FKT, p.T - k0);
             for (int kk = 0; kk < kn; ++kk) {
                 float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; d += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(sK + kk * HD + d);
+                for (int d = 0; d < D; d += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(sK + kk * D + d);
                     s = fmaf(qv[d], t.x, s); s = fmaf(qv[d + 1], t.y, s); s = fmaf(qv[d + 2], t.z, s); s = fmaf(qv[d + 3], t.w, s);
                 }
                 s = s * inv_sqrt_d;
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
                 if (p.pdrop > 0.f)  // dropout on the normalised probabilities: dropped weights still count in l
                     pv = keep_elem(p.seed, ((uint64_t)blockIdx.x * p.T + q) * p.T + key, p.pdrop) ? pv / (1.0f - p.pdrop) : 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; d += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(sV + kk * HD + d);
+                for (int d = 0; d < D; d += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(sV + kk * D + d);
                     o[d] = fmaf(pv, t.x, o[d] * alpha); o[d + 1] = fmaf(pv, t.y, o[d + 1] * alpha);
                     o[d + 2] = fmaf(pv, t.z, o[d + 2] * alpha); o[d + 3] = fmaf(pv, t.w, o[d + 3] * alpha);
                 }
@@ -287,12 +292,30 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
         }
         if (qvalid) {
             const float inv = 1.0f / l_run;
-            float* out = reinterpret_cast<float*>(p.ctx) + ((long)row * p.T + q) * p.H + (long)head * HD;
+            T* out = reinterpret_cast<T*>(p.ctx) + ((long)row * p.T + q) * p.H + (long)head * D;
 #pragma unroll
-            for (int d = 0; d < HD; d += 4)
-                *reinterpret_cast<float4*>(out + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+            for (int d = 0; d < D; d += 4) {
+                if (sizeof(T) == 4)
+                    *reinterpret_cast<float4*>(out + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+                else
+                    *reinterpret_cast<uint2*>(out + d) = make_uint2(pack_bf16x2(o[d] * inv, o[d + 1] * inv), pack_bf16x2(o[d + 2] * inv, o[d + 3] * inv));
+            }
         }
     }
+}
+
+template <typename T>
+int launch_valu(const AttnArgs& a, int head_dim, hipStream_t s) {
+    const dim3 grid(a.R * a.heads), block(256);
+    switch (head_dim) {
+        case 8: hipLaunchKernelGGL((attn_valu_kernel<T, 8>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((attn_valu_kernel<T, 16>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((attn_valu_kernel<T, 32>), grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL((attn_valu_kernel<T, 64>), grid, block, 0, s, a); break;
+        default: return ag_fail(AG_ERR_INVALID, "masked attention: head_dim %d not built (8, 16, 32, 64)", head_dim);
+    }
+    AG_LAUNCH_CHECK();
+    return AG_OK;
 }
 
 }  // namespace
@@ -300,7 +323,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs p) {
 extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
                                    int heads, int qkv_share, int mask_mode, int n_query, int dtype, void* stream) {
     AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention: null pointer");
-    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H == heads * HD, "ag_masked_attention: head_dim must be %d (H=%d heads=%d)", HD, H, heads);
+    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H % heads == 0, "ag_masked_attention: H=%d is not a multiple of heads=%d", H, heads);
+    const int hd = H / heads;
     AG_REQUIRE(qkv_share >= 1 && R % qkv_share == 0, "ag_masked_attention: R=%d not a multiple of share=%d", R, qkv_share);
     AG_REQUIRE(mask_mode == AG_MASK_VIT_MUL || mask_mode == AG_MASK_BERT_ADD, "ag_masked_attention: bad mask mode %d", mask_mode);
     if (R == 0) return AG_OK;
@@ -314,7 +338,8 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     const double es = dtype == AG_BF16 ? 2.0 : 4.0;
     AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)a.nq * T * H,
                      ((double)(R / qkv_share) * T * 3 * H + (double)R * a.nq * H) * es, s);
-    if (dtype == AG_BF16) {
+    if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_masked_attention: bad dtype %d", dtype);
+    if (dtype == AG_BF16 && hd == HD) {
         const size_t lds = (size_t)2 * a.Tp * ROWB;
         AG_REQUIRE(lds <= 160 * 1024, "ag_masked_attention: T=%d too long for the single-pass LDS image", T);
         const int nqb = (a.nq + 31) / 32;
@@ -331,9 +356,9 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
         if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_VIT_MUL>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
         else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
     } else if (dtype == AG_F32) {
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(R * heads), dim3(256), 0, s, a);
+        return launch_valu<float>(a, hd, s);
     } else {
-        return ag_fail(AG_ERR_INVALID, "ag_masked_attention: bad dtype %d", dtype);
+        return launch_valu<bf16_t>(a, hd, s);   // narrow heads in bf16 storage
     }
     AG_LAUNCH_CHECK();
     return AG_OK;
@@ -342,13 +367,11 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
 extern "C" int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H,
                                          int heads, int mask_mode, float p_drop, uint32_t seed, void* stream) {
     AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention_train: null pointer");
-    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H == heads * HD && p_drop >= 0.f && p_drop < 1.f, "ag_masked_attention_train: bad arguments");
+    AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H % heads == 0 && p_drop >= 0.f && p_drop < 1.f, "ag_masked_attention_train: bad arguments");
     if (R == 0) return AG_OK;
     AttnArgs a;
     a.qkv = (const char*)d_qkv; a.mask = d_mask_bits; a.ctx = (char*)d_ctx;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = 1; a.mode = mask_mode;
     a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed;
-    hipLaunchKernelGGL(attn_f32_kernel, dim3(R * heads), dim3(256), 0, (hipStream_t)stream, a);
-    AG_LAUNCH_CHECK();
-    return AG_OK;
+    return launch_valu<float>(a, H / heads, (hipStream_t)stream);
 }

@@ -35,6 +35,8 @@ struct GemmArgs {
     const void* R; long ldr;  // residual, storage dtype
     int T, share;
     int M, N, K;
+    long kbytes;          // K * sizeof(T): 16-B chunks at or beyond it are read from `zeros` instead
+    const char* zeros;    // >= 16 B of zeros in HBM
 };
 
 template <typename T> struct Mma;
@@ -60,7 +62,7 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 // stage one 128-row x 128-byte operand tile; rows beyond `rows_total` are clamped (their products
 // only reach accumulators that the epilogue never stores).
 __device__ __forceinline__ void stage_tile(const char* base, long ld_b, int row0, int rows_total, long kbyte0,
-                                           char* lds_tile, int wave, int lane) {
+                                           char* lds_tile, int wave, int lane, long kbytes, const char* zeros) {
     const int r_in = lane >> 3, slot = lane & 7;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -68,7 +70,8 @@ __device__ __forceinline__ void stage_tile(const char* base, long ld_b, int row0
         int grow = row0 + row;
         grow = grow < rows_total ? grow : rows_total - 1;
         const int chunk = slot ^ (row & 7);
-        glds16(base + (long)grow * ld_b + kbyte0 + chunk * 16, lds_tile + (wave * 32 + i * 8) * ROWB);
+        const long kb = kbyte0 + chunk * 16;   // K tail (K*sizeof(T) not a multiple of 128 B): the missing chunks are zeros
+        glds16(kb < kbytes ? base + (long)grow * ld_b + kb : zeros, lds_tile + (wave * 32 + i * 8) * ROWB);
     }
 }
 
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)(((long)p.K * (long)sizeof(T)) / ROWB);
+    const int nk = (int)((p.kbytes + ROWB - 1) / ROWB);
     // LDS: [buf0: A tile | W tile][buf1: A tile | W tile]
-    stage_tile(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane);
-    stage_tile(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane, p.kbytes, p.zeros);
+    stage_tile(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane);
-            stage_tile(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane);
+            stage_tile(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane, p.kbytes, p.zeros);
+            stage_tile(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
         }
         const char* tA = smem + cur * 2 * TILE_BYTES;
         const char* tW = tA + TILE_BYTES;
@@ -133,13 +136,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
 
     // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15) per sub-tile ----
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32 || sizeof(T) == 4);
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (EPI != AG_EPI_BIAS_RESID || (p.ldr & 3) == 0);
+    constexpr bool HAS_R = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_GELU_ADD);
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!HAS_R || (p.ldr & 3) == 0);
 #pragma unroll
     for (int sm = 0; sm < 4; ++sm) {
         const int m = m0 + wm * 64 + sm * 16 + frow;
         if (m >= p.M) continue;
         long rrow = 0;
-        if (EPI == AG_EPI_BIAS_RESID) {
+        if (HAS_R) {
             const int seq = m / p.T, t = m - seq * p.T;
             rrow = (long)(seq / p.share) * p.T + t;
         }
@@ -148,14 +152,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
             const int n = n0 + wn * 64 + sn * 16 + fq * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
+            float rres[4] = {0.f, 0.f, 0.f, 0.f};   // AG_EPI_BIAS_GELU_ADD: residual joins after the activation
             if (vec_ok) {
                 if (p.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if (EPI == AG_EPI_BIAS_RESID) {
+                if (HAS_R) {
                     const float4 rv = load4_as_f32(reinterpret_cast<const T*>(p.R) + rrow * p.ldr + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                    if (EPI == AG_EPI_BIAS_RESID) { v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+                    else { rres[0] = rv.x; rres[1] = rv.y; rres[2] = rv.z; rres[3] = rv.w; }
                 }
             } else {
 #pragma unroll
@@ -163,12 +169,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
                     if (n + j < p.N) {
                         if (p.bias) v[j] += p.bias[n + j];
                         if (EPI == AG_EPI_BIAS_RESID) v[j] += Store<T>::load(reinterpret_cast<const T*>(p.R) + rrow * p.ldr + n + j);
+                        if (EPI == AG_EPI_BIAS_GELU_ADD) rres[j] = Store<T>::load(reinterpret_cast<const T*>(p.R) + rrow * p.ldr + n + j);
                     }
                 }
             }
-            if (EPI == AG_EPI_BIAS_GELU) {
+            if (EPI == AG_EPI_BIAS_GELU || EPI == AG_EPI_BIAS_GELU_ADD) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? fast_gelu(v[j]) : gelu_erf(v[j]);  // bf16 mode: |erf err| <= 1.5e-7
+                for (int j = 0; j < 4; ++j) v[j] = (sizeof(T) == 2 ? fast_gelu(v[j]) : gelu_erf(v[j])) + rres[j];  // bf16 mode: |gelu err| <= 1e-4
             }
             if (EPI == AG_EPI_BIAS_TANH) {
 #pragma unroll
@@ -220,6 +227,7 @@ int dispatch(int epi, const GemmArgs& a, hipStream_t s) {
         case AG_EPI_BIAS_RESID: return launch<T, AG_EPI_BIAS_RESID>(a, s);
         case AG_EPI_BIAS_F32: return launch<T, AG_EPI_BIAS_F32>(a, s);
         case AG_EPI_BIAS_TANH: return launch<T, AG_EPI_BIAS_TANH>(a, s);
+        case AG_EPI_BIAS_GELU_ADD: return launch<T, AG_EPI_BIAS_GELU_ADD>(a, s);
         default: return ag_fail(AG_ERR_INVALID, "ag_gemm: unknown epilogue %d", epi);
     }
 }
@@ -234,9 +242,10 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gemm: bad dtype %d", dtype);
     const size_t es = dtype_size(dtype);
-    AG_REQUIRE((K * es) % ROWB == 0, "ag_gemm: K=%d must be a multiple of %d for this dtype", K, (int)(ROWB / es));
+    AG_REQUIRE((K * es) % 16 == 0, "ag_gemm: K=%d must be a multiple of %d for this dtype", K, (int)(16 / es));
     AG_REQUIRE((lda * es) % 16 == 0, "ag_gemm: lda=%ld rows must be 16-byte aligned", (long)lda);
-    AG_REQUIRE(epilogue != AG_EPI_BIAS_RESID || (d_R && rows_per_seq > 0 && resid_share > 0),
+    const bool has_r = epilogue == AG_EPI_BIAS_RESID || epilogue == AG_EPI_BIAS_GELU_ADD;
+    AG_REQUIRE(!has_r || (d_R && rows_per_seq > 0 && resid_share > 0),
                "ag_gemm: residual epilogue needs R, rows_per_seq and resid_share");
     if (M == 0) return AG_OK;
     GemmArgs a;
@@ -244,14 +253,20 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     a.W = (const char*)d_W; a.ldw_b = (long)K * es;
     a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc;
     a.R = d_R; a.ldr = ldr; a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
-    a.M = M; a.N = N; a.K = K;
+    a.M = M; a.N = N; a.K = K; a.kbytes = (long)K * es;
+    static char* zero_chunk = nullptr;   // source of the K-tail chunks (one per process; never freed)
+    if (!zero_chunk) {
+        AG_HIP_CHECK(hipMalloc((void**)&zero_chunk, 256));
+        AG_HIP_CHECK(hipMemset(zero_chunk, 0, 256));
+    }
+    a.zeros = zero_chunk;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic work of this launch: 2*M*N*K flops; bytes = A + W + C (+R) each touched once
     const double out_es = (epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
-                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (epilogue == AG_EPI_BIAS_RESID ? (double)M * N * es : 0.0), s);
+                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (has_r ? (double)M * N * es : 0.0), s);
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
-    const bool big = dtype == AG_BF16 && !force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
+    const bool big = dtype == AG_BF16 && !force_small && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
     AG_REQUIRE(big || (!d_ln_stats && !d_stats_out), "ag_gemm: LayerNorm folding is only available on the large-M bf16 path "
                "(check ag_gemm_supports_ln_fold first)");
     AG_REQUIRE(!d_ln_stats || d_ln_colsum, "ag_gemm: ln_stats given without ln_colsum");

@@ -122,13 +122,13 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks
 // qkv [R,T,3H] (row r reads source row r: no sharing in training), dctx [R,T,H], ctx [R,T,H].
 // Pass A (thread per query i): m_i, l_i, D_i = dO_i.O_i, and dQ_i.   Pass B (thread per key j): dK_j, dV_j.
 // s_ij = q_i.k_j/8, ViT: s*=mask_j, BERT: masked j excluded.  p-dropout: kept entries scaled by 1/(1-p).
-constexpr int AHD = 64;
 struct AttnBwdArgs {
     const float* qkv; const uint32_t* mask; const float* ctx; const float* dctx;
     float* dqkv; float* stats;  // stats [R*heads*T][3] = (m, l, D)
     int R, T, H, heads, mode, Tw; float pdrop; uint32_t seed;
 };
-__device__ __forceinline__ float dot64(const float* a, const float* b) {
+template <int AHD>
+__device__ __forceinline__ float dot_hd(const float* a, const float* b) {
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < AHD; d += 4) {
@@ -137,7 +137,9 @@ __device__ __forceinline__ float dot64(const float* a, const float* b) {
     }
     return s;
 }
+template <int AHD>
 __global__ __launch_bounds__(256) void attn_bwd_query_kernel(AttnBwdArgs p) {
+    const float inv_sqrt_d = 1.0f / sqrtf((float)AHD);
     __shared__ __attribute__((aligned(16))) float sK[64 * AHD];
     __shared__ __attribute__((aligned(16))) float sV[64 * AHD];
     const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads, tid = threadIdx.x;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_bwd_query_kernel(AttnBwdArgs p) {
             for (int kk = 0; kk < kn; ++kk) {
                 const int j = k0 + kk;
                 const bool on = (mrow[j >> 5] >> (j & 31)) & 1u;
-                float s = dot64(q, sK + kk * AHD) * 0.125f;
+                float s = dot_hd<AHD>(q, sK + kk * AHD) * inv_sqrt_d;
                 if (p.mode == AG_MASK_VIT_MUL) s = on ? s : 0.f; else if (!on) continue;
                 const float mn = fmaxf(m, s);
                 l = l * expf(m - mn) + expf(s - mn);
@@ -195,12 +197,12 @@ __global__ __launch_bounds__(256) void attn_bwd_query_kernel(AttnBwdArgs p) {
             for (int kk = 0; kk < kn; ++kk) {
                 const int j = k0 + kk;
                 const bool on = (mrow[j >> 5] >> (j & 31)) & 1u;
-                float s = dot64(q, sK + kk * AHD) * 0.125f;
+                float s = dot_hd<AHD>(q, sK + kk * AHD) * inv_sqrt_d;
                 if (p.mode == AG_MASK_VIT_MUL) s = on ? s : 0.f; else if (!on) continue;
                 const float pr = expf(s - m) / l;
-                float dP = dot64(dO, sV + kk * AHD);
+                float dP = dot_hd<AHD>(dO, sV + kk * AHD);
                 if (p.pdrop > 0.f) dP = keep_elem(p.seed, ((uint64_t)(blockIdx.x) * p.T + i) * p.T + j, p.pdrop) ? dP * keep_sc : 0.f;
-                float ds = pr * (dP - D) * 0.125f;
+                float ds = pr * (dP - D) * inv_sqrt_d;
                 if (p.mode == AG_MASK_VIT_MUL && !on) ds = 0.f;  // d(s*0)/ds = 0
 #pragma unroll
                 for (int d = 0; d < AHD; ++d) dq[d] = fmaf(ds, sK[kk * AHD + d], dq[d]);
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(256) void attn_bwd_query_kernel(AttnBwdArgs p) {
         }
     }
 }
+template <int AHD>
 __global__ __launch_bounds__(256) void attn_bwd_key_kernel(AttnBwdArgs p) {
+    const float inv_sqrt_d = 1.0f / sqrtf((float)AHD);
     __shared__ __attribute__((aligned(16))) float sQ[64 * AHD];
     __shared__ __attribute__((aligned(16))) float sO[64 * AHD];
     __shared__ float sS[64 * 3];
@@ -254,17 +258,17 @@ __global__ __launch_bounds__(256) void attn_bwd_key_kernel(AttnBwdArgs p) {
             if (valid && (p.mode == AG_MASK_VIT_MUL || on)) {
                 for (int ii = 0; ii < in; ++ii) {
                     const int i = i0 + ii;
-                    float s = dot64(k, sQ + ii * AHD) * 0.125f;
+                    float s = dot_hd<AHD>(k, sQ + ii * AHD) * inv_sqrt_d;
                     if (p.mode == AG_MASK_VIT_MUL) s = on ? s : 0.f;
                     const float pr = expf(s - sS[ii * 3]) / sS[ii * 3 + 1];
-                    float dP = dot64(v, sO + ii * AHD);
+                    float dP = dot_hd<AHD>(v, sO + ii * AHD);
                     float pk = pr;  // weight that multiplied V_j in the forward (after dropout)
                     if (p.pdrop > 0.f) {
                         const bool kp_ = keep_elem(p.seed, ((uint64_t)(blockIdx.x) * p.T + i) * p.T + j, p.pdrop);
                         dP = kp_ ? dP * keep_sc : 0.f;
                         pk = kp_ ? pr * keep_sc : 0.f;
                     }
-                    float ds = pr * (dP - sS[ii * 3 + 2]) * 0.125f;
+                    float ds = pr * (dP - sS[ii * 3 + 2]) * inv_sqrt_d;
                     if (p.mode == AG_MASK_VIT_MUL && !on) ds = 0.f;
 #pragma unroll
                     for (int d = 0; d < AHD; ++d) { dv[d] = fmaf(pk, sO[ii * AHD + d], dv[d]); dk[d] = fmaf(ds, sQ[ii * AHD + d], dk[d]); }
@@ -350,14 +354,27 @@ extern "C" int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mas
                                        float* d_dqkv, float* d_stats, int R, int T, int H, int heads, int mask_mode,
                                        float p_drop, uint32_t seed, void* stream) {
     AG_REQUIRE(d_qkv && d_mask_bits && d_ctx && d_dctx && d_dqkv && d_stats, "ag_masked_attention_bwd: null pointer");
-    AG_REQUIRE(H == heads * AHD && R >= 0 && T >= 1 && p_drop >= 0.f && p_drop < 1.f, "ag_masked_attention_bwd: bad arguments");
+    AG_REQUIRE(heads > 0 && H % heads == 0 && R >= 0 && T >= 1 && p_drop >= 0.f && p_drop < 1.f, "ag_masked_attention_bwd: bad arguments");
     if (R == 0) return AG_OK;
     AttnBwdArgs a;
     a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = d_ctx; a.dctx = d_dctx; a.dqkv = d_dqkv; a.stats = d_stats;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
-    hipLaunchKernelGGL(attn_bwd_query_kernel, dim3(R * heads), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(R * heads), block(256);
+    hipStream_t hs = (hipStream_t)stream;
+    switch (H / heads) {
+        case 8: hipLaunchKernelGGL(attn_bwd_query_kernel<8>, grid, block, 0, hs, a); break;
+        case 16: hipLaunchKernelGGL(attn_bwd_query_kernel<16>, grid, block, 0, hs, a); break;
+        case 32: hipLaunchKernelGGL(attn_bwd_query_kernel<32>, grid, block, 0, hs, a); break;
+        case 64: hipLaunchKernelGGL(attn_bwd_query_kernel<64>, grid, block, 0, hs, a); break;
+        default: return ag_fail(AG_ERR_INVALID, "ag_masked_attention_bwd: head_dim %d not built (8, 16, 32, 64)", H / heads);
+    }
     AG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_key_kernel, dim3(R * heads), dim3(256), 0, (hipStream_t)stream, a);
+    switch (H / heads) {
+        case 8: hipLaunchKernelGGL(attn_bwd_key_kernel<8>, grid, block, 0, hs, a); break;
+        case 16: hipLaunchKernelGGL(attn_bwd_key_kernel<16>, grid, block, 0, hs, a); break;
+        case 32: hipLaunchKernelGGL(attn_bwd_key_kernel<32>, grid, block, 0, hs, a); break;
+        default: hipLaunchKernelGGL(attn_bwd_key_kernel<64>, grid, block, 0, hs, a); break;
+    }
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -40,7 +40,7 @@ enum {
     AG_EPI_BIAS_RESID = 2,  /* C = A·Wᵀ + b + R   (R, C: storage dtype = the residual stream) */
     AG_EPI_BIAS_F32 = 3,    /* C = A·Wᵀ + b                     -> fp32                     */
     AG_EPI_BIAS_TANH = 4,   /* C = tanh(A·Wᵀ + b)               -> storage dtype (pooler)   */
-    AG_EPI_BIAS_GELU_F32 = 5 /* reserved */
+    AG_EPI_BIAS_GELU_ADD = 5 /* C = R + gelu_erf(A·Wᵀ + b)  (side-network ladder add, reference models/ltt_vit.py:431) */
 };
 
 int ag_abi_version(void);

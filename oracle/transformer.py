@@ -208,3 +208,99 @@ def bert_explainer(ids: np.ndarray, mask_p: np.ndarray, grand: np.ndarray, null:
     if duo:
         return phi, bert_pool_classify(z, sd, act=False)
     return phi
+
+
+# ----------------------------------------------------------------------------- LTT (ladder side network)
+def _ltt_encoder(h: np.ndarray, mask_t: np.ndarray, sd: SD, cfg: dict, prefix: str, branches, layer_fn,
+                 collect: Optional[list] = None):
+    """reference models/ltt_vit.py:407-440 / models/ltt_bert.py:468-500: after backbone layer i, every requested
+    branch b does  side_b = side_b + gelu(Linear_{b,i}(hidden));  side_b = Layer_{b,i}(side_b, mask)."""
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    side = {b: np.float32(0.0) for b in branches}
+    for i in range(cfg["num_hidden_layers"]):
+        h = layer_fn(h, mask_t, sd, f"{prefix}.encoder.layers.{i}", nh, eps)
+        if collect is not None:
+            collect.append(h)
+        for b in branches:
+            s = side[b] + gelu(linear(h, sd, f"{prefix}.encoder.s_attn_maps.{b}_{i}"))
+            side[b] = layer_fn(s.astype(np.float32), mask_t, sd, f"{prefix}.encoder.s_attn_layers.{b}_{i}", nh, eps)
+    return h, [side[b] for b in branches]
+
+
+def ltt_vit_model(x: np.ndarray, mask_t: np.ndarray, sd: SD, cfg: dict, branches, collect: Optional[list] = None):
+    """reference models/ltt_vit.py:323-340 -> (LN_f(hidden), [LN_b(side_b)])."""
+    h = vit_embeddings(x, sd, "vit.embeddings", cfg["img_patch_size"])
+    if collect is not None:
+        collect.append(h)
+    h, sides = _ltt_encoder(h, mask_t, sd, cfg, "vit", branches, vit_layer, collect)
+    eps = cfg["layer_norm_eps"]
+    return layer_norm(h, sd, "vit.layernorm", eps), [layer_norm(s, sd, f"vit.s_attn_layernorm.{b}", eps) for b, s in zip(branches, sides)]
+
+
+def ltt_vit_surrogate(x: np.ndarray, mask_p: np.ndarray, sd: SD, cfg: dict, collect: Optional[list] = None):
+    """models/ltt_vit.py:79-94 -> (side probabilities, backbone probabilities)."""
+    z, (s,) = ltt_vit_model(x, prepend_cls(mask_p), sd, cfg, [0], collect)
+    return softmax(linear(s[:, 0, :], sd, "s_attn_classifier")), softmax(linear(z[:, 0, :], sd, "classifier"))
+
+
+def _ltt_vit_head(o: np.ndarray, mask_t: np.ndarray, sd: SD, cfg: dict, grand, null) -> np.ndarray:
+    for j in range(cfg["explainer_s_attn_num_layers"]):
+        o = vit_layer(o, mask_t, sd, f"s_explainer_attn.{j}", cfg["num_attention_heads"], cfg["layer_norm_eps"], norm1_identity=(j == 0))
+    o = layer_norm(o, sd, "s_explainer_mlp.0", 1e-5)  # torch default eps (models/ltt_vit.py:124)
+    o = linear(gelu(linear(gelu(linear(o, sd, "s_explainer_mlp.1")), sd, "s_explainer_mlp.3")), sd, "s_explainer_mlp.5")
+    if cfg["explainer_normalize"]:
+        o = normalize_shapley_explanation(o, grand, null)
+    return np.ascontiguousarray(o[:, 1:, :].transpose(0, 2, 1))
+
+
+def ltt_vit_explainer(x, mask_p, grand, null, sd: SD, cfg: dict):
+    """models/ltt_vit.py:143-183 -> (phi [B,C,P], backbone probabilities)."""
+    mask_t = prepend_cls(mask_p)
+    z, (e,) = ltt_vit_model(x, mask_t, sd, cfg, [0])
+    return _ltt_vit_head(e, mask_t, sd, cfg, grand, null), softmax(linear(z[:, 0, :], sd, "classifier"))
+
+
+def ltt_vit_final(x, sd: SD, cfg: dict):
+    """models/ltt_vit.py:231-287 (explainer_normalize=True) -> (backbone probabilities, phi)."""
+    mask_t = np.ones((x.shape[0], (cfg["img_px_size"] // cfg["img_patch_size"]) ** 2 + 1), dtype=np.int64)
+    z, (s, e) = ltt_vit_model(x, mask_t, sd, cfg, [0, 1])
+    grand = softmax(linear(s[:, 0, :], sd, "s_attn_classifier"))
+    return softmax(linear(z[:, 0, :], sd, "classifier")), _ltt_vit_head(e, mask_t, sd, cfg, grand, sd["surrogate_null"])
+
+
+def ltt_bert_model(ids: np.ndarray, mask_t: np.ndarray, sd: SD, cfg: dict, branches, collect: Optional[list] = None):
+    """models/ltt_bert.py:383-401 (no final LayerNorms)."""
+    h = bert_embeddings(ids, sd, "bert.embeddings", cfg["layer_norm_eps"])
+    if collect is not None:
+        collect.append(h)
+    return _ltt_encoder(h, mask_t, sd, cfg, "bert", branches, bert_layer, collect)
+
+
+def ltt_bert_surrogate(ids, mask_p, sd: SD, cfg: dict, collect: Optional[list] = None):
+    """models/ltt_bert.py:98-117 -> (side probabilities, backbone probabilities)."""
+    z, (s,) = ltt_bert_model(ids, prepend_cls(mask_p), sd, cfg, [0], collect)
+    return bert_pool_classify(s, sd, "bert_s_attn_pooler", "s_attn_classifier"), bert_pool_classify(z, sd)
+
+
+def _ltt_bert_head(o: np.ndarray, mask_t: np.ndarray, sd: SD, cfg: dict, grand, null) -> np.ndarray:
+    for j in range(cfg["explainer_s_attn_num_layers"]):
+        o = bert_layer(o, mask_t, sd, f"s_attn_attention_layers.{j}", cfg["num_attention_heads"], cfg["layer_norm_eps"], norm1_identity=(j == 0))
+    o = linear(gelu(linear(gelu(linear(o, sd, "s_attn_explainer.0")), sd, "s_attn_explainer.2")), sd, "s_attn_explainer.4")
+    if cfg["explainer_normalize"]:
+        o = normalize_shapley_explanation(o, grand, null)
+    return np.ascontiguousarray(o[:, 1:, :].transpose(0, 2, 1))
+
+
+def ltt_bert_explainer(ids, mask_p, grand, null, sd: SD, cfg: dict):
+    """models/ltt_bert.py:167-218 -> (phi, backbone probabilities)."""
+    mask_t = prepend_cls(mask_p)
+    z, (e,) = ltt_bert_model(ids, mask_t, sd, cfg, [0])
+    return _ltt_bert_head(e, mask_t, sd, cfg, grand, null), bert_pool_classify(z, sd)
+
+
+def ltt_bert_final(ids, sd: SD, cfg: dict):
+    """models/ltt_bert.py:258-338 (explainer_normalize=True) -> (backbone probabilities, phi)."""
+    mask_t = np.ones_like(ids)
+    z, (s, e) = ltt_bert_model(ids, mask_t, sd, cfg, [0, 1])
+    grand = bert_pool_classify(s, sd, "bert_s_attn_pooler", "s_attn_classifier")
+    return bert_pool_classify(z, sd), _ltt_bert_head(e, mask_t, sd, cfg, grand, sd["surrogate_null"])

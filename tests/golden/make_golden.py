@@ -35,6 +35,8 @@ import reference.recipes.duo_vanilla_vit as r_dvit  # noqa: E402
 import reference.recipes.duo_vanilla_bert as r_dbert  # noqa: E402
 import reference.recipes.froyo_vit as r_fvit  # noqa: E402
 import reference.recipes.froyo_bert as r_fbert  # noqa: E402
+import reference.recipes.ltt_vit as r_lvit  # noqa: E402
+import reference.recipes.ltt_bert as r_lbert  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -210,7 +212,7 @@ def layer_trace(model_backbone_layers, run):
     return res, np.stack(outs)
 
 
-def gen_model_fixture(tag, recipe_fn, params, kind, B, K, mask_seed, duo=False, froyo=False):
+def gen_model_fixture(tag, recipe_fn, params, kind, B, K, mask_seed, duo=False, froyo=False, ltt=False):
     recipe = recipe_fn()
     cfg = recipe.t_config(**params)
     P = recipe.n_players(cfg)
@@ -239,6 +241,16 @@ def gen_model_fixture(tag, recipe_fn, params, kind, B, K, mask_seed, duo=False, 
         # an all-zero mask row and an all-one row are legal sampler outputs: pin them too
         edge_masks = torch.stack([torch.zeros(P, dtype=torch.long), torch.ones(P, dtype=torch.long)])
         v_edge, _ = recipe.fw_surrogate(m_srg, Xs[:1].repeat_interleave(2, 0), edge_masks)
+    aux = {}
+    if ltt:   # side-network recipes: the second output of fw_surrogate is the frozen backbone's own prediction, and
+        # Final runs two ladders off one backbone pass: pin both
+        with torch.no_grad():
+            _, v_s_cls = recipe.fw_surrogate(m_srg, Xs_ext, masks)
+            m_fin = recipe.t_final(cfg)
+            synth.load_synth_weights(m_fin, seed=2)
+            m_fin.eval()
+            fin_logits, fin_phi = recipe.fw_final(m_fin, Xs)
+        aux = dict(v_s_cls=v_s_cls.numpy(), fin_logits=fin_logits.numpy(), fin_phi=fin_phi.numpy())
     phi, extra = recipe.fw_explainer(m_exp, Xs, ones, v_1, v_0)
     phi_leaf = phi.detach().clone().requires_grad_(True)
     loss = rshap.loss_shapley_new(B, K, P, masks.reshape(B, K, P), v_0, v_s, v_1, phi_leaf)
@@ -250,11 +262,16 @@ def gen_model_fixture(tag, recipe_fn, params, kind, B, K, mask_seed, duo=False, 
         phi=phi.detach().numpy(), loss=np.asarray([loss.item()], dtype=np.float32), dphi=phi_leaf.grad.numpy(),
         layer_trace=trace,
     )
+    arrs.update(aux)
     if extra is not None:
         arrs["exp_logits"] = extra.detach().numpy()
     with open(os.path.join(HERE, f"model_{tag}.json"), "w") as f:
-        json.dump({"kind": kind, "duo": duo, "froyo": froyo, "params": params, "B": B, "K": K,
-                   "weights": {"surrogate_seed": 0, "explainer_seed": 1}, "input_seed": 0}, f, indent=1)
+        meta = {"kind": kind, "duo": duo, "froyo": froyo, "params": params, "B": B, "K": K,
+                "weights": {"surrogate_seed": 0, "explainer_seed": 1}, "input_seed": 0}
+        if ltt:
+            meta["ltt"] = True
+            meta["weights"]["final_seed"] = 2
+        json.dump(meta, f, indent=1)
     save(f"model_{tag}.npz", **arrs)
 
 
@@ -274,6 +291,36 @@ def gen_models():
     gen_model_fixture("froyo_vit_tiny_l3", r_fvit.froyo_vit_recipe, dvit, "vit", B=2, K=4, mask_seed=3407, froyo=True)
     fbert = dict(hparams("bert_base_tayp_froyo"), num_hidden_layers=2, max_position_embeddings=128)
     gen_model_fixture("froyo_bert_base_l2", r_fbert.froyo_bert_recipe, fbert, "bert", B=2, K=4, mask_seed=3407, froyo=True)
+
+
+def gen_ltt_models():
+    """LTT (ladder side network): a 3-layer ViT-tiny backbone with a 24-wide ladder (3 heads of 8, the
+    shipped head width) and the shipped BERT LTT config truncated to 2 layers (96-wide ladder, 12 heads of 8)."""
+    tiny = hparams("vit_tiny_imagenette_vanilla")
+    lvit = {k: v for k, v in tiny.items() if not k.startswith("explainer_")}
+    lvit.update(num_hidden_layers=3, explainer_s_attn_num_layers=1, explainer_s_head_hidden_size=128,
+                explainer_normalize=True, s_attn_hidden_size=24, s_attn_intermediate_size=96)
+    gen_model_fixture("ltt_vit_tiny_l3", r_lvit.ltt_vit_recipe, lvit, "vit", B=2, K=4, mask_seed=3407, ltt=True)
+    lbert = dict(hparams("bert_base_tayp_ltt"), num_hidden_layers=2, max_position_embeddings=128, explainer_s_head_hidden_size=256)
+    gen_model_fixture("ltt_bert_base_l2", r_lbert.ltt_bert_recipe, lbert, "bert", B=2, K=4, mask_seed=3407, ltt=True)
+
+
+def gen_ltt_state_keys():
+    tiny = hparams("vit_tiny_imagenette_vanilla")
+    lvit = {k: v for k, v in tiny.items() if not k.startswith("explainer_")}
+    lvit.update(num_hidden_layers=2, explainer_s_attn_num_layers=1, explainer_s_head_hidden_size=128,
+                explainer_normalize=True, s_attn_hidden_size=24, s_attn_intermediate_size=96)
+    lbert = dict(hparams("bert_base_tayp_ltt"), num_hidden_layers=1, max_position_embeddings=128)
+    out = {}
+    for kind, (fn, params) in {"ltt_vit": (r_lvit.ltt_vit_recipe, lvit), "ltt_bert": (r_lbert.ltt_bert_recipe, lbert)}.items():
+        rec = fn()
+        cfg = rec.t_config(**params)
+        out[kind] = {"params": params, "roles": {
+            role: {k: list(v.shape) for k, v in getattr(rec, "t_" + role)(cfg).state_dict().items()}
+            for role in ("classifier", "surrogate", "explainer", "final")}}
+    with open(os.path.join(HERE, "state_keys_ltt.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote state_keys_ltt.json")
 
 
 def gen_state_keys():
@@ -300,9 +347,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "state_keys":
         gen_state_keys()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
+        gen_ltt_models()
+        gen_ltt_state_keys()
+        sys.exit(0)
     seeds = gen_seeds()
     gen_masks(seeds)
     gen_shapley_fns()
     gen_perturbed()
     gen_models()
     gen_state_keys()
+    gen_ltt_models()
+    gen_ltt_state_keys()

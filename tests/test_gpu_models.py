@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import MODEL_TAGS, build_case
+from util import LTT_TAGS, MODEL_TAGS, build_case
 
 pytestmark = pytest.mark.gpu
 
@@ -96,3 +96,53 @@ def test_final_module_coherency(cuda_device):
     assert float((logits - ref_logits).abs().max()) <= 1e-5
     assert float((attr - ref_attr).abs().max()) <= 1e-5
     np.testing.assert_allclose(final.surrogate_null.cpu().numpy(), c["g"]["v_0"], rtol=1e-4, atol=1e-5)
+
+
+def _run_ltt(c, dev, precision):
+    from autognothi_amd import engine
+    engine.set_precision(precision)
+    recipe, g = c["recipe"], c["g"]
+    srg, exp, fin = c["surrogate"].to(dev), c["explainer"].to(dev), c["final"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    null = torch.from_numpy(c["null"]).to(dev)
+    masks = torch.from_numpy(c["masks"]).to(dev)
+    ones1 = torch.ones((1, c["P"]), dtype=torch.long, device=dev)
+    onesb = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
+    with torch.no_grad():
+        v_0, _ = recipe.fw_surrogate(srg, null, ones1)
+        v_s, v_s_cls = recipe.fw_surrogate(srg, xs, masks)      # B inputs, R = B*K masks (layer-0 sharing)
+        v_s_mat, _ = recipe.fw_surrogate(srg, torch.repeat_interleave(xs, c["K"], dim=0), masks)
+        v_1, _ = recipe.fw_surrogate(srg, xs, onesb)
+        edge = torch.stack([torch.zeros(c["P"], dtype=torch.long), torch.ones(c["P"], dtype=torch.long)]).to(dev)
+        v_edge, _ = recipe.fw_surrogate(srg, xs[:1], edge)
+        phi, exp_logits = recipe.fw_explainer(exp, xs, onesb, torch.from_numpy(g["v_1"]).to(dev), torch.from_numpy(g["v_0"]).to(dev))
+        fin_logits, fin_phi = recipe.fw_final(fin, xs)
+    out = dict(v_0=v_0, v_s=v_s, v_s_mat=v_s_mat, v_s_cls=v_s_cls, v_1=v_1, v_edge=v_edge, phi=phi, exp_logits=exp_logits,
+               fin_logits=fin_logits, fin_phi=fin_phi)
+    return {k: v.float().cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_ltt_fp32_matches_reference(cuda_device, tag):
+    """LTT ladder side network (reference models/ltt_vit.py, models/ltt_bert.py): side-branch
+    surrogate, explainer and the two-branch Final against reference-generated fixtures, fp32, 1e-4."""
+    c = build_case(tag)
+    got, g = _run_ltt(c, cuda_device, "fp32"), c["g"]
+    for k in ("v_0", "v_s", "v_s_cls", "v_1", "v_edge", "exp_logits", "fin_logits"):
+        np.testing.assert_allclose(got[k], g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    np.testing.assert_array_equal(got["v_s"], got["v_s_mat"])
+    for k in ("phi", "fin_phi"):
+        scale = float(np.abs(g[k]).max())
+        np.testing.assert_allclose(got[k], g[k], rtol=1e-4, atol=1e-4 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_ltt_bf16_close_to_reference(cuda_device, tag):
+    """Throughput mode (bf16 storage, 8-wide side heads on the VALU attention kernel): stated looser bound."""
+    c = build_case(tag)
+    got, g = _run_ltt(c, cuda_device, "bf16"), c["g"]
+    for k in ("v_0", "v_s", "v_s_cls", "v_1", "fin_logits"):
+        np.testing.assert_allclose(got[k], g[k], rtol=0, atol=2e-2, err_msg=k)
+    for k in ("phi", "fin_phi"):
+        scale = float(np.abs(g[k]).max())
+        assert float(np.abs(got[k] - g[k]).max()) <= 5e-2 * scale, k

@@ -36,7 +36,8 @@ def test_merge_rules():
 def test_state_dict_layout_contract():
     """Key names/shapes recorded from the reference classes (tests/golden/state_keys.json)."""
     from autognothi_amd.recipes import get_recipe
-    g = golden_json("state_keys.json")
+    g = dict(golden_json("state_keys.json"))
+    g.update(golden_json("state_keys_ltt.json"))
     for kind, entry in g.items():
         recipe = get_recipe(kind)
         cfg = recipe.t_config(**entry["params"])
@@ -69,8 +70,45 @@ def test_converters_round_trip_on_cpu_weights():
 def test_recipe_registry():
     from autognothi_amd.recipes import get_recipe
     assert get_recipe("vanilla_vit").id == "vanilla_bert"  # the reference's own copy-paste id (recipes/vanilla_vit.py:37)
+    assert get_recipe("ltt_vit").id == "ltt_vit" and get_recipe("ltt_bert").id == "ltt_bert"
     with pytest.raises(ValueError):
-        get_recipe("ltt_vit")
+        get_recipe("kernel_shap_bert")
+
+
+def test_ltt_converters_move_the_ladders():
+    """LTT stage machine (reference recipes/ltt_vit.py:84-224): classifier -> surrogate -> explainer keep the frozen
+    backbone; the surrogate's ladder stays branch 0 of Final and the explainer's becomes branch 1."""
+    from autognothi_amd.recipes import get_recipe
+    from autognothi_amd.utils import synth
+    g = golden_json("state_keys_ltt.json")
+    recipe = get_recipe("ltt_vit")
+    cfg = recipe.t_config(**g["ltt_vit"]["params"])
+    cls = recipe.t_classifier(cfg)
+    synth.load_synth_weights(cls, seed=3)
+    srg = recipe.conv_classifier_surrogate(cfg, None, cls)
+    exp = recipe.conv_surrogate_explainer(cfg, None, srg)
+    synth_exp = {k: v.clone() for k, v in exp.state_dict().items()}
+    a, b, c = cls.state_dict(), srg.state_dict(), exp.state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k])
+        if k.startswith("vit.") or k.startswith("classifier."):
+            assert torch.equal(a[k], c[k])
+    assert not any(k.startswith("s_attn_classifier") for k in c)
+    # Final: rules only (the null replay needs the GPU) — apply the same rules with a given surrogate_null
+    from autognothi_amd.recipes import ltt_vit as r
+    from autognothi_amd.utils.nnmodel import merge_state_dicts
+    final = recipe.t_final(cfg)
+    backbone = {"vit.embeddings.{_}": ..., "vit.encoder.layers.{_}": ..., "vit.layernorm.{wb}": ..., "classifier.{wb}": ...}
+    drop = {"vit.embeddings.{_}": None, "vit.encoder.layers.{_}": None, "vit.layernorm.{wb}": None, "classifier.{_}": None}
+    rc = dict(backbone); rc.update(r._side_rules(0, None, None)); rc["s_attn_classifier.{wb}"] = None
+    rs = dict(drop); rs.update(r._side_rules(0, None, ...)); rs["s_attn_classifier.{wb}"] = ...
+    re_ = dict(drop); re_.update(r._side_rules(0, 1, "move")); re_["s_explainer_attn.{_}"] = ...; re_["s_explainer_mlp.{_}"] = ...
+    merge_state_dicts((rc, cls), (rs, srg), (re_, exp), ({"surrogate_null": ...}, {"surrogate_null": torch.zeros(1, cfg.num_labels)}), into=final)
+    f = final.state_dict()
+    assert torch.equal(f["vit.encoder.s_attn_maps.0_1.weight"], b["vit.encoder.s_attn_maps.0_1.weight"])
+    assert torch.equal(f["vit.encoder.s_attn_maps.1_1.weight"], synth_exp["vit.encoder.s_attn_maps.0_1.weight"])
+    assert torch.equal(f["vit.s_attn_layernorm.1.weight"], synth_exp["vit.s_attn_layernorm.0.weight"])
+    assert torch.equal(f["s_explainer_mlp.5.weight"], synth_exp["s_explainer_mlp.5.weight"])
 
 
 def test_flop_accounting_matches_survey():

@@ -7,7 +7,7 @@ import pytest
 from oracle import shapley as osh
 from oracle import torch_port as otp
 from oracle import transformer as otr
-from util import MODEL_TAGS, build_case, state_dict_numpy
+from util import LTT_TAGS, MODEL_TAGS, build_case, state_dict_numpy
 
 ATOL = 1e-5
 
@@ -59,3 +59,34 @@ def test_oracle_matches_reference(tag):
     loss, dphi = osh.loss_shapley_new(c["B"], c["K"], c["P"], c["masks"], g["v_0"], g["v_s"], g["v_1"], g["phi"])
     np.testing.assert_allclose(loss, g["loss"][0], rtol=1e-5)
     np.testing.assert_allclose(dphi, g["dphi"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_oracle_ltt_matches_reference(tag):
+    """LTT (ladder side network): surrogate (side + backbone heads), explainer, two-branch Final."""
+    c = build_case(tag)
+    g, prm, kind = c["g"], c["meta"]["params"], c["meta"]["kind"]
+    sd_s, sd_e, sd_f = state_dict_numpy(c["surrogate"]), state_dict_numpy(c["explainer"]), state_dict_numpy(c["final"])
+    xs_ext = np.repeat(c["xs"], c["K"], axis=0)
+    ones1 = np.ones((1, c["P"]), dtype=np.int64)
+    onesb = np.ones((c["B"], c["P"]), dtype=np.int64)
+    srg = otr.ltt_vit_surrogate if kind == "vit" else otr.ltt_bert_surrogate
+    exp = otr.ltt_vit_explainer if kind == "vit" else otr.ltt_bert_explainer
+    fin = otr.ltt_vit_final if kind == "vit" else otr.ltt_bert_final
+    trace = []
+    v_s, v_s_cls = srg(xs_ext, c["masks"], sd_s, prm, collect=trace)
+    np.testing.assert_allclose(v_s, g["v_s"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(v_s_cls, g["v_s_cls"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(srg(c["null"], ones1, sd_s, prm)[0], g["v_0"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(srg(c["xs"], onesb, sd_s, prm)[0], g["v_1"], rtol=0, atol=ATOL)
+    for li in range(prm["num_hidden_layers"]):
+        got, want = checks(trace[li + 1]), g["layer_trace"][li]
+        np.testing.assert_allclose(got[2:], want[2:], rtol=0, atol=5e-5)
+    edge = np.stack([np.zeros(c["P"], dtype=np.int64), np.ones(c["P"], dtype=np.int64)])
+    np.testing.assert_allclose(srg(np.repeat(c["xs"][:1], 2, axis=0), edge, sd_s, prm)[0], g["v_edge"], rtol=0, atol=ATOL)
+    phi, logits = exp(c["xs"], onesb, g["v_1"], g["v_0"], sd_e, prm)
+    np.testing.assert_allclose(phi, g["phi"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(logits, g["exp_logits"], rtol=0, atol=ATOL)
+    f_logits, f_phi = fin(c["xs"], sd_f, prm)
+    np.testing.assert_allclose(f_logits, g["fin_logits"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(f_phi, g["fin_phi"], rtol=0, atol=2e-5)

@@ -38,7 +38,12 @@ MODEL_TAGS = ["vit_tiny_c1", "vit_base_l2", "vit_large_l2", "bert_base_l2", "duo
               "froyo_vit_tiny_l3", "froyo_bert_base_l2"]
 
 
+LTT_TAGS = ["ltt_vit_tiny_l3", "ltt_bert_base_l2"]
+
+
 def recipe_kind(meta):
+    if meta.get("ltt"):
+        return "ltt_" + meta["kind"]
     pre = "duo_vanilla_" if meta["duo"] else ("froyo_" if meta["froyo"] else "vanilla_")
     return pre + meta["kind"]
 
@@ -64,5 +69,10 @@ def build_case(tag):
     else:
         xs = synth.synth_token_ids(b, prm["max_position_embeddings"], prm["vocab_size"], seed=meta["input_seed"])
         null = synth.synth_null_ids(prm["max_position_embeddings"], prm["vocab_size"])
-    return dict(meta=meta, g=g, recipe=recipe, cfg=cfg, surrogate=srg, explainer=exp, xs=xs, null=null,
-                masks=unpack(g["masks"], p), B=b, K=k, P=p)
+    out = dict(meta=meta, g=g, recipe=recipe, cfg=cfg, surrogate=srg, explainer=exp, xs=xs, null=null,
+               masks=unpack(g["masks"], p), B=b, K=k, P=p)
+    if "final_seed" in meta["weights"]:
+        fin = recipe.t_final(cfg)
+        synth.load_synth_weights(fin, seed=meta["weights"]["final_seed"])
+        out["final"] = fin.eval()
+    return out
