@@ -79,10 +79,10 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
     """reference _explainer_epoch_train (:128-207) / _duo_explainer_epoch_train: per batch — K-mask surrogate
     targets (no grad, HIP inference path), explainer forward + Shapley loss + backward (HIP training kernels,
     autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean)."""
-    from ..training import ExplainerTrainer
+    from ..training import make_explainer_trainer
     env = env or Log()
     rng = device_rng(m_surrogate, device, seed)
-    trainer = m_explainer.__dict__.get("_ag_trainer") or ExplainerTrainer(m_recipe, m_explainer)
+    trainer = m_explainer.__dict__.get("_ag_trainer") or make_explainer_trainer(m_recipe, m_explainer)
     m_explainer.__dict__["_ag_trainer"] = trainer
     reg_loss, total = 0.0, 0
     m_explainer.train()

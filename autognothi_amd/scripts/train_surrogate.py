@@ -22,7 +22,7 @@ def surrogate_batch_loss(recipe: ModelRecipe, m_classifier, m_surrogate, xs: Ten
     _, bits = ops.mask_purely_uniform(rng, b, n_players, want_i64=False, want_bits=True)
     ones = torch.ones((b, n_players), dtype=torch.long, device=xs.device)
     with torch.no_grad():
-        orig, _ = recipe.fw_classifier(m_classifier, xs, ones)
+        _, orig = recipe.fw_classifier(m_classifier, xs, ones)   # the SECOND output, as the reference (:141): LTT returns (side, backbone)
         adapt, _ = recipe.fw_surrogate(m_surrogate, xs, bits)
     loss, dcur = ops.kl_loss(orig, adapt)
     return loss, dcur, orig, adapt
@@ -50,10 +50,10 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
                           gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None) -> float:
     """reference _surrogate_epoch_train (:112-160): uniform masks, frozen-classifier targets (no grad), masked
     surrogate forward + KL + backward on the HIP training kernels, reference optimiser step.  -> mean KL."""
-    from ..training import SurrogateTrainer
+    from ..training import make_surrogate_trainer
     env = env or Log()
     rng = device_rng(m_surrogate, device, seed)
-    trainer = m_surrogate.__dict__.get("_ag_trainer") or SurrogateTrainer(m_recipe, m_surrogate)
+    trainer = m_surrogate.__dict__.get("_ag_trainer") or make_surrogate_trainer(m_recipe, m_surrogate)
     m_surrogate.__dict__["_ag_trainer"] = trainer
     m_classifier.eval()
     m_surrogate.train()
@@ -65,7 +65,7 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
         _, bits = ops.mask_purely_uniform(rng, b, n_players, want_i64=False, want_bits=True)
         ones = torch.ones((b, n_players), dtype=torch.long, device=xs.device)
         with torch.no_grad():
-            orig, _ = m_recipe.fw_classifier(m_classifier, xs, ones)
+            _, orig = m_recipe.fw_classifier(m_classifier, xs, ones)   # second output (reference :141)
         loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
         distributed.allreduce_grads([p for p in m_surrogate.parameters() if p.requires_grad], average=True)
         optimizer.step()

@@ -203,8 +203,8 @@ class ViTBackboneTrainer:
         self.proj = Lin([vit.embeddings.patch_embeddings.projection])
         self.saved = None
 
-    def forward(self, x: Tensor, bits: Tensor, seeds: Seeds, train: bool) -> Tensor:
-        """-> LN_final(hidden) fp32 [B*T, H]."""
+    def forward(self, x: Tensor, bits: Tensor, seeds: Seeds, train: bool, tap: Optional[Callable[[int, Tensor], None]] = None) -> Tensor:
+        """-> LN_final(hidden) fp32 [B*T, H].  ``tap(i, hidden_i)`` is called after layer i (LTT ladder)."""
         c = self.vit.config
         b, p, h = x.shape[0], self.vit.n_players, c.hidden_size
         t = p + 1
@@ -224,8 +224,10 @@ class ViTBackboneTrainer:
         s_emb = seeds.next()
         ph = c.hidden_dropout_prob if train else 0.0
         hid = ops.dropout(h0.view(b * t, h), ph, s_emb)
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
             hid = blk.forward(hid, bits, b, t, seeds, train)
+            if tap is not None:
+                tap(i, hid)
         self.saved = (b, p, h, ph, s_emb)
         return self.ln_f.forward(hid)
 
@@ -256,7 +258,7 @@ class BertBackboneTrainer:
         self.ln_e = Norm(bert.embeddings.LayerNorm, c.layer_norm_eps)
         self.saved = None
 
-    def forward(self, ids: Tensor, bits: Tensor, seeds: Seeds, train: bool) -> Tensor:
+    def forward(self, ids: Tensor, bits: Tensor, seeds: Seeds, train: bool, tap: Optional[Callable[[int, Tensor], None]] = None) -> Tensor:
         c, e = self.bert.config, self.bert.embeddings
         ids = ids.contiguous().to(torch.int64)
         b, t = ids.shape
@@ -269,8 +271,10 @@ class BertBackboneTrainer:
         s_emb = seeds.next()
         ph = c.hidden_dropout_prob if train else 0.0
         hid = ops.dropout(self.ln_e.forward(emb), ph, s_emb)
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
             hid = blk.forward(hid, bits, b, t, seeds, train)
+            if tap is not None:
+                tap(i, hid)
         self.saved = (ids, b, t, h, ph, s_emb)
         return hid
 
@@ -448,3 +452,157 @@ class SurrogateTrainer:
         dz[:, 0, :].copy_(dzc)
         self.backbone.backward(dz.view(b * t, h))
         return loss, probs
+
+
+# ------------------------------------------------------------------------------------------------ LTT (ladder side network)
+class LadderTrainer:
+    """LttViTModel / LttBertModel with ONE side branch (reference models/ltt_vit.py:407-440, ltt_bert.py:468-500): the
+    frozen backbone is run layer by layer; after layer i the trainable ladder does
+    ``side = side + gelu(map_i(hidden_i)); side = SideLayer_i(side, mask)``.  Backward touches the ladder only."""
+
+    def __init__(self, model: nn.Module, is_vit: bool, branch: int = 0):
+        self.model, self.is_vit, self.branch = model, is_vit, branch
+        c = model.config
+        self.kind = L.AG_MASK_VIT_MUL if is_vit else L.AG_MASK_BERT_ADD
+        frozen = [model.embeddings, model.encoder.layers] + ([model.layernorm] if is_vit else [])
+        if any(_any_trainable(m) for m in frozen):
+            raise NotImplementedError("LTT training expects the backbone frozen (reference models/ltt_vit.py:68-74)")
+        self.backbone = ViTBackboneTrainer(model) if is_vit else BertBackboneTrainer(model)
+        enc = model.encoder
+        n = enc.num_layers
+        self.maps = [Lin([enc.s_attn_maps[f"{branch}_{i}"]]) for i in range(n)]
+        self.side = [Block(enc.s_attn_layers[f"{branch}_{i}"], self.kind, c.num_attention_heads, c.layer_norm_eps,
+                           c.hidden_dropout_prob, c.attention_probs_dropout_prob) for i in range(n)]
+        self.ln_s = Norm(model.s_attn_layernorm[branch], c.layer_norm_eps) if is_vit else None
+        self.pre: List[Tensor] = []
+
+    def forward(self, x: Tensor, bits: Tensor, seeds: Seeds, train: bool) -> Tuple[Tensor, Tensor]:
+        """-> (backbone output [B*T, H] (ViT: after the final LN), side output [B*T, h] (ViT: after its LN))."""
+        enc = self.model.encoder
+        b = x.shape[0]
+        state = {"side": None, "t": None}
+        self.pre = []
+
+        def tap(i: int, hid: Tensor) -> None:
+            if i >= enc._ltt_freeze_layer:
+                return
+            t = hid.shape[0] // b
+            pre = self.maps[i].forward(hid)
+            g = ops.gelu(pre)
+            s_in = g if state["side"] is None else ops.add(state["side"], g)
+            state["side"] = self.side[i].forward(s_in, bits, b, t, seeds, train)
+            self.pre.append(pre)
+
+        z = self.backbone.forward(x, bits, seeds, train, tap=tap)
+        side = state["side"]
+        if self.ln_s is not None:
+            side = self.ln_s.forward(side)
+        return z, side
+
+    def backward(self, dside: Tensor) -> None:
+        d = self.ln_s.backward(dside) if self.ln_s is not None else dside
+        for i in reversed(range(len(self.pre))):
+            d = self.side[i].backward(d)                       # grad of (side_{i-1} + gelu(pre_i))
+            self.maps[i].backward(ops.gelu_bwd(self.pre[i], d), need_dx=False)   # the backbone is frozen: no dX
+        self.pre = []
+        # drop what the frozen backbone saved
+        for blk in self.backbone.blocks:
+            blk.saved = None
+            for lin in (blk.qkv, blk.o, blk.fc1, blk.fc2):
+                lin.x = None
+            blk.n1.x = blk.n2.x = None
+        self.backbone.saved = None
+
+
+class LttSurrogateTrainer:
+    """LTT surrogate step (scripts/train_surrogate.py:133-147 on recipes/ltt_*): masked ladder forward, side head,
+    KL against the frozen backbone's own prediction, backward into the ladder + side head."""
+
+    def __init__(self, recipe, m_surrogate: nn.Module):
+        self.recipe, self.m = recipe, m_surrogate
+        self.is_vit = hasattr(m_surrogate, "vit")
+        self.ladder = LadderTrainer(m_surrogate.vit if self.is_vit else m_surrogate.bert, self.is_vit, 0)
+        self.cls = Lin([m_surrogate.s_attn_classifier])
+        self.pool = None if self.is_vit else Lin([m_surrogate.bert_s_attn_pooler.dense])
+        self.step = 0
+
+    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+        cfg = self.m.config
+        engine.set_precision("fp32")
+        self.step += 1
+        seeds = Seeds(seed * 104729 + self.step)
+        b = xs.shape[0]
+        t, hs = self.recipe.n_players(cfg) + 1, cfg.s_attn_hidden_size
+        _, side = self.ladder.forward(xs, bits, seeds, train)
+        sc = side.view(b, t, hs)[:, 0, :].contiguous()
+        ph = 0.0
+        if self.is_vit:
+            logits = self.cls.forward(sc, L.AG_EPI_BIAS_F32)
+        else:
+            pooled = self.pool.forward(sc, L.AG_EPI_BIAS_TANH)
+            s_pool = seeds.next()
+            ph = cfg.hidden_dropout_prob if train else 0.0
+            logits = self.cls.forward(ops.dropout(pooled, ph, s_pool), L.AG_EPI_BIAS_F32)
+        probs = ops.softmax_rows(logits)
+        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
+        dlogits = ops.softmax_rows_bwd(probs, dprobs)
+        if self.is_vit:
+            dsc = self.cls.backward(dlogits)
+        else:
+            dp = ops.dropout(self.cls.backward(dlogits), ph, s_pool)
+            dsc = self.pool.backward(ops.tanh_bwd(pooled, dp))
+        dside = torch.zeros((b, t, hs), dtype=torch.float32, device=xs.device)
+        dside[:, 0, :].copy_(dsc)
+        self.ladder.backward(dside.view(b * t, hs))
+        return loss, probs
+
+
+class LttExplainerTrainer:
+    """LTT explainer step (scripts/train_explainer.py:182-196 on recipes/ltt_*): all-ones-mask ladder forward ->
+    side explainer layers -> MLP -> normalise -> Shapley loss; backward into the ladder + side head."""
+
+    def __init__(self, recipe, m_explainer: nn.Module):
+        self.recipe, self.m = recipe, m_explainer
+        cfg = m_explainer.config
+        self.is_vit = hasattr(m_explainer, "vit")
+        self.kind = L.AG_MASK_VIT_MUL if self.is_vit else L.AG_MASK_BERT_ADD
+        self.ladder = LadderTrainer(m_explainer.vit if self.is_vit else m_explainer.bert, self.is_vit, 0)
+        layers = m_explainer.s_explainer_attn if self.is_vit else m_explainer.s_attn_attention_layers
+        self.attn = [Block(ly, self.kind, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob,
+                           cfg.attention_probs_dropout_prob) for ly in layers]
+        self.mlp = MLPHead(m_explainer.s_explainer_mlp if self.is_vit else m_explainer.s_attn_explainer)
+        self.step = 0
+
+    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
+                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+        cfg = self.m.config
+        engine.set_precision("fp32")
+        self.step += 1
+        seeds = Seeds(seed * 7919 + self.step)
+        b = xs.shape[0]
+        p = self.recipe.n_players(cfg)
+        t, c = p + 1, cfg.num_labels
+        ones_bits = engine.ones_mask_bits(b, p, xs.device)
+        _, o = self.ladder.forward(xs, ones_bits, seeds, train)
+        for blk in self.attn:
+            o = blk.forward(o, ones_bits, b, t, seeds, train)
+        s_exp = seeds.next()
+        ph = cfg.hidden_dropout_prob if (train and not self.is_vit) else 0.0   # BERT s_attn_exp_dropout (ltt_bert.py:205)
+        o = ops.dropout(o, ph, s_exp)
+        pred = self.mlp.forward(o).view(b, t, c)
+        phi = ops.shapley_normalize(pred, v_1, v_0, normalize=bool(cfg.explainer_normalize))
+        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
+        dpred = ops.shapley_normalize_bwd(dphi, t, normalize=bool(cfg.explainer_normalize)).view(b * t, c)
+        d = ops.dropout(self.mlp.backward(dpred), ph, s_exp)
+        for blk in reversed(self.attn):
+            d = blk.backward(d)
+        self.ladder.backward(d)
+        return loss, phi
+
+
+def make_explainer_trainer(recipe, m_explainer: nn.Module):
+    return LttExplainerTrainer(recipe, m_explainer) if recipe.id.startswith("ltt_") else ExplainerTrainer(recipe, m_explainer)
+
+
+def make_surrogate_trainer(recipe, m_surrogate: nn.Module):
+    return LttSurrogateTrainer(recipe, m_surrogate) if recipe.id.startswith("ltt_") else SurrogateTrainer(recipe, m_surrogate)

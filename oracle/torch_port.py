@@ -144,3 +144,57 @@ def bert_surrogate(ids, mask_p, sd: SD, cfg: dict):
         h = _ln(_lin(F.gelu(_lin(a, sd, p + ".intermediate.dense")), sd, p + ".output.dense") + a, sd, p + ".output.LayerNorm", eps)
     pooled = torch.tanh(_lin(h[:, 0], sd, "bert_pooler.dense"))
     return F.softmax(_lin(pooled, sd, "classifier"), dim=-1)
+
+
+# ----------------------------------------------------------------------------- LTT (ladder side network), differentiable
+def _ltt_run(x, mask_t, sd: SD, cfg: dict, kind: str, branch: int = 0):
+    """reference models/ltt_vit.py:323-340,:407-440 / models/ltt_bert.py:383-401,:468-500 -> (backbone out, side out)."""
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    if kind == "vit":
+        pr = "vit.embeddings"
+        e = F.conv2d(x, sd[pr + ".patch_embeddings.projection.weight"], sd[pr + ".patch_embeddings.projection.bias"],
+                     stride=cfg["img_patch_size"]).flatten(2).transpose(1, 2)
+        h = torch.cat([sd[pr + ".cls_token"].expand(x.shape[0], -1, -1), e], dim=1) + sd[pr + ".position_embeddings"]
+        layer, top = _vit_layer, "vit"
+    else:
+        t = x.shape[1]
+        pr = "bert.embeddings"
+        e = sd[pr + ".word_embeddings.weight"][x] + sd[pr + ".token_type_embeddings.weight"][0]
+        h = _ln(e + sd[pr + ".position_embeddings.weight"][:t][None], sd, pr + ".LayerNorm", eps)
+        layer, top = _bert_layer, "bert"
+    side = 0.0
+    for i in range(cfg["num_hidden_layers"]):
+        h = layer(h, mask_t, sd, f"{top}.encoder.layers.{i}", nh, eps)
+        side = side + F.gelu(_lin(h, sd, f"{top}.encoder.s_attn_maps.{branch}_{i}"))
+        side = layer(side, mask_t, sd, f"{top}.encoder.s_attn_layers.{branch}_{i}", nh, eps)
+    if kind == "vit":
+        return _ln(h, sd, "vit.layernorm", eps), _ln(side, sd, f"vit.s_attn_layernorm.{branch}", eps)
+    return h, side
+
+
+def ltt_surrogate_probs(x, mask_p, sd: SD, cfg: dict, kind: str):
+    """side-branch surrogate output (models/ltt_vit.py:79-94 / ltt_bert.py:98-117), dropout off."""
+    _, s = _ltt_run(x, _prepend_cls(mask_p), sd, cfg, kind)
+    if kind == "vit":
+        return F.softmax(_lin(s[:, 0], sd, "s_attn_classifier"), dim=-1)
+    return F.softmax(_lin(torch.tanh(_lin(s[:, 0], sd, "bert_s_attn_pooler.dense")), sd, "s_attn_classifier"), dim=-1)
+
+
+def ltt_explainer_phi(x, mask_p, grand, null, sd: SD, cfg: dict, kind: str):
+    """fw_explainer of the LTT recipes (models/ltt_vit.py:143-183 / ltt_bert.py:167-218), dropout off -> phi [B,C,P]."""
+    mask_t = _prepend_cls(mask_p)
+    nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    _, o = _ltt_run(x, mask_t, sd, cfg, kind)
+    if kind == "vit":
+        for j in range(cfg["explainer_s_attn_num_layers"]):
+            o = _vit_layer(o, mask_t, sd, f"s_explainer_attn.{j}", nh, eps, norm1_identity=(j == 0))
+        o = F.layer_norm(o, (o.shape[-1],), sd["s_explainer_mlp.0.weight"], sd["s_explainer_mlp.0.bias"], 1e-5)
+        o = _lin(F.gelu(_lin(F.gelu(_lin(o, sd, "s_explainer_mlp.1")), sd, "s_explainer_mlp.3")), sd, "s_explainer_mlp.5")
+    else:
+        for j in range(cfg["explainer_s_attn_num_layers"]):
+            o = _bert_layer(o, mask_t, sd, f"s_attn_attention_layers.{j}", nh, eps, norm1_identity=(j == 0))
+        o = _lin(F.gelu(_lin(F.gelu(_lin(o, sd, "s_attn_explainer.0")), sd, "s_attn_explainer.2")), sd, "s_attn_explainer.4")
+    if cfg["explainer_normalize"]:
+        t = o.shape[1]
+        o = o + ((grand.unsqueeze(1) - null.reshape(1, 1, -1)) - o.sum(dim=1, keepdim=True)) / t
+    return o[:, 1:, :].permute(0, 2, 1)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import torch_port as otp
-from util import build_case
+from util import LTT_TAGS, build_case
 
 pytestmark = pytest.mark.gpu
 
@@ -132,3 +132,83 @@ def test_explainer_train_epoch_reduces_loss(cuda_device):
     for n, p in exp.named_parameters():
         if n.startswith("vit."):
             assert not p.requires_grad
+
+
+def _check_grads(module, sd, tol):
+    gscale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    checked = 0
+    for name, p in module.named_parameters():
+        ref = sd[name].grad
+        if not p.requires_grad:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert ref is not None and p.grad is not None, name
+        got = p.grad.cpu().numpy()
+        if float(ref.abs().max()) < 1e-5 * gscale:
+            assert float(np.abs(got).max()) < 1e-4 * gscale, name
+            continue
+        assert _rel(got, ref.numpy()) < tol, (name, _rel(got, ref.numpy()))
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_ltt_explainer_step_gradients_match_autograd(cuda_device, tag):
+    """LTT: only the ladder (maps + narrow side layers + side LN) and the side explainer head train; the backbone is
+    frozen (reference models/ltt_vit.py:132-138).  Gradients vs torch autograd on the CPU port, dropout off."""
+    from autognothi_amd import ops
+    from autognothi_amd.training import make_explainer_trainer
+    from autognothi_amd.utils import synth
+    c = build_case(tag)
+    dev, g, recipe, kind = cuda_device, c["g"], c["recipe"], c["meta"]["kind"]
+    prm = _zero_dropout(c["meta"])
+    cfg = recipe.t_config(**prm)
+    exp = recipe.t_explainer(cfg)
+    synth.load_synth_weights(exp, seed=1)
+    exp = exp.to(dev)
+    exp.train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    masks = torch.from_numpy(c["masks"])
+    bits = ops.pack_mask(masks.to(dev))
+    v0, vs, v1 = [torch.from_numpy(g[k]) for k in ("v_0", "v_s", "v_1")]
+    tr = make_explainer_trainer(recipe, exp)
+    loss, phi = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], train=True)
+    sd = {k: v.detach().cpu().clone().requires_grad_(exp.state_dict(keep_vars=True)[k].requires_grad)
+          for k, v in exp.state_dict(keep_vars=True).items()}
+    ones = torch.ones((c["B"], c["P"]), dtype=torch.long)
+    phi_ref = otp.ltt_explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
+    loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref, c["P"])
+    loss_ref.backward()
+    np.testing.assert_allclose(loss.cpu().numpy()[0], loss_ref.item(), rtol=2e-4)
+    np.testing.assert_allclose(phi.cpu().numpy(), phi_ref.detach().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(phi.cpu().numpy(), g["phi"], rtol=1e-3, atol=1e-4 * float(np.abs(g["phi"]).max()))
+    assert _check_grads(exp, sd, 2e-3) >= 20
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_ltt_surrogate_step_gradients_match_autograd(cuda_device, tag):
+    from autognothi_amd import ops
+    from autognothi_amd.training import make_surrogate_trainer
+    from autognothi_amd.utils import synth
+    c = build_case(tag)
+    dev, recipe, kind = cuda_device, c["recipe"], c["meta"]["kind"]
+    prm = _zero_dropout(c["meta"])
+    cfg = recipe.t_config(**prm)
+    srg = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(srg, seed=0)
+    srg = srg.to(dev).train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    masks = torch.from_numpy(c["masks"][:c["B"]])
+    bits = ops.pack_mask(masks.to(dev))
+    ncls = prm["num_labels"]
+    orig = torch.softmax(torch.from_numpy(np.random.default_rng(2).standard_normal((c["B"], ncls)).astype(np.float32)), -1)
+    tr = make_surrogate_trainer(recipe, srg)
+    loss, probs = tr.loss_and_grads(xs, bits, orig.to(dev), train=True)
+    sd = {k: v.detach().cpu().clone().requires_grad_(srg.state_dict(keep_vars=True)[k].requires_grad)
+          for k, v in srg.state_dict(keep_vars=True).items()}
+    p_ref = otp.ltt_surrogate_probs(torch.from_numpy(c["xs"]), masks, sd, prm, kind)
+    l_ref = torch.nn.functional.kl_div(torch.log_softmax(orig, -1), torch.softmax(p_ref, -1), reduction="batchmean")
+    l_ref.backward()
+    np.testing.assert_allclose(probs.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy()[0], l_ref.item(), rtol=1e-3, atol=1e-7)
+    assert _check_grads(srg, sd, 3e-3) >= 20
