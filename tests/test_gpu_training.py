@@ -212,3 +212,44 @@ def test_ltt_surrogate_step_gradients_match_autograd(cuda_device, tag):
     np.testing.assert_allclose(probs.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(loss.cpu().numpy()[0], l_ref.item(), rtol=1e-3, atol=1e-7)
     assert _check_grads(srg, sd, 3e-3) >= 20
+
+
+@pytest.mark.parametrize("tag", LTT_TAGS)
+def test_ltt_train_epochs_run_and_reduce_loss(cuda_device, tag):
+    """End-to-end on the LTT recipes: surrogate epochs (KL of the side head against the frozen backbone) and explainer
+    epochs (Shapley loss), dropout on, AdamW over the trainable (ladder + side head) parameters only."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import train_explainer as te
+    from autognothi_amd.scripts import train_surrogate as ts
+    c = build_case(tag)
+    dev, recipe, cfg = cuda_device, c["recipe"], c["cfg"]
+    engine.set_precision("fp32")
+    cls = recipe.t_classifier(cfg)
+    cls.load_state_dict(c["surrogate"].state_dict())
+    cls = cls.to(dev).eval()
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    gen = lambda a, b: (xs, torch.zeros(c["B"], dtype=torch.long, device=dev))  # noqa: E731
+    items = [(None, None)] * 3
+    srg.train()
+    trainable = [p for p in srg.parameters() if p.requires_grad]
+    assert 0 < len(trainable) < len(list(srg.parameters()))
+    opt_s = torch.optim.AdamW(trainable, lr=2e-3)
+    first = ts.surrogate_epoch_train(None, dev, c["P"], items, recipe, cls, srg, opt_s, 1, gen, seed=1)
+    for e in range(2, 6):
+        last = ts.surrogate_epoch_train(None, dev, c["P"], items, recipe, cls, srg, opt_s, e, gen, seed=1)
+    assert np.isfinite(first) and np.isfinite(last) and last < first
+    before = {n: p.detach().clone() for n, p in srg.named_parameters() if not p.requires_grad}
+    for n, p in srg.named_parameters():   # the frozen backbone did not move
+        if n in before:
+            assert torch.equal(p, before[n])
+    srg.eval()
+    v0 = torch.from_numpy(c["g"]["v_0"]).to(dev)
+    exp.train()
+    opt_e = torch.optim.AdamW([p for p in exp.parameters() if p.requires_grad], lr=1e-3)
+    first = te.explainer_epoch_train(None, dev, 4, c["P"], v0, items, recipe, srg, exp, opt_e, 1, gen, seed=1)
+    for e in range(2, 6):
+        last = te.explainer_epoch_train(None, dev, 4, c["P"], v0, items, recipe, srg, exp, opt_e, e, gen, seed=1)
+    assert np.isfinite(first) and last < first
+    ev = te.explainer_epoch_eval(None, dev, 4, c["P"], v0, items[:1], recipe, srg, exp, 1, gen, seed=3407)
+    assert np.isfinite(ev)
