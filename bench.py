@@ -55,9 +55,16 @@ WORKLOADS = {
                                        layer_norm_eps=1e-12, max_position_embeddings=128, num_attention_heads=12,
                                        num_hidden_layers=12, num_labels=2, pad_token_id=0, type_vocab_size=2, vocab_size=30522), 32),
 }
+# LTT (ladder side network): the shipped ladder width (96 = 12 heads of 8, 384 intermediate,
+# experiments/bert_base_tayp_ltt/.hparams.json) on the base backbones; fw_surrogate = frozen backbone + ladder 0
+_LTT = dict(explainer_s_attn_num_layers=1, explainer_s_head_hidden_size=3072, s_attn_hidden_size=96, s_attn_intermediate_size=384)
+WORKLOADS["ltt_vit_base"] = ("ltt_vit", dict({k: v for k, v in WORKLOADS["vit_base"][1].items() if not k.startswith("explainer_")},
+                                              explainer_normalize=True, **_LTT), 32)
+WORKLOADS["ltt_bert_base"] = ("ltt_bert", dict({k: v for k, v in WORKLOADS["bert_base"][1].items() if not k.startswith("explainer_")},
+                                                explainer_normalize=True, **_LTT), 32)
 
 EPI_NAMES = {0: "gemm<bias>", 1: "gemm<bias+gelu>", 2: "gemm<bias+residual>", 3: "gemm<bias,f32out>", 4: "gemm<bias+tanh>",
-             8: "masked_attention", 9: "layernorm"}
+             5: "gemm<bias+gelu+add>", 8: "masked_attention", 9: "layernorm"}
 
 
 def flops_per_forward(kind, p, T):
@@ -65,10 +72,13 @@ def flops_per_forward(kind, p, T):
     L*(8TH^2 + 4T^2H + 4THI) + embed + head."""
     H, I, Lr, C_ = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"], p["num_labels"]
     f = Lr * (8 * T * H * H + 4 * T * T * H + 4 * T * H * I)
-    if kind == "vanilla_vit":
+    if kind.endswith("vit"):
         f += 2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H + 2 * H * C_
     else:
         f += 2 * H * H + 2 * H * C_
+    if kind.startswith("ltt_"):   # one ladder: per backbone layer a map H->h and an h-wide layer; side head
+        h, i_s = p["s_attn_hidden_size"], p["s_attn_intermediate_size"]
+        f += Lr * (2 * T * H * h + 8 * T * h * h + 4 * T * T * h + 4 * T * h * i_s) + 2 * h * C_ + (0 if kind.endswith("vit") else 2 * h * h)
     return float(f)
 
 
@@ -77,10 +87,11 @@ def flops_executed(kind, p, T, K):
     last layer's Q-projection/attention/out-proj/MLP on the CLS token only."""
     H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
     f = flops_per_forward(kind, p, T)
-    shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind == "vanilla_vit" else 0)
+    shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind.endswith("vit") else 0)
     f -= shared * (K - 1) / K
-    # last layer: attention for 1 query instead of T, out-proj + MLP for 1 token instead of T (QKV still full)
-    f -= (4 * T * T * H + 2 * T * H * H + 4 * T * H * I) * (T - 1) / T
+    if not kind.startswith("ltt_"):   # (the ladder taps every token of every layer: nothing to skip there)
+        # last layer: attention for 1 query instead of T, out-proj + MLP for 1 token instead of T (QKV still full)
+        f -= (4 * T * T * H + 2 * T * H * H + 4 * T * H * I) * (T - 1) / T
     return float(f)
 
 
@@ -95,7 +106,12 @@ def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
     bounded sample of the same workload, the K masked copies materialised as the reference does
     (scripts/train_explainer.py:159-163)."""
     from oracle import torch_port as otp
-    fn = otp.vit_surrogate if kind == "vanilla_vit" else otp.bert_surrogate
+    if kind.startswith("ltt_"):
+        def fn(x, m, sd_, prm):
+            with torch.no_grad():
+                return otp.ltt_surrogate_probs(x, m, sd_, prm, "vit" if kind.endswith("vit") else "bert")
+    else:
+        fn = otp.vit_surrogate if kind == "vanilla_vit" else otp.bert_surrogate
     rows = masks_np.shape[0]
     xs_ext = torch.from_numpy(np.repeat(xs_np, rows // xs_np.shape[0], axis=0))
     masks = torch.from_numpy(masks_np)
@@ -161,7 +177,7 @@ def main():
     surrogate = recipe.t_surrogate(cfg)
     synth.load_synth_weights(surrogate, seed=0)   # random-init weights of the named architecture (no network)
     surrogate = surrogate.to(dev).eval()
-    if kind == "vanilla_vit":
+    if kind.endswith("vit"):
         xs_np = synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=rank)
     else:
         xs_np = synth.synth_token_ids(B, params["max_position_embeddings"], params["vocab_size"], seed=rank)
@@ -208,7 +224,7 @@ def main():
         final = recipe.t_final(cfg)
         synth.load_synth_weights(final, seed=1)
         final = final.to(dev).eval()
-        if kind == "vanilla_vit":
+        if kind.endswith("vit"):
             fx_np = synth.synth_images(args.attr_batch, params["img_px_size"], params["img_channels"], seed=100 + rank)
         else:
             fx_np = synth.synth_token_ids(args.attr_batch, params["max_position_embeddings"], params["vocab_size"], seed=100 + rank)
@@ -277,7 +293,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": {"vit_base": "vit_base_imagenette_vanilla", "vit_large": "vit_large_imagenette_vanilla",
-                                    "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128"}[args.workload],
+                                    "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128",
+                                    "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128"}[args.workload],
                        "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_step": R * world, "tokens": T,
                        "sharding": "rows by input, no data-path collective", "weights": "seeded random init"},
             "roofline": roofline,
