@@ -40,20 +40,30 @@ struct AttnArgs {
     char* ctx;        // [R, T, H]
     int R, T, H, heads, share, mode, Tw, Tp, nq;
     float pdrop; uint32_t seed;  // fp32 training forward only
+    const int* cu;    // packed (token-pruned) sequences: row r owns tokens [cu[r], cu[r+1]) of qkv / ctx, all visible; else null
 };
 
 template <int MODE>
 __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ldsK = smem;
-    char* ldsV = smem + p.Tp * ROWB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
     const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
-    const int src = row / p.share;
+    // fixed-length rows, or (p.cu) this row's packed token range: every packed token is a visible key
+    int T = p.T, Tp = p.Tp, nq = p.nq;
+    long tok_in = (long)(row / p.share) * p.T, tok_out = (long)row * p.T;
+    if (p.cu) {
+        const int t0 = p.cu[row];
+        T = p.cu[row + 1] - t0;
+        Tp = (T + 31) & ~31;
+        nq = p.nq < p.T ? p.nq : T;    // CLS-only (nq = 1) or every token of the row
+        tok_in = tok_out = t0;
+    }
+    char* ldsK = smem;
+    char* ldsV = smem + Tp * ROWB;
     const long rowstride = (long)3 * p.H * 2;  // bytes per token in qkv
-    const char* qbase = p.qkv + (long)src * p.T * rowstride + (long)head * HD * 2;
+    const char* qbase = p.qkv + tok_in * rowstride + (long)head * HD * 2;
     const char* kbase = qbase + (long)p.H * 2;
     const char* vbase = qbase + (long)2 * p.H * 2;
 
@@ -61,11 +71,11 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     // per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= T are clamped to row T-1 (finite
     // data; those keys get weight exactly 0 below), never out-of-bounds.
     {
-        const int npieces = p.Tp >> 3;
+        const int npieces = Tp >> 3;
         const int r_in = lane >> 3, slot = lane & 7;
         for (int pc = wave; pc < npieces; pc += nwaves) {
             const int r = pc * 8 + r_in;
-            const int rc = r < p.T ? r : p.T - 1;
+            const int rc = r < T ? r : T - 1;
             const long src = (long)rc * rowstride + ((slot ^ swz(r)) << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + src),
                                              (__attribute__((address_space(3))) void*)(ldsK + pc * 1024), 16, 0, 0);
@@ -76,12 +86,12 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nkb = p.Tp >> 5;           // 32-key blocks
-    const int nqb = (p.nq + 31) >> 5;    // 32-query blocks
+    const int nkb = Tp >> 5;             // 32-key blocks
+    const int nqb = (nq + 31) >> 5;      // 32-query blocks
     const int lr = lane & 31, lh = lane >> 5;
     // this row's mask words: lane w holds word w (Tw <= 16), fetched once; v_readlane per key block
     const uint32_t* mrow = p.mask + (long)row * p.Tw;
-    const uint32_t mwords = lane < p.Tw ? mrow[lane] : 0u;
+    const uint32_t mwords = p.cu ? 0xFFFFFFFFu : (lane < p.Tw ? mrow[lane] : 0u);
     // soft-max in base 2 on the raw scores: p = exp2(s*c - m*c), c = log2(e)/sqrt(64); the 1/sqrt(d) scale
     // (exact power of two) is order-preserving, so the running max is tracked on the raw scores.
     const float c2 = 0.125f * 1.4426950408889634f;
@@ -108,8 +118,8 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
 
     for (int qb = wave; qb < nqb; qb += nwaves) {
         int q = qb * 32 + lr;
-        const bool qvalid = q < p.nq;
-        const int qc = qvalid ? q : p.T - 1;
+        const bool qvalid = q < nq;
+        const int qc = qvalid ? q : T - 1;
         uint4 qf[4];  // Q fragments (B operand): lane holds Q[q][16ks + 8lh .. +8]
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
             // keys >= T (ragged last block only): -inf in both modes.
             const uint32_t mw = __builtin_amdgcn_readlane(mwords, kb);
             const uint32_t mwl = mw >> (4 * lh);
-            const int kvalid = p.T - kb * 32;
+            const int kvalid = T - kb * 32;
             float bmax = NEG_BIG;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
         }
         const float inv = 1.0f / l_tot;
         if (qvalid) {
-            char* out = p.ctx + ((long)row * p.T + q) * p.H * 2 + (long)head * HD * 2;
+            char* out = p.ctx + (tok_out + q) * p.H * 2 + (long)head * HD * 2;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 8 * g4 + 4 * lh;  // within a 32-wide d tile
@@ -231,15 +241,22 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) float sV[FKT * D];
     const int tid = threadIdx.x;
     const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
-    const int src = row / p.share;
+    int Tn = p.T, nq = p.nq;
+    long tok_in = (long)(row / p.share) * p.T, tok_out = (long)row * p.T;
+    if (p.cu) {   // packed (token-pruned) rows: every packed token is a visible key
+        const int t0 = p.cu[row];
+        Tn = p.cu[row + 1] - t0;
+        nq = p.nq < p.T ? p.nq : Tn;
+        tok_in = tok_out = t0;
+    }
     const long ts = (long)3 * p.H;  // elements per token
-    const T* base = reinterpret_cast<const T*>(p.qkv) + (long)src * p.T * ts + (long)head * D;
+    const T* base = reinterpret_cast<const T*>(p.qkv) + tok_in * ts + (long)head * D;
     const uint32_t* mrow = p.mask + (long)row * p.Tw;
     const float inv_sqrt_d = 1.0f / sqrtf((float)D);
 
-    for (int q0 = 0; q0 < p.nq; q0 += blockDim.x) {
+    for (int q0 = 0; q0 < nq; q0 += blockDim.x) {
         const int q = q0 + tid;
-        const bool qvalid = q < p.nq;
+        const bool qvalid = q < nq;
         float qv[D], o[D];
         const T* qp = base + (long)(qvalid ? q : 0) * ts;
 #pragma unroll
@@ -249,12 +266,12 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
             o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
         }
         float m_run = NEG_BIG, l_run = 0.f;
-        for (int k0 = 0; k0 < p.T; k0 += FKT) {
+        for (int k0 = 0; k0 < Tn; k0 += FKT) {
             __syncthreads();
             for (int c = tid; c < FKT * (D / 4); c += blockDim.x) {
                 const int r = c / (D / 4), ch = c % (D / 4);
                 float4 kv = make_float4(0, 0, 0, 0), vv = kv;
-                if (k0 + r < p.T) {
+                if (k0 + r < Tn) {
                     kv = load4_as_f32(base + (long)(k0 + r) * ts + p.H + ch * 4);
                     vv = load4_as_f32(base + (long)(k0 + r) * ts + 2 * p.H + ch * 4);
                 }
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
                 *reinterpret_cast<float4*>(sV + r * D + ch * 4) = vv;
             }
             __syncthreads();
-            const int kn = min(FKT, p.T - k0);
+            const int kn = min(FKT, Tn - k0);
             for (int kk = 0; kk < kn; ++kk) {
                 float s = 0.f;
 #pragma unroll
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
                 }
                 s = s * inv_sqrt_d;
                 const int key = k0 + kk;
-                const bool on = (mrow[key >> 5] >> (key & 31)) & 1u;
+                const bool on = p.cu ? true : ((mrow[key >> 5] >> (key & 31)) & 1u);
                 if (p.mode == AG_MASK_VIT_MUL) s = on ? s : 0.f;
                 else if (!on) continue;  // exactly zero weight
                 const float m_new = fmaxf(m_run, s);
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(AttnArgs p) {
         }
         if (qvalid) {
             const float inv = 1.0f / l_run;
-            T* out = reinterpret_cast<T*>(p.ctx) + ((long)row * p.T + q) * p.H + (long)head * D;
+            T* out = reinterpret_cast<T*>(p.ctx) + (tok_out + q) * p.H + (long)head * D;
 #pragma unroll
             for (int d = 0; d < D; d += 4) {
                 if (sizeof(T) == 4)
@@ -318,6 +335,34 @@ int launch_valu(const AttnArgs& a, int head_dim, hipStream_t s) {
     return AG_OK;
 }
 
+// dispatch shared by the fixed-length and the packed (varlen) entry points
+int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream_t s) {
+    if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "masked attention: bad dtype %d", dtype);
+    if (dtype == AG_BF16 && hd == HD) {
+        const size_t lds = (size_t)2 * a.Tp * ROWB;
+        AG_REQUIRE(lds <= 160 * 1024, "masked attention: T=%d too long for the single-pass LDS image", a.T);
+        const int nqb = (a.nq + 31) / 32;
+        int nwaves = nqb < 8 ? nqb : 8;
+        if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_VIT_MUL>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_BERT_ADD>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_VIT_MUL>, dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
+        else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
+    } else if (dtype == AG_F32) {
+        return launch_valu<float>(a, hd, s);
+    } else {
+        return launch_valu<bf16_t>(a, hd, s);   // narrow heads in bf16 storage
+    }
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 }  // namespace
 
 extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
@@ -333,35 +378,34 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = qkv_share; a.mode = mask_mode;
     a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32;
     a.nq = (n_query > 0 && n_query < T) ? n_query : T;
-    a.pdrop = 0.f; a.seed = 0;
+    a.pdrop = 0.f; a.seed = 0; a.cu = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == AG_BF16 ? 2.0 : 4.0;
     AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)a.nq * T * H,
                      ((double)(R / qkv_share) * T * 3 * H + (double)R * a.nq * H) * es, s);
-    if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_masked_attention: bad dtype %d", dtype);
-    if (dtype == AG_BF16 && hd == HD) {
-        const size_t lds = (size_t)2 * a.Tp * ROWB;
-        AG_REQUIRE(lds <= 160 * 1024, "ag_masked_attention: T=%d too long for the single-pass LDS image", T);
-        const int nqb = (a.nq + 31) / 32;
-        int nwaves = nqb < 8 ? nqb : 8;
-        if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_VIT_MUL>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_BERT_ADD>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
-        }
-        if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_VIT_MUL>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
-        else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(R * heads), dim3(nwaves * 64), lds, s, a);
-    } else if (dtype == AG_F32) {
-        return launch_valu<float>(a, hd, s);
-    } else {
-        return launch_valu<bf16_t>(a, hd, s);   // narrow heads in bf16 storage
-    }
-    AG_LAUNCH_CHECK();
-    return AG_OK;
+    return run_attention(a, dtype, hd, mask_mode, s);
+}
+
+/* Packed (token-pruned) sequences: row r owns tokens [cu[r], cu[r+1]) of qkv [N,3H] / ctx [N,H]; every packed token
+ * is a visible key (BERT: an additively masked key has exactly zero weight, so it is simply absent).  cls_only: only
+ * the first token of each row is a query.  t_max bounds the row lengths (sizes the LDS image). */
+extern "C" int ag_masked_attention_varlen(const void* d_qkv, const int* d_cu_seqlens, void* d_ctx, int R, int t_max, int H,
+                                          int heads, int cls_only, int dtype, void* stream) {
+    AG_REQUIRE(d_qkv && d_cu_seqlens && d_ctx, "ag_masked_attention_varlen: null pointer");
+    AG_REQUIRE(R >= 0 && t_max > 0 && heads > 0 && H % heads == 0, "ag_masked_attention_varlen: bad shape");
+    if (R == 0) return AG_OK;
+    AttnArgs a;
+    a.qkv = (const char*)d_qkv; a.mask = nullptr; a.ctx = (char*)d_ctx;
+    a.R = R; a.T = t_max; a.H = H; a.heads = heads; a.share = 1; a.mode = AG_MASK_BERT_ADD;
+    a.Tw = (t_max + 31) / 32; a.Tp = a.Tw * 32;
+    a.nq = cls_only ? 1 : t_max;
+    a.pdrop = 0.f; a.seed = 0; a.cu = d_cu_seqlens;
+    hipStream_t s = (hipStream_t)stream;
+    const double es = dtype == AG_BF16 ? 2.0 : 4.0;
+    // work is data dependent: account the dense bound scaled by 1/4 (half the keys x half the queries on Shapley masks)
+    AgProfScope prof(AG_PROF_ATTENTION, (cls_only ? 2.0 : 1.0) * R * (double)a.nq * t_max * H,
+                     ((double)R * t_max * 3 * H * 0.5 + (double)R * a.nq * H * (cls_only ? 1.0 : 0.5)) * es, s);
+    return run_attention(a, dtype, H / heads, AG_MASK_BERT_ADD, s);
 }
 
 extern "C" int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H,
@@ -372,6 +416,6 @@ extern "C" int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_m
     AttnArgs a;
     a.qkv = (const char*)d_qkv; a.mask = d_mask_bits; a.ctx = (char*)d_ctx;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = 1; a.mode = mask_mode;
-    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed;
+    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed; a.cu = nullptr;
     return launch_valu<float>(a, H / heads, (hipStream_t)stream);
 }

@@ -196,6 +196,58 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
     for (int c = lane; c < C; c += 64) y[(int64_t)row * C + c] = expf(x[(int64_t)row * C + c] - m) / s;
 }
 
+// ---- token pruning (BERT additive mask): pack the visible tokens of every row ---------------------------------
+// counts[r] = popcount(mask row r) (CLS bit included); cu = exclusive scan (cu[R] = total); one workgroup.
+__global__ __launch_bounds__(1024) void seq_scan_kernel(const uint32_t* __restrict__ mask, int R, int Tw, int T, int* __restrict__ cu) {
+    __shared__ int part[1024];
+    const uint32_t last = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;   // bits at or beyond T do not count
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = (R + nt - 1) / nt;
+    const int r0 = tid * per, r1 = min(R, r0 + per);
+    int sum = 0;
+    for (int r = r0; r < r1; ++r)
+        for (int w = 0; w < Tw; ++w) sum += __popc(mask[(long)r * Tw + w] & (w == Tw - 1 ? last : 0xFFFFFFFFu));
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {   // Hillis-Steele inclusive scan of the per-thread sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int r = r0; r < r1; ++r) {
+        cu[r] = run;
+        for (int w = 0; w < Tw; ++w) run += __popc(mask[(long)r * Tw + w] & (w == Tw - 1 ? last : 0xFFFFFFFFu));
+    }
+    if (tid == nt - 1) cu[R] = part[nt - 1];
+}
+// tok_src[cu[r] + rank(t)] = r*T + t for every visible token t of row r; one wave per row
+__global__ __launch_bounds__(256) void seq_index_kernel(const uint32_t* __restrict__ mask, int R, int T, int Tw,
+                                                        const int* __restrict__ cu, int* __restrict__ tok_src) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    int base = cu[row];
+    for (int w0 = 0; w0 < Tw; w0 += 2) {           // 64 tokens per step: lane = token
+        const int t = w0 * 32 + lane;
+        const uint32_t word = (w0 + (lane >> 5)) < Tw ? mask[(long)row * Tw + w0 + (lane >> 5)] : 0u;
+        const bool on = t < T && ((word >> (lane & 31)) & 1u);
+        const unsigned long long ball = __ballot(on);
+        if (on) tok_src[base + __popcll(ball & ((1ull << lane) - 1ull))] = row * T + t;
+        base += __popcll(ball);
+    }
+}
+// dst[i, :] = src[idx[i], :]  (rows of H elements of `es` bytes, 16-byte vectors)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, long ld_src_b, const int* __restrict__ idx,
+                                                          char* __restrict__ dst, long ld_dst_b, int n, int row_bytes) {
+    const int vec = row_bytes >> 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * vec; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / vec), v = (int)(i % vec);
+        *reinterpret_cast<uint4*>(dst + (long)r * ld_dst_b + v * 16) =
+            *reinterpret_cast<const uint4*>(src + (long)idx[r] * ld_src_b + v * 16);
+    }
+}
+
 }  // namespace
 
 extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream) {
@@ -284,6 +336,32 @@ extern "C" int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, 
     AG_REQUIRE(d_x && d_stats && rows >= 0 && H % 4 == 0 && ldx % 4 == 0, "ag_row_stats_bf16: bad arguments");
     if (rows == 0) return AG_OK;
     hipLaunchKernelGGL(row_stats_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_x, ldx, rows, H, d_stats);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_seq_compact_plan(const uint32_t* d_mask_bits, int R, int T, int* d_cu_seqlens, int* d_tok_src, void* stream) {
+    AG_REQUIRE(d_mask_bits && d_cu_seqlens && d_tok_src && R >= 1 && T >= 1, "ag_seq_compact_plan: bad arguments");
+    const int Tw = (T + 31) / 32;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, s, d_mask_bits, R, Tw, T, d_cu_seqlens);
+    AG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seq_index_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, s, d_mask_bits, R, T, Tw, d_cu_seqlens, d_tok_src);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_index, void* d_dst, int64_t ld_dst, int n, int H,
+                              int dtype, void* stream) {
+    AG_REQUIRE(d_src && d_index && d_dst && n >= 0 && H >= 1, "ag_gather_rows: bad arguments");
+    AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gather_rows: bad dtype %d", dtype);
+    const size_t es = dtype_size(dtype);
+    AG_REQUIRE((H * es) % 16 == 0 && (ld_src * es) % 16 == 0 && (ld_dst * es) % 16 == 0, "ag_gather_rows: rows must be 16-byte multiples");
+    if (n == 0) return AG_OK;
+    const long total = (long)n * ((H * es) >> 4);
+    const int grid = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)d_src, (long)(ld_src * es), d_index,
+                       (char*)d_dst, (long)(ld_dst * es), n, (int)(H * es));
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

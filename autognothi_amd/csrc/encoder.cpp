@@ -26,6 +26,7 @@ struct Ws {
     char* ha;      // [M, H]   BERT: post-attention LayerNorm output
     float* st1;    // [M, 2]   (sum, sumsq) of the rows entering LN1 (folded into the QKV GEMM)
     float* st2;    // [M, 2]   same for LN2 (folded into fc1)
+    int* idx;      // [R+1 + M] token pruning plan
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -43,6 +44,8 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * es) : nullptr;
     char* st1 = take(M * 2 * sizeof(float));
     char* st2 = take(M * 2 * sizeof(float));
+    char* idx = take((M + (size_t)R + 1) * sizeof(int));   // token pruning: cu_seqlens [R+1] + packed-row sources [M]
+    if (ws) ws->idx = (int*)idx;
     if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; ws->st1 = (float*)st1; ws->st2 = (float*)st2; }
     return off;
 }
@@ -155,6 +158,85 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
         }
         h_in = (const char*)d_h;
         in_share = 1;
+    }
+    return AG_OK;
+}
+
+
+// ---- BERT with token pruning ----------------------------------------------------------------------------------
+// reference models/vanilla_bert.py:523: scores + (1 - mask) * finfo.min  =>  a masked key's soft-max weight is exactly
+// 0 in every layer and every head.  The classifier reads the CLS row only (models/vanilla_bert.py:73-76), CLS is never
+// masked, so the hidden states of masked tokens are never read by anything that reaches the output: they are dead
+// rows.  Layer 0 still runs on all tokens (its LN/QKV are shared by the K masks of an input); after it the visible
+// tokens of every row are packed (cu_seqlens) and layers 1.. run on the packed rows with a mask-free varlen
+// attention; the last layer's out-projection / MLP run on the CLS rows only.  On Shapley-kernel masks half the
+// players are off on average: half the GEMM rows, a quarter of the attention.
+// Output contract = ag_encoder_forward(cls_only_last = 1): d_h [R,T,H] with token 0 of every row defined.
+// One 4-byte device->host read (the packed row count) sizes the launches: this entry synchronises the stream once.
+extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const void* d_h0, int R, int share,
+                                              const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
+                                              int* packed_rows_out, void* stream) {
+    AG_REQUIRE(d && d_h0 && d_mask_bits && d_h && d_workspace, "ag_bert_encoder_forward_pruned: null pointer");
+    AG_REQUIRE(d->kind == AG_MASK_BERT_ADD, "ag_bert_encoder_forward_pruned: only the additive (BERT) mask prunes exactly");
+    AG_REQUIRE(d->n_layers >= 1 && d->layers, "ag_bert_encoder_forward_pruned: no layers");
+    if (d->n_layers == 1) {
+        if (packed_rows_out) *packed_rows_out = R * d->T;
+        return ag_encoder_forward(d, d_h0, R, share, d_mask_bits, d_h, 1, d_workspace, workspace_bytes, stream);
+    }
+    AG_REQUIRE(workspace_bytes >= ag_encoder_workspace_bytes(d, R), "ag_bert_encoder_forward_pruned: workspace too small");
+    Ws ws;
+    carve(d, R, (char*)d_workspace, &ws);
+    const int T = d->T, H = d->H, I = d->I, dt = d->dtype;
+    const size_t es = dtype_size(dt);
+    hipStream_t hs = (hipStream_t)stream;
+    // layer 0 on every token (shared LN/QKV), full output into d_h
+    ag_encoder_desc d0 = *d;
+    d0.n_layers = 1;
+    TRY(ag_encoder_forward(&d0, d_h0, R, share, d_mask_bits, d_h, 0, d_workspace, workspace_bytes, stream));
+    // plan + pack
+    int* cu = ws.idx;
+    int* tok_src = ws.idx + R + 1;
+    TRY(ag_seq_compact_plan(d_mask_bits, R, T, cu, tok_src, stream));
+    int N = 0;
+    AG_HIP_CHECK(hipMemcpyAsync(&N, cu + R, sizeof(int), hipMemcpyDeviceToHost, hs));
+    AG_HIP_CHECK(hipStreamSynchronize(hs));
+    AG_REQUIRE(N >= R && N <= R * T, "ag_bert_encoder_forward_pruned: packed row count %d out of range (CLS bit missing from a mask row?)", N);
+    if (packed_rows_out) *packed_rows_out = N;
+    char* x = ws.xs;                       // packed stream entering the layer
+    TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, stream));
+    char* xn = (char*)d_h;                 // d_h is free again (only token 0 of each row is defined at exit): ping-pong
+    for (int l = 1; l < d->n_layers; ++l) {
+        const ag_layer_weights& w = d->layers[l];
+        const bool last = l == d->n_layers - 1;
+        AG_REQUIRE(w.ln2_g, "ag_bert_encoder_forward_pruned: BERT output.LayerNorm missing in layer %d", l);
+        TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_masked_attention_varlen(ws.qkv, cu, ws.ctx, R, T, H, d->heads, last ? 1 : 0, dt, stream));
+        const char* ctx = ws.ctx;
+        const char* res = x;
+        int Mo = N;
+        if (last) {   // CLS rows only: compact [R,H] copies of the attention output and of the residual
+            TRY(ag_gather_rows(ws.ctx, H, cu, ws.inter, H, R, H, dt, stream));
+            TRY(ag_gather_rows(x, H, cu, ws.inter + (size_t)R * H * es, H, R, H, dt, stream));
+            ctx = ws.inter; res = ws.inter + (size_t)R * H * es; Mo = R;
+        }
+        TRY(ag_gemm(ctx, H, w.w_o, w.b_o, ws.hx, H, res, H, 1, 1, Mo, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        const char* a = ws.hx;
+        if (w.ln1_g) {
+            TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+            a = ws.ha;
+        }
+        char* inter = last ? ws.qkv : ws.inter;   // (last: ws.inter holds the gathered CLS rows)
+        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        char* pre = (a == ws.hx) ? ws.ha : ws.hx;
+        TRY(ag_gemm(inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        if (last) {
+            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
+            hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R, hipMemcpyDeviceToDevice, hs);
+            if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
+        } else {
+            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, xn, nullptr, dt, stream));
+            char* t = x; x = xn; xn = t;
+        }
     }
     return AG_OK;
 }

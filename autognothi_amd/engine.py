@@ -16,6 +16,8 @@ from . import _lib as L
 from . import ops
 
 _PRECISION = {"dtype": L.AG_BF16}
+PRUNE_BERT_TOKENS = os.environ.get("AG_BERT_PRUNE", "1") != "0"  # BERT cls-only forwards skip additively masked tokens after layer 0
+LAST_PACKED_ROWS = 0   # visible tokens of the last pruned forward (bench.py: executed-work accounting)
 FOLD_LAYERNORM = os.environ.get("AG_LN_FOLD", "1") != "0"  # bf16 ViT: fold LayerNorm into the consuming GEMM epilogue
 
 
@@ -172,6 +174,13 @@ class PackedEncoder:
         with torch.cuda.device(h0.device):
             need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
             ws = WORKSPACE.get(h0.device, need)
+            if self.kind == L.AG_MASK_BERT_ADD and cls_only_last and len(self.layers) >= 2 and PRUNE_BERT_TOKENS:
+                global LAST_PACKED_ROWS
+                n_packed = C.c_int32(0)
+                L.check(L.lib().ag_bert_encoder_forward_pruned(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
+                                                               L.ptr(ws), ws.numel(), C.byref(n_packed), L.stream()))
+                LAST_PACKED_ROWS = int(n_packed.value)
+                return out
             L.check(L.lib().ag_encoder_forward(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
                                                1 if cls_only_last else 0, L.ptr(ws), ws.numel(), L.stream()))
         return out

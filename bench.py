@@ -82,10 +82,18 @@ def flops_per_forward(kind, p, T):
     return float(f)
 
 
-def flops_executed(kind, p, T, K):
+def flops_executed(kind, p, T, K, frac=1.0):
     """F_exec: F_ref minus work legitimately skipped per row: embed + layer-0 QKV shared across the K masks,
-    last layer's Q-projection/attention/out-proj/MLP on the CLS token only."""
+    last layer's Q-projection/attention/out-proj/MLP on the CLS token only; BERT token pruning (frac = visible
+    tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
     H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
+    if kind == "vanilla_bert" and frac < 1.0 and Lr >= 2:
+        layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
+        f = layer - 6 * T * H * H * (K - 1) / K                                   # layer 0: every token, shared QKV
+        f += (Lr - 2) * (frac * (8 * T * H * H + 4 * T * H * I) + frac * frac * 4 * T * T * H)
+        f += frac * 6 * T * H * H + 4 * frac * T * H + 2 * H * H + 4 * H * I     # last: QKV packed, the rest CLS only
+        f += 2 * H * H + 2 * H * p["num_labels"]
+        return float(f)
     f = flops_per_forward(kind, p, T)
     shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind.endswith("vit") else 0)
     f -= shared * (K - 1) / K
@@ -253,7 +261,8 @@ def main():
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
-        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K)
+        frac = engine.LAST_PACKED_ROWS / float(R * T) if (kind == "vanilla_bert" and engine.LAST_PACKED_ROWS) else 1.0
+        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         # dominant kernel = the instrumented class with the largest total time
         dom = max(stats, key=lambda c: stats[c][0])
@@ -296,7 +305,8 @@ def main():
                                     "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128",
                                     "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128"}[args.workload],
                        "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_step": R * world, "tokens": T,
-                       "sharding": "rows by input, no data-path collective", "weights": "seeded random init"},
+                       "sharding": "rows by input, no data-path collective", "weights": "seeded random init",
+                       "visible_token_fraction_after_layer0": round(frac, 4)},
             "roofline": roofline,
         }
         if attrs_per_s is not None:

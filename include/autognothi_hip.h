@@ -253,6 +253,26 @@ int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, con
 int ag_profile_enable(int on);
 int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * BERT token pruning.  reference models/vanilla_bert.py:523 adds (1 - mask) * finfo.min to the scores, so a masked
+ * key's soft-max weight is exactly 0 in every layer; the heads read the CLS row only (:73-76) and CLS is never
+ * masked: hidden states of masked tokens are dead rows.  ag_bert_encoder_forward_pruned = ag_encoder_forward(...,
+ * cls_only_last = 1) for the BERT kind, computing layer 0 on every token (its LN/QKV are shared by the K masks) and
+ * layers 1.. on the packed visible tokens only (mask-free varlen attention).  Same output contract (token 0 of
+ * every row of d_h [R,T,H]); *packed_rows_out (optional, host) receives the number of visible tokens.  Reads one
+ * int back from the device: synchronises the stream once.
+ * Building blocks: ag_seq_compact_plan (cu_seqlens [R+1] by popcount + scan, packed-row -> source-row table [<= R*T]),
+ * ag_gather_rows (dst[i,:] = src[index[i],:]), ag_masked_attention_varlen (rows = token ranges of cu_seqlens).
+ * ---------------------------------------------------------------------------------------------- */
+int ag_seq_compact_plan(const uint32_t* d_mask_bits, int R, int T, int* d_cu_seqlens, int* d_tok_src, void* stream);
+int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_index, void* d_dst, int64_t ld_dst, int n, int H,
+                   int dtype, void* stream);
+int ag_masked_attention_varlen(const void* d_qkv, const int* d_cu_seqlens, void* d_ctx, int R, int t_max, int H,
+                               int heads, int cls_only, int dtype, void* stream);
+int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
+                                   const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
+                                   int* packed_rows_out, void* stream);
+
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
  * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per
  * wave — the power-capped MFMA ceiling — and the effective shader clock during it (s_memtime ticks against

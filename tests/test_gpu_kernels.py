@@ -251,3 +251,49 @@ def test_gemm_layernorm_fold(cuda_device):
     # the folded path is refused where it is not implemented (small / fp32 GEMMs) instead of silently ignored
     with pytest.raises(RuntimeError, match="folding"):
         ops.gemm(X[:64], wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=stats[:64], ln_colsum=colsum)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("t,heads,rows,cls_only", [(128, 2, 6, 0), (128, 12, 5, 1), (65, 1, 4, 0)])
+def test_token_pruning_blocks(cuda_device, dtype, t, heads, rows, cls_only):
+    """BERT token pruning: compaction plan (popcount scan + source table), row gather, mask-free varlen attention ==
+    additive-mask attention of the visible tokens (reference models/vanilla_bert.py:523: masked keys get weight 0)."""
+    import ctypes as C
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    h, d = heads * 64, 64
+    g = np.random.default_rng(t + heads)
+    mask = g.integers(0, 2, size=(rows, t - 1), dtype=np.int64)
+    mask[0] = 0
+    mask[-1] = 1
+    bits = ops.pack_mask(torch.from_numpy(mask).to(dev))
+    cu = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(rows * t, dtype=torch.int32, device=dev)
+    L.check(L.lib().ag_seq_compact_plan(L.ptr(bits), rows, t, L.ptr(cu), L.ptr(src), L.stream()))
+    full = otr.prepend_cls(mask)
+    counts = full.sum(1)
+    want_cu = np.concatenate([[0], np.cumsum(counts)])
+    np.testing.assert_array_equal(cu.cpu().numpy(), want_cu)
+    n = int(want_cu[-1])
+    want_src = np.concatenate([r * t + np.nonzero(full[r])[0] for r in range(rows)])
+    np.testing.assert_array_equal(src.cpu().numpy()[:n], want_src)
+    # gather the visible tokens of a [rows, t, 3h] qkv
+    qkv = g.standard_normal((rows, t, 3 * h)).astype(np.float32)
+    if dtype == BF16:
+        qkv = _bf16_round(qkv)
+    QKV = _to_store(qkv, dtype, dev)
+    packed = torch.empty((n, 3 * h), dtype=QKV.dtype, device=dev)
+    L.check(L.lib().ag_gather_rows(L.ptr(QKV), 3 * h, L.ptr(src), L.ptr(packed), 3 * h, n, 3 * h, dtype, L.stream()))
+    np.testing.assert_array_equal(packed.float().cpu().numpy(), qkv.reshape(rows * t, 3 * h)[want_src])
+    ctx = torch.zeros((n, h), dtype=QKV.dtype, device=dev)
+    L.check(L.lib().ag_masked_attention_varlen(L.ptr(packed), L.ptr(cu), L.ptr(ctx), rows, t, h, heads, cls_only, dtype, L.stream()))
+    got = ctx.float().cpu().numpy()
+    # oracle: additive-mask attention on the unpacked rows, compared on the visible tokens
+    q, k, v = qkv[..., :h], qkv[..., h:2 * h], qkv[..., 2 * h:]
+    hd = lambda x: x.reshape(rows, t, heads, d).transpose(0, 2, 1, 3)  # noqa: E731
+    s = (hd(q) @ hd(k).transpose(0, 1, 3, 2)) / np.float32(8.0)
+    m = full.astype(np.float32)[:, None, None, :]
+    ref = (otr.softmax(s + (1 - m) * otr.F32_MIN) @ hd(v)).transpose(0, 2, 1, 3).reshape(rows * t, h)[want_src]
+    tol = dict(rtol=1e-4, atol=2e-5) if dtype == F32 else dict(rtol=2e-2, atol=2e-2)
+    sel = want_cu[:-1] if cls_only else np.arange(n)
+    np.testing.assert_allclose(got[sel], ref[sel], **tol)
