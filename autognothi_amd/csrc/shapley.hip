@@ -143,6 +143,39 @@ __global__ __launch_bounds__(256) void kl_kernel(const float* __restrict__ ref, 
     }
 }
 
+// ---- Monte-Carlo permutation Shapley reduction (reference scripts/preview_text_shapley.py:112-132, :135-153) ----
+// v [reps, P+1, C]: surrogate outputs along each permutation's nested-mask chain (row i = the first i players of the
+// permutation visible).  value f = log(p / (1 - p + 1e-6)) with p = softmax over classes of the (already soft-maxed)
+// outputs — the reference's "sharpening", quirk included.  Player q sits at position rank[r][q] of permutation r, so
+// its marginal contribution there is f(v[r, rank+1]) - f(v[r, rank]); sv[c, q] = mean over r.  Thread per (q, c):
+// no atomics, deterministic.
+__device__ __forceinline__ float mc_value(const float* __restrict__ row, int C, int c) {
+    float m = -3.0e38f;
+    for (int k = 0; k < C; ++k) m = fmaxf(m, row[k]);
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s += expf(row[k] - m);
+    const float p = expf(row[c] - m) / s;
+    return logf(p / (1.0f - p + 1e-6f));
+}
+__global__ void mc_shapley_kernel(const float* __restrict__ v, const int* __restrict__ rank, int reps, int P, int C,
+                                  float* __restrict__ sv, float* __restrict__ v0, float* __restrict__ vn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {   // the cached end points: of the LAST permutation, as the reference returns them (:128-129)
+        const float* last = v + (long)(reps - 1) * (P + 1) * C;
+        v0[i] = mc_value(last, C, i);
+        vn[i] = mc_value(last + (long)P * C, C, i);
+    }
+    if (i >= P * C) return;
+    const int q = i / C, c = i % C;
+    float acc = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        const int j = rank[(long)r * P + q];
+        const float* base = v + ((long)r * (P + 1) + j) * C;
+        acc += mc_value(base + C, C, c) - mc_value(base, C, c);
+    }
+    sv[(long)c * P + q] = acc / (float)reps;
+}
+
 }  // namespace
 
 extern "C" int ag_shapley_normalize(const float* d_pred, const float* d_grand, const float* d_null, int B, int T, int C,
@@ -185,6 +218,15 @@ extern "C" int ag_shapley_loss(const uint32_t* d_mask_bits, const float* d_v0, c
 extern "C" int ag_kl_loss(const float* d_ref, const float* d_cur, int B, int C, float* d_loss, float* d_dcur, void* stream) {
     AG_REQUIRE(d_ref && d_cur && d_loss && B >= 1 && C >= 1, "ag_kl_loss: bad arguments");
     hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_ref, d_cur, B, C, d_loss, d_dcur);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_mc_shapley_reduce(const float* d_v, const int* d_rank, int reps, int P, int C, float* d_sv, float* d_v0,
+                                    float* d_vn, void* stream) {
+    AG_REQUIRE(d_v && d_rank && d_sv && d_v0 && d_vn && reps >= 1 && P >= 1 && C >= 1, "ag_mc_shapley_reduce: bad arguments");
+    const int n = P * C > C ? P * C : C;
+    hipLaunchKernelGGL(mc_shapley_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, d_v, d_rank, reps, P, C, d_sv, d_v0, d_vn);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

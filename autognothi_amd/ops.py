@@ -286,6 +286,19 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
     return loss, d
 
 
+def mc_shapley_reduce(v: Tensor, rank: Tensor):
+    """scripts/preview_text_shapley.py:112-153: v [reps, P+1, C] fp32, rank [reps, P] int32 -> (sv [C,P], v0 [C], vn [C])."""
+    L.require_gpu(v, rank)
+    v, rank = v.contiguous().float(), rank.contiguous().to(torch.int32)
+    reps, p1, c = v.shape
+    sv = torch.empty((c, p1 - 1), dtype=torch.float32, device=v.device)
+    v0 = torch.empty(c, dtype=torch.float32, device=v.device)
+    vn = torch.empty(c, dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        L.check(L.lib().ag_mc_shapley_reduce(L.ptr(v), L.ptr(rank), reps, p1 - 1, c, L.ptr(sv), L.ptr(v0), L.ptr(vn), L.stream()))
+    return sv, v0, vn
+
+
 # ----------------------------------------------------------------------------- training building blocks (fp32)
 def _f32c(t: Tensor) -> Tensor:
     L.require_gpu(t)

@@ -163,6 +163,13 @@ int ag_shapley_loss(const uint32_t* d_mask_bits, const float* d_v0, const float*
  * loss (1 float) and optional d loss / d current [B,C]. */
 int ag_kl_loss(const float* d_ref, const float* d_cur, int B, int C, float* d_loss, float* d_dcur, void* stream);
 
+/* Monte-Carlo permutation Shapley (reference scripts/preview_text_shapley.py:62-153): v [reps, P+1, C] fp32 = surrogate
+ * outputs along each permutation's nested-mask chain, rank [reps, P] int32 = position of each player in its
+ * permutation -> sv [C, P] (mean marginal contribution of the sharpened value log(p/(1-p+1e-6)), p = softmax(v)),
+ * v0 / vn [C] = that value at the empty / full coalition of the last permutation (as the reference returns them). */
+int ag_mc_shapley_reduce(const float* d_v, const int* d_rank, int reps, int P, int C, float* d_sv, float* d_v0,
+                         float* d_vn, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole masked forward: the composite the recipes' fw_surrogate / fw_classifier / fw_explainer call.
  * ---------------------------------------------------------------------------------------------- */

@@ -130,3 +130,26 @@ def auc(values: np.ndarray) -> float:
     """reference scripts/measure_faithfulness.py:143-146."""
     v = np.asarray(values, dtype=np.float64)
     return float(((v[1:] + v[:-1]) / 2).mean())
+
+
+def mc_permutation_shapley(probs_fn, perms: np.ndarray):
+    """reference scripts/preview_text_shapley.py:62-153 restated.  probs_fn(masks [n, P] int64) -> surrogate outputs
+    [n, C]; perms [reps, P].  -> (sv [C, P], v0 [C], vn [C])."""
+    reps, p = perms.shape
+    sv = None
+    v0 = vn = None
+    for r in range(reps):
+        perm = perms[r]
+        masks = np.zeros((p + 1, p), dtype=np.int64)
+        for i in range(p + 1):
+            masks[i, perm[:i]] = 1                                     # :87-90
+        classes = np.asarray(probs_fn(masks), dtype=np.float32)
+        e = np.exp(classes - classes.max(axis=1, keepdims=True))
+        pr = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)      # :146  softmax of the (already soft-maxed) outputs
+        vs = np.log(pr / (np.float32(1.0) - pr + np.float32(1e-6)))     # :148
+        d_p = vs[1:] - vs[:-1]                                          # :118
+        d = np.zeros_like(d_p)
+        d[perm] = d_p                                                   # :122-123
+        sv = d if sv is None else sv + d
+        v0, vn = vs[0], vs[-1]                                          # :127-128
+    return (sv.T.reshape(classes.shape[1], -1) / reps).astype(np.float32), v0, vn

@@ -305,6 +305,31 @@ def gen_ltt_models():
     gen_model_fixture("ltt_bert_base_l2", r_lbert.ltt_bert_recipe, lbert, "bert", B=2, K=4, mask_seed=3407, ltt=True)
 
 
+def gen_mc_shapley():
+    """Monte-Carlo permutation Shapley: the reference's own _get_shap (scripts/preview_text_shapley.py:62-132)
+    on the 2-layer BERT fixture model; the permutations it drew are recorded (torch.randperm on the host generator)."""
+    _stub_modules()
+    import reference.scripts.preview_text_shapley as pts
+    meta = json.load(open(os.path.join(HERE, "model_bert_base_l2.json")))
+    params = meta["params"]
+    recipe = r_vbert.vanilla_bert_recipe()
+    cfg = recipe.t_config(**params)
+    m_srg = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(m_srg, seed=0)
+    m_srg.eval()
+    L = params["max_position_embeddings"]
+    ids = torch.from_numpy(synth.synth_token_ids(2, L, params["vocab_size"], seed=0))[1:2]
+    P, reps = L - 1, 3
+    torch.manual_seed(1234)
+    perms = torch.stack([torch.randperm(P) for _ in range(reps)])
+    torch.manual_seed(1234)
+    sv, v0, vn = pts._get_shap(device=torch.device("cpu"), m_recipe=recipe, m_surrogate=m_srg,
+                               gen_input=lambda a, b: (ids, torch.zeros(1, dtype=torch.long)), n_players=P, _inputs="x",
+                               reps=reps, batch_size=16)
+    save("mc_shapley.npz", perms=perms.numpy(), sv=sv.numpy(), v0=v0.numpy(), vn=vn.numpy(), input_row=np.asarray([1], dtype=np.int64),
+         reps=np.asarray([reps], dtype=np.int64))
+
+
 def gen_ltt_state_keys():
     tiny = hparams("vit_tiny_imagenette_vanilla")
     lvit = {k: v for k, v in tiny.items() if not k.startswith("explainer_")}
@@ -347,6 +372,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "state_keys":
         gen_state_keys()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
+        gen_mc_shapley()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
         gen_ltt_models()
         gen_ltt_state_keys()
@@ -359,3 +387,4 @@ if __name__ == "__main__":
     gen_state_keys()
     gen_ltt_models()
     gen_ltt_state_keys()
+    gen_mc_shapley()

@@ -82,3 +82,52 @@ def test_surrogate_kl_batch(cuda_device):
     assert dcur.shape == adapt.shape
 
 
+
+
+def test_mc_permutation_shapley_matches_reference(cuda_device):
+    """SURVEY §8 f3 (scripts/preview_text_shapley.py:62-153): nested masks on the device, K-shared rows of one input,
+    one reduction kernel — against the reference's own output for the same permutations."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import mc_shapley
+    engine.set_precision("fp32")
+    g = golden("mc_shapley.npz")
+    c = build_case("bert_base_l2")
+    dev = cuda_device
+    srg = c["surrogate"].to(dev)
+    xs = torch.from_numpy(c["xs"][int(g["input_row"][0])][None]).to(dev)
+    perms = torch.from_numpy(g["perms"])
+    sv, v0, vn = mc_shapley.get_shap(dev, c["recipe"], srg, xs, c["P"], int(g["reps"][0]), perms=perms, rows_per_pass=200)
+    scale = float(np.abs(g["sv"]).max())
+    np.testing.assert_allclose(sv.cpu().numpy(), g["sv"], rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(v0.cpu().numpy(), g["v0"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(vn.cpu().numpy(), g["vn"], rtol=1e-4, atol=1e-4)
+    # efficiency property of permutation sampling: the contributions telescope to v(N) - v(0) for every class
+    np.testing.assert_allclose(sv.sum(dim=1).cpu().numpy(), (vn - v0).cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_accuracy_reports(cuda_device):
+    """measure_accuracy / measure_cls_acc loop bodies against the oracle on the same python-random masks."""
+    import random
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import measure_accuracy as ma
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    srg = c["surrogate"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    sd_s, prm = state_dict_numpy(c["surrogate"]), c["meta"]["params"]
+    labels = torch.tensor([3, 5])
+    gen = lambda a, b: (xs, labels.to(dev))  # noqa: E731
+    random.seed(11)
+    rep = ma.measure_accuracy(None, dev, c["P"], 3, lambda: [(None, None)] * 2, recipe, srg, 1, gen)
+    assert rep.masked_players == [0, 98, 196]
+    random.seed(11)
+    want = []
+    for n_masked in rep.masked_players:
+        correct = 0
+        for _ in range(2):
+            m = osh.mask_uniform_selective(c["B"], c["P"], n_masked)
+            ys = otr.vit_surrogate(c["xs"], m, sd_s, prm)
+            correct += int((ys.argmax(1) == labels.numpy()).sum())
+        want.append(correct / (2 * c["B"]))
+    assert rep.accuracy == want

@@ -27,3 +27,21 @@ def test_normalize_efficiency_gap_quirk():
     total_with_cls = out.sum(axis=1)
     np.testing.assert_allclose(total_with_cls, g["vit_norm_grand"] - g["vit_norm_null"], atol=2e-5)
     assert np.abs(out[:, 1:].sum(axis=1) - (g["vit_norm_grand"] - g["vit_norm_null"])).max() > 1e-4
+
+
+def test_mc_permutation_shapley_matches_reference():
+    """the oracle's permutation-Shapley loop vs the reference's own _get_shap output
+    (tests/golden/mc_shapley.npz, 3 permutations on the 2-layer BERT fixture model)."""
+    from oracle import transformer as otr
+    from util import build_case, state_dict_numpy
+    g = golden("mc_shapley.npz")
+    c = build_case("bert_base_l2")
+    sd, prm = state_dict_numpy(c["surrogate"]), c["meta"]["params"]
+    ids = c["xs"][int(g["input_row"][0])][None]
+
+    def probs(masks):
+        return otr.bert_surrogate(np.repeat(ids, masks.shape[0], axis=0), masks, sd, prm)
+    sv, v0, vn = osh.mc_permutation_shapley(probs, g["perms"])
+    np.testing.assert_allclose(sv, g["sv"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(v0, g["v0"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(vn, g["vn"], rtol=0, atol=1e-5)
