@@ -335,6 +335,164 @@ int launch_valu(const AttnArgs& a, int head_dim, hipStream_t s) {
     return AG_OK;
 }
 
+// ---- bf16 MFMA kernel for narrow heads (D = 8 or 16: the LTT side network, reference models/ltt_vit.py:383-394) ----
+// Same roles as attn_bf16_kernel (S^T = K.Q^T on 32x32x16, a lane owns a query, P^T reused as the PV B operand), with
+// the head dim zero-padded to the 16-wide contraction of ONE MFMA per 32-key block, and O^T = V^T.P^T on a single
+// 32-row d tile of which D rows are live.  K is staged row-major ([key][D] bf16), V transposed ([d][key]) by the staging
+// threads, so the V^T fragments are two 8-byte reads per lane.  Per (query, key) pair the VALU work drops from ~36
+// operations of the scalar kernel to the ~10 of the soft-max.
+template <int MODE, int D>
+__global__ __launch_bounds__(512) void attn_narrow_bf16_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    int T = p.T, Tp = p.Tp, nq = p.nq;
+    long tok_in = (long)(row / p.share) * p.T, tok_out = (long)row * p.T;
+    if (p.cu) {
+        const int t0 = p.cu[row];
+        T = p.cu[row + 1] - t0;
+        Tp = (T + 31) & ~31;
+        nq = p.nq < p.T ? p.nq : T;
+        tok_in = tok_out = t0;
+    }
+    constexpr int KROW = D * 2;                 // bytes per key in the K image
+    const int vstride = Tp * 2 + 16;            // bytes per d row of the V^T image (+16: rows land on different banks)
+    char* ldsK = smem;
+    char* ldsV = smem + p.Tp * KROW;            // (sized for the longest row)
+    const long rowstride = (long)3 * p.H * 2;
+    const char* qbase = p.qkv + tok_in * rowstride + (long)head * D * 2;
+    const char* kbase = qbase + (long)p.H * 2;
+    const char* vbase = qbase + (long)2 * p.H * 2;
+    for (int k = tid; k < Tp; k += blockDim.x) {     // keys >= T: a finite copy of the last key; masked to -inf below
+        const int kc = k < T ? k : T - 1;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            *reinterpret_cast<uint4*>(ldsK + k * KROW + c * 16) = *reinterpret_cast<const uint4*>(kbase + (long)kc * rowstride + c * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)kc * rowstride + c * 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<bf16_t*>(ldsV + (c * 8 + e) * vstride + k * 2) = (bf16_t)((w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        }
+    }
+    __syncthreads();
+
+    const int nkb = Tp >> 5, nqb = (nq + 31) >> 5;
+    const int lr = lane & 31, lh = lane >> 5;
+    const uint32_t* mrow = p.mask + (long)row * p.Tw;
+    const uint32_t mwords = p.cu ? 0xFFFFFFFFu : (lane < p.Tw ? mrow[lane] : 0u);
+    const float c2 = 1.4426950408889634f / sqrtf((float)D);
+    const bool live = lh * 8 < D;               // this lane half carries real head-dim elements of the QK operands
+    const bool vlive = lr < D;                  // this lane's d row of the PV A operand is real
+
+    for (int qb = wave; qb < nqb; qb += nwaves) {
+        const int q = qb * 32 + lr;
+        const bool qvalid = q < nq;
+        const int qc = qvalid ? q : T - 1;
+        uint4 qf = make_uint4(0, 0, 0, 0);
+        if (live) qf = *reinterpret_cast<const uint4*>(qbase + (long)qc * rowstride + lh * 16);
+        f32x16_t o0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o0[i] = 0.f;
+        float m_run = NEG_BIG, l_run = 0.f;
+        for (int kb = 0; kb < nkb; ++kb) {
+            uint4 kf = make_uint4(0, 0, 0, 0);
+            if (live) kf = *reinterpret_cast<const uint4*>(ldsK + (kb * 32 + lr) * KROW + lh * 16);
+            f32x16_t s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf), s, 0, 0, 0);
+            // key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh (as in attn_bf16_kernel): mask, ragged tail
+            const uint32_t mw = __builtin_amdgcn_readlane(mwords, kb);
+            const uint32_t mwl = mw >> (4 * lh);
+            const int kvalid = T - kb * 32;
+            float bmax = NEG_BIG;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = (i & 3) + 8 * (i >> 2);
+                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
+                const uint32_t sb = __float_as_uint(s[i]);
+                s[i] = __uint_as_float(MODE == AG_MASK_VIT_MUL ? (sb & m) : ((sb & m) | (NEG_BIG_BITS & ~m)));
+            }
+            if (kvalid < 32) {
+                const uint32_t vwl = ((1u << kvalid) - 1u) >> (4 * lh);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kk = (i & 3) + 8 * (i >> 2);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vwl, kk, 1);
+                    s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bmax = fmaxf(bmax, s[i]);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+                bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float m_new = fmaxf(m_run, bmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            const float mc = -m_new * c2;
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c2, mc));
+                s[i] = pv;
+                psum += pv;
+            }
+            l_run = fmaf(l_run, alpha, psum);
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o0[i] *= alpha;
+            // P^T fragments: regs 8st..8st+7 -> k-step st; element j <-> key 16st + 8(j>>2) + 4lh + (j&3)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 pf;
+                pf.x = pack_bf16x2(s[8 * st + 0], s[8 * st + 1]);
+                pf.y = pack_bf16x2(s[8 * st + 2], s[8 * st + 3]);
+                pf.z = pack_bf16x2(s[8 * st + 4], s[8 * st + 5]);
+                pf.w = pack_bf16x2(s[8 * st + 6], s[8 * st + 7]);
+                uint4 vf = make_uint4(0, 0, 0, 0);       // V^T[d = lr][the same 8 keys]
+                if (vlive) {
+                    const char* vr = ldsV + lr * vstride + (kb * 32 + 16 * st + 4 * lh) * 2;
+                    const uint2 a = *reinterpret_cast<const uint2*>(vr), b = *reinterpret_cast<const uint2*>(vr + 16);
+                    vf = make_uint4(a.x, a.y, b.x, b.y);
+                }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
+            }
+        }
+        float l_tot;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+            l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float inv = 1.0f / l_tot;
+        if (qvalid) {   // accumulator register i of lane (lr = query, lh) is d row (i&3) + 8(i>>2) + 4lh
+            char* out = p.ctx + (tok_out + q) * p.H * 2 + (long)head * D * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < D / 8; ++g4) {
+                const int d = 8 * g4 + 4 * lh;
+                *reinterpret_cast<uint2*>(out + d * 2) =
+                    make_uint2(pack_bf16x2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv), pack_bf16x2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv));
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_narrow(const AttnArgs& a, int mask_mode, hipStream_t s) {
+    const size_t lds = (size_t)a.Tp * D * 2 + (size_t)D * ((size_t)a.Tp * 2 + 16);
+    AG_REQUIRE(lds <= 64 * 1024, "masked attention: T=%d too long for the narrow-head LDS image", a.T);
+    const int nqb = (a.nq + 31) / 32;
+    int nwaves = nqb < 8 ? nqb : 8;
+    if (nwaves < 2) nwaves = 2;
+    if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL((attn_narrow_bf16_kernel<AG_MASK_VIT_MUL, D>), dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
+    else hipLaunchKernelGGL((attn_narrow_bf16_kernel<AG_MASK_BERT_ADD, D>), dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 // dispatch shared by the fixed-length and the packed (varlen) entry points
 int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream_t s) {
     if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "masked attention: bad dtype %d", dtype);
@@ -356,8 +514,12 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
     } else if (dtype == AG_F32) {
         return launch_valu<float>(a, hd, s);
+    } else if (hd == 8 && !getenv("AG_ATTN_VALU")) {
+        return launch_narrow<8>(a, mask_mode, s);
+    } else if (hd == 16 && !getenv("AG_ATTN_VALU")) {
+        return launch_narrow<16>(a, mask_mode, s);
     } else {
-        return launch_valu<bf16_t>(a, hd, s);   // narrow heads in bf16 storage
+        return launch_valu<bf16_t>(a, hd, s);   // other head dims in bf16 storage
     }
     AG_LAUNCH_CHECK();
     return AG_OK;
