@@ -37,6 +37,21 @@ def _acc(dst: Tensor, src: Tensor) -> None:
         L.check(L.lib().ag_add_f32(L.ptr(dst), L.ptr(src.contiguous()), L.ptr(dst), dst.numel(), L.stream()))
 
 
+def _fp32_step(fn):
+    """Training steps run the fp32 kernels; the caller's inference precision (bf16 throughput mode for the K-mask
+    surrogate targets of the same batch loop) is restored afterwards."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        prev = engine.precision_name()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            engine.set_precision(prev)
+    return wrapper
+
+
 class Seeds:
     """Fresh dropout seed per site per step (train mode); p == 0 disables everything."""
 
@@ -358,12 +373,12 @@ class ExplainerTrainer:
         self.pool = Lin([m_explainer.bert_pooler.dense]) if (self.duo and not self.is_vit) else None
         self.step = 0
 
+    @_fp32_step
     def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
                        labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
         """One reference training-step body (scripts/train_explainer.py:182-196 / train_duo_explainer.py:180-196):
         explainer forward (all-ones mask), loss, backward into param.grad.  -> (loss tensor [1], phi)."""
         cfg = self.m.config
-        engine.set_precision("fp32")
         self.step += 1
         seeds = Seeds(seed * 7919 + self.step)
         b = xs.shape[0]
@@ -423,9 +438,9 @@ class SurrogateTrainer:
         self.pool = None if self.is_vit else Lin([m_surrogate.bert_pooler.dense])
         self.step = 0
 
+    @_fp32_step
     def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
         cfg = self.m.config
-        engine.set_precision("fp32")
         self.step += 1
         seeds = Seeds(seed * 104729 + self.step)
         b = xs.shape[0]
@@ -526,9 +541,9 @@ class LttSurrogateTrainer:
         self.pool = None if self.is_vit else Lin([m_surrogate.bert_s_attn_pooler.dense])
         self.step = 0
 
+    @_fp32_step
     def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
         cfg = self.m.config
-        engine.set_precision("fp32")
         self.step += 1
         seeds = Seeds(seed * 104729 + self.step)
         b = xs.shape[0]
@@ -573,10 +588,10 @@ class LttExplainerTrainer:
         self.mlp = MLPHead(m_explainer.s_explainer_mlp if self.is_vit else m_explainer.s_attn_explainer)
         self.step = 0
 
+    @_fp32_step
     def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
                        labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
         cfg = self.m.config
-        engine.set_precision("fp32")
         self.step += 1
         seeds = Seeds(seed * 7919 + self.step)
         b = xs.shape[0]

@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per explainer training step of the secondary block (0 = skip)")
     ap.add_argument("--attr-batch", type=int, default=128, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
     args = ap.parse_args()
 
@@ -258,6 +259,43 @@ def main():
             el = float(tm.item())
         attrs_per_s = args.attr_batch * world * n_attr / el
         del final, fx, phi
+
+    # ---- training-step rate (SURVEY §8d metric 2): one reference _explainer_epoch_train body per step = K-mask
+    # surrogate targets (bf16 inference path) + explainer forward/backward (fp32 training kernels) + AdamW step
+    train_imgs_per_s = None
+    if args.train_batch > 0:
+        from autognothi_amd.scripts import train_explainer as te
+        m_exp = recipe.t_explainer(cfg)
+        synth.load_synth_weights(m_exp, seed=1)
+        m_exp = m_exp.to(dev)
+        m_exp.train()
+        tb = args.train_batch
+        if kind.endswith("vit"):
+            tx = torch.from_numpy(synth.synth_images(tb, params["img_px_size"], params["img_channels"], seed=200 + rank)).to(dev)
+        else:
+            tx = torch.from_numpy(synth.synth_token_ids(tb, params["max_position_embeddings"], params["vocab_size"], seed=200 + rank)).to(dev)
+        labels = torch.zeros(tb, dtype=torch.long, device=dev)
+        opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5)
+        v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
+        gen = lambda a, b_: (tx, labels)  # noqa: E731
+        te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)], recipe, surrogate, m_exp, opt, 1, gen, seed=7)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        tt = time.perf_counter()
+        n_train = 3
+        te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)] * n_train, recipe, surrogate, m_exp, opt, 2, gen, seed=7)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - tt
+        if dist is not None:
+            tm = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        train_imgs_per_s = tb * world * n_train / el
+        surrogate.eval()
+        del m_exp, opt
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
@@ -313,6 +351,10 @@ def main():
             line["secondary"] = {"metric": "Shapley-attrs/sec/image", "value": round(attrs_per_s, 1), "unit": "images/s",
                                  "path": "fw_final (classifier + surrogate + explainer forward -> phi[B,C,P])",
                                  "images_per_gpu_per_pass": args.attr_batch, "passes": 4}
+            if train_imgs_per_s is not None:
+                line["secondary"]["train_explainer_step"] = {
+                    "value": round(train_imgs_per_s, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
+                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (fp32 kernels) + AdamW, as scripts/train_explainer.py:128-207"}
         if world == 1 and not args.no_cpu_baseline:
             sample_b = 1
             masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()
