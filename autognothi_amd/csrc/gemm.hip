@@ -23,8 +23,8 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per tile row
-constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand tile
+constexpr int ROWB = 128;                      // bytes of K per tile row
+// block tile BT x BT (128, or 64 when a launch would otherwise leave most CUs idle): 4 waves as 2 x 2, wave tile BT/2
 constexpr int NTHREADS = 256;
 
 struct GemmArgs {
@@ -61,17 +61,19 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
 
 // stage one 128-row x 128-byte operand tile; rows beyond `rows_total` are clamped (their products
 // only reach accumulators that the epilogue never stores).
+template <int BT>
 __device__ __forceinline__ void stage_tile(const char* base, long ld_b, int row0, int rows_total, long kbyte0,
                                            char* lds_tile, int wave, int lane, long kbytes, const char* zeros) {
     const int r_in = lane >> 3, slot = lane & 7;
+    constexpr int RW = BT / 4;   // rows staged by one wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + r_in;
+    for (int i = 0; i < RW / 8; ++i) {
+        const int row = wave * RW + i * 8 + r_in;
         int grow = row0 + row;
         grow = grow < rows_total ? grow : rows_total - 1;
         const int chunk = slot ^ (row & 7);
         const long kb = kbyte0 + chunk * 16;   // K tail (K*sizeof(T) not a multiple of 128 B): the missing chunks are zeros
-        glds16(kb < kbytes ? base + (long)grow * ld_b + kb : zeros, lds_tile + (wave * 32 + i * 8) * ROWB);
+        glds16(kb < kbytes ? base + (long)grow * ld_b + kb : zeros, lds_tile + (wave * RW + i * 8) * ROWB);
     }
 }
 
@@ -79,8 +81,9 @@ __device__ __forceinline__ uint4 lds_frag(const char* lds_tile, int row, int chu
     return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + ((chunk ^ (row & 7)) << 4));
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int BT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
+    constexpr int BM = BT, BN = BT, TILE_BYTES = BT * ROWB, NS = BT / 32, WT = BT / 2;   // NS sub-tiles per wave and dim
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,16 +97,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
 
-    f32x4_t acc[4][4];  // [n sub-tile][m sub-tile]
+    f32x4_t acc[NS][NS];  // [n sub-tile][m sub-tile]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NS; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)((p.kbytes + ROWB - 1) / ROWB);
     // LDS: [buf0: A tile | W tile][buf1: A tile | W tile]
-    stage_tile(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane, p.kbytes, p.zeros);
-    stage_tile(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
+    stage_tile<BT>(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane, p.kbytes, p.zeros);
+    stage_tile<BT>(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -112,23 +115,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane, p.kbytes, p.zeros);
-            stage_tile(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
+            stage_tile<BT>(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane, p.kbytes, p.zeros);
+            stage_tile<BT>(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
         }
         const char* tA = smem + cur * 2 * TILE_BYTES;
         const char* tW = tA + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 fw[4], fx[4];
+            uint4 fw[NS], fx[NS];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                fw[s] = lds_frag(tW, wn * 64 + s * 16 + frow, kk * 4 + fq);
-                fx[s] = lds_frag(tA, wm * 64 + s * 16 + frow, kk * 4 + fq);
+            for (int s = 0; s < NS; ++s) {
+                fw[s] = lds_frag(tW, wn * WT + s * 16 + frow, kk * 4 + fq);
+                fx[s] = lds_frag(tA, wm * WT + s * 16 + frow, kk * 4 + fq);
             }
 #pragma unroll
-            for (int sn = 0; sn < 4; ++sn)
+            for (int sn = 0; sn < NS; ++sn)
 #pragma unroll
-                for (int sm = 0; sm < 4; ++sm) Mma<T>::run(fw[sn], fx[sm], acc[sn][sm]);
+                for (int sm = 0; sm < NS; ++sm) Mma<T>::run(fw[sn], fx[sm], acc[sn][sm]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool HAS_R = (EPI == AG_EPI_BIAS_RESID || EPI == AG_EPI_BIAS_GELU_ADD);
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!HAS_R || (p.ldr & 3) == 0);
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) {
-        const int m = m0 + wm * 64 + sm * 16 + frow;
+    for (int sm = 0; sm < NS; ++sm) {
+        const int m = m0 + wm * WT + sm * 16 + frow;
         if (m >= p.M) continue;
         long rrow = 0;
         if (HAS_R) {
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
             rrow = (long)(seq / p.share) * p.T + t;
         }
 #pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-            const int n = n0 + wn * 64 + sn * 16 + fq * 4;
+        for (int sn = 0; sn < NS; ++sn) {
+            const int n = n0 + wn * WT + sn * 16 + fq * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
             float rres[4] = {0.f, 0.f, 0.f, 0.f};   // AG_EPI_BIAS_GELU_ADD: residual joins after the activation
@@ -204,19 +207,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int EPI>
-int launch(const GemmArgs& a, hipStream_t s) {
-    const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
+template <typename T, int EPI, int BT>
+int launch_bt(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, EPI, BT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BT * ROWB);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, EPI>), dim3(tiles), dim3(NTHREADS), 4 * TILE_BYTES, s, a);
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, BT>), dim3(tiles), dim3(NTHREADS), 4 * BT * ROWB, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
+}
+
+template <typename T, int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+    // 128^2 tiles unless they would leave most of the 256 CUs (2 workgroups each) without work: the training steps run
+    // on a few images (M = B*T ~ 1.5 k rows) and their dW GEMMs have N x K outputs of a few dozen 128^2 tiles
+    const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
+    if (tiles128 < 384) return launch_bt<T, EPI, 64>(a, s);
+    return launch_bt<T, EPI, 128>(a, s);
 }
 
 template <typename T>

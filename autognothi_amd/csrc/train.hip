@@ -26,17 +26,22 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, i
     }
 }
 
-// ---- column sums: out[n] (+)= sum_m x[m][n] ; one block per 64 columns, 4 row lanes ----
+// ---- column sums: out[n] (+)= sum_m x[m][n] ; block = 64 columns x one row slab (gridDim.y slabs), 4 row lanes ----
+// One slab: plain store / read-modify-write.  Several slabs (tall inputs: a 64-column block alone would walk all M rows
+// on one CU): partial sums are combined with float atomics into an output the launcher zeroed (or that accumulates).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ldx, float* __restrict__ out, int accumulate) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+    const int m_lo = blockIdx.y * rows_per, m_hi = min(M, m_lo + rows_per);
     float s = 0.f;
-    if (c < N) for (int m = w; m < M; m += 4) s += x[(int64_t)m * ldx + c];
+    if (c < N) for (int m = m_lo + w; m < m_hi; m += 4) s += x[(int64_t)m * ldx + c];
     part[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && c < N) {
         const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        out[c] = accumulate ? out[c] + t : t;
+        if (gridDim.y > 1) atomicAdd(out + c, t);
+        else out[c] = accumulate ? out[c] + t : t;
     }
 }
 
@@ -297,7 +302,12 @@ extern "C" int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t 
 }
 extern "C" int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream) {
     AG_REQUIRE(d_x && d_out && M >= 0 && N >= 1, "ag_colsum_f32: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, d_x, M, N, ldx, d_out, accumulate);
+    int slabs = M / 128;                       // >= 128 rows per slab; enough blocks to cover the chip
+    const int want = 1024 / ceil_div(N, 64);
+    if (slabs > want) slabs = want;
+    if (slabs < 1) slabs = 1;
+    if (slabs > 1 && !accumulate) AG_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), slabs), dim3(256), 0, (hipStream_t)stream, d_x, M, N, ldx, d_out, accumulate);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

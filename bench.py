@@ -150,7 +150,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images (or sequences) per GPU per step")
+    # 48 inputs x 32 masks x 197 tokens = 1182 M-tiles of 256 rows: 3546 / 10638 / 14184 tiles for the N = 768 / 2304 / 3072
+    # GEMMs = 13.85 / 41.6 / 55.4 rounds of 256 CUs (<= 1.1 % idle in the last round; B=16 loses 7.7 % on the N = 768 ones)
+    ap.add_argument("--batch", type=int, default=48, help="images (or sequences) per GPU per step")
     ap.add_argument("--workload", default="vit_base", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
