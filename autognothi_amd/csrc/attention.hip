@@ -501,6 +501,8 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         AG_REQUIRE(lds <= 160 * 1024, "masked attention: T=%d too long for the single-pass LDS image", a.T);
         const int nqb = (a.nq + 31) / 32;
         int nwaves = nqb < 8 ? nqb : 8;
+        static const int waves_env = getenv("AG_ATTN_WAVES") ? atoi(getenv("AG_ATTN_WAVES")) : 0;
+        if (waves_env > 0 && nwaves > waves_env) nwaves = waves_env;
         if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
         static size_t lds_set = 0;
         if (lds > lds_set) {
