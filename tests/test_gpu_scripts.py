@@ -131,3 +131,32 @@ def test_accuracy_reports(cuda_device):
             correct += int((ys.argmax(1) == labels.numpy()).sum())
         want.append(correct / (2 * c["B"]))
     assert rep.accuracy == want
+
+
+def test_performance_report(cuda_device):
+    """SURVEY §8 f4 (scripts/measure_performance.py): report structure, parameter counts, and the executed-FLOP count of
+    the batch-of-one forwards against the closed form of SURVEY §8a (GEMM + attention contractions, 2 flops per MAC)."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import measure_performance as mp
+    engine.set_precision("bf16")
+    c = build_case("vit_tiny_c1")
+    dev, recipe, cfg, prm = cuda_device, c["recipe"], c["cfg"], c["meta"]["params"]
+    cls = recipe.t_classifier(cfg)
+    cls.load_state_dict(c["surrogate"].state_dict())
+    cls = cls.to(dev)
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    xs = torch.from_numpy(c["xs"][:1]).to(dev)
+    null = torch.from_numpy(c["null"]).to(dev)
+    gen = lambda a, b: (xs, torch.zeros(1, dtype=torch.long, device=dev))  # noqa: E731
+    rep = mp.measure_performance(None, dev, recipe, c["P"], lambda: [(None, None)] * 2, gen, null, loops=2,
+                                 m_classifier=cls, m_surrogate=srg, m_explainer=exp)
+    assert rep.final is None and len(rep.classifier.time) == 4 and rep.classifier.time_avg > 0
+    n_params = sum(p.numel() for p in cls.parameters()) / 1e6
+    assert abs(rep.classifier.params_all - n_params) < 1e-9
+    t, h, i_, nl, ncls = c["P"] + 1, prm["hidden_size"], prm["intermediate_size"], prm["num_hidden_layers"], prm["num_labels"]
+    layer = 8 * t * h * h + 4 * t * t * h + 4 * t * h * i_
+    embed = 2 * (t - 1) * (3 * 16 * 16) * h
+    last_cls_only = 6 * t * h * h + 4 * t * h + 2 * h * h + 4 * h * i_          # QKV on all tokens, the rest on the CLS row
+    want_cls = (nl - 1) * layer + last_cls_only + embed + 2 * h * ncls
+    assert abs(rep.classifier.gflops * 1e9 - want_cls) / want_cls < 0.02
+    assert rep.explainer.gflops > rep.surrogate.gflops > 0
