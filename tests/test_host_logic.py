@@ -117,3 +117,32 @@ def test_flop_accounting_matches_survey():
         kind, params, _ = bench.WORKLOADS[name]
         t = 197 if "vit" in name else 128
         assert abs(bench.flops_per_forward(kind, params, t) - want) / want < 2e-3
+
+
+def test_checkpoint_wire_format_round_trip(tmp_path):
+    """reference scripts/resources.py:150-271: `{section}-epoch-{n}.ckpt` plain state dicts; retention by `ckpt_when`."""
+    from autognothi_amd.recipes import get_recipe
+    from autognothi_amd.scripts import resources as rs
+    from autognothi_amd.utils import synth
+    assert [e for e in range(0, 31) if rs.ranged_modulo_test("<=10:%2==1; _:%10==0")(e)] == [1, 3, 5, 7, 9, 20, 30]
+    # the reference's own known-answer vectors for this helper (utils/strings.py:176-184)
+    for patt, expected in [("<=10:%2==0; <=5:%3==1; <= 20 : %5 == 0", ".*..*.*.*.*....*....*"), (" <=6:%4==2 ;", "..*...*......."),
+                           ("<=5:%2==1; _:%3==0", ".*.*.**..*..*..*..")]:
+        fn = rs.ranged_modulo_test(patt)
+        assert "".join("*" if fn(i) else "." for i in range(len(expected))) == expected
+    g = golden_json("state_keys.json")
+    recipe = get_recipe("vanilla_vit")
+    cfg = recipe.t_config(**g["vanilla_vit"]["params"])
+    srg = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(srg, seed=4)
+    for ep in range(0, 5):
+        rs.save_epoch_ckpt(tmp_path, "surrogate", "_:%2==0", 4, ep, srg)
+    assert rs.get_epoch_ckpts(tmp_path, "surrogate", 10) == [0, 2, 4]          # 1 and 3 were dropped when 2 and 4 arrived
+    epoch, model = rs.load_epoch_model(tmp_path, recipe, cfg, "surrogate", 10)
+    assert epoch == 4 and not model.training
+    for k, v in srg.state_dict().items():
+        assert torch.equal(v, model.state_dict()[k])
+    raw = torch.load(rs.ckpt_path(tmp_path, "surrogate", 4), weights_only=False)
+    assert list(raw.keys()) == list(g["vanilla_vit"]["roles"]["surrogate"].keys())   # the reference's own key order / names
+    with pytest.raises(FileNotFoundError):
+        rs.load_epoch_ckpt(tmp_path, "explainer", 3, required=True)
