@@ -146,3 +146,31 @@ def test_checkpoint_wire_format_round_trip(tmp_path):
     assert list(raw.keys()) == list(g["vanilla_vit"]["roles"]["surrogate"].keys())   # the reference's own key order / names
     with pytest.raises(FileNotFoundError):
         rs.load_epoch_ckpt(tmp_path, "explainer", 3, required=True)
+
+
+def test_merge_items_reference_known_answers():
+    """The reference's own unit-test vectors for the state-dict merge engine (utils/nnmodel.py:242-307), as data."""
+    from autognothi_amd.utils.nnmodel import New, merge_items
+    src_1 = {"alpha.default.0": 0, "alpha.default.1": 0, "alpha.0": 0, "alpha.1": 0, "beta.2": 0, "gamma.3": 0}
+    src_2 = {"iota.0": 1, "kappa.1": 1}
+    dest = {"gamma.3": 2, "theta.4": 2}
+    rules_1 = {"alpha.default.{_}": ..., "alpha.{_}": [..., "epsilon.{_}", "zeta.{_}"], "beta.{_}": None, "gamma.{_}": None,
+               New(): "gamma.{_}", New(): "theta.{_}"}
+    rules_2 = {"iota.{_}": ..., "kappa.{_}": None}
+    actual = merge_items([(rules_1, src_1), (rules_2, src_2)], dest, duplicate_action=lambda x: x + 5)
+    assert actual == {"alpha.default.0": 0, "alpha.default.1": 0, "alpha.0": 0, "alpha.1": 0, "epsilon.0": 5, "epsilon.1": 5,
+                      "gamma.3": 2, "iota.0": 1, "theta.4": 2, "zeta.0": 5, "zeta.1": 5}
+    with pytest.raises(ValueError):
+        merge_items([({"alpha.{_}": "beta.{_}"}, {"alpha.0": 0, "alpha.1": 0})], {"beta.0": 1, "beta.1": 1, "gamma.0": 1}, lambda x: x)
+
+
+def test_set_iterative_seed_reference_property():
+    """utils/tools.py:57-70: the same (master, key) reseeds python's generator to the same stream."""
+    import random
+    from autognothi_amd.utils.tools import set_iterative_seed
+
+    def get(key):
+        set_iterative_seed(3407, key)
+        return random.randint(0, 1000)
+    a, b, c = get("stage-a"), get("stage-b"), get("stage-c")
+    assert (get("stage-c"), get("stage-a"), get("stage-b")) == (c, a, b)
