@@ -531,6 +531,7 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
 
 extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
                                    int heads, int qkv_share, int mask_mode, int n_query, int dtype, void* stream) {
+    if (R == 0) return AG_OK;
     AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention: null pointer");
     AG_REQUIRE(R >= 0 && T > 0 && heads > 0 && H % heads == 0, "ag_masked_attention: H=%d is not a multiple of heads=%d", H, heads);
     const int hd = H / heads;

@@ -263,6 +263,7 @@ extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype
 
 extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
                             float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream) {
+    if (rows == 0) return AG_OK;
     AG_REQUIRE(d_x && d_gamma && d_beta && (d_y_store || d_y_f32), "ag_layernorm: null pointer");
     AG_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAXV && ldx % 4 == 0, "ag_layernorm: H=%d unsupported (multiple of 4, <= %d)", H, 64 * 4 * LN_MAXV);
     if (rows == 0) return AG_OK;

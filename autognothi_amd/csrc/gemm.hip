@@ -250,6 +250,7 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
                        const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
                        int epilogue, int dtype, const float* d_ln_stats, const float* d_ln_colsum, float ln_eps,
                        float* d_stats_out, void* stream) {
+    if (M == 0) return AG_OK;   // empty row sets (an empty torch tensor has a null data pointer) are legal no-ops
     AG_REQUIRE(d_A && d_W && d_C, "ag_gemm: null pointer");
     AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gemm: bad dtype %d", dtype);

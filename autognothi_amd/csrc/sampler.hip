@@ -265,6 +265,7 @@ extern "C" int ag_mask_purely_uniform(void* d_state, int batch, int n_players, i
 }
 
 extern "C" int ag_pack_mask(const int64_t* d_mask_i64, int rows, int n_players, uint32_t* d_mask_bits, void* stream) {
+    if (rows == 0) return AG_OK;
     AG_REQUIRE(d_mask_i64 && d_mask_bits && rows >= 0 && n_players >= 1, "ag_pack_mask: bad arguments");
     if (rows == 0) return AG_OK;
     hipLaunchKernelGGL(pack_mask_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, d_mask_i64, rows,

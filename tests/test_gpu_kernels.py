@@ -297,3 +297,26 @@ def test_token_pruning_blocks(cuda_device, dtype, t, heads, rows, cls_only):
     tol = dict(rtol=1e-4, atol=2e-5) if dtype == F32 else dict(rtol=2e-2, atol=2e-2)
     sel = want_cu[:-1] if cls_only else np.arange(n)
     np.testing.assert_allclose(got[sel], ref[sel], **tol)
+
+
+def test_empty_inputs(cuda_device):
+    """Zero-row inputs are legal everywhere the reference would produce empty tensors (e.g. mask_shapley_new(0, P) returns
+    [0, P]); nothing may launch an empty grid."""
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    rng = ops.DeviceMT19937(dev, 1)
+    before = rng.raw(4).cpu().numpy()
+    rng.seed(1)
+    mi, mb = ops.mask_shapley_new(rng, 0, 196)
+    assert tuple(mi.shape) == (0, 196) and mb.shape[0] == 0
+    np.testing.assert_array_equal(rng.raw(4).cpu().numpy(), before)            # no draws were consumed
+    a = torch.zeros((0, 768), device=dev)
+    w = torch.zeros((16, 768), device=dev)
+    assert tuple(ops.gemm(a, w, None, L.AG_EPI_BIAS_F32, F32, m=0).shape) == (0, 16)
+    bits = torch.zeros((0, 7), dtype=torch.int32, device=dev)
+    qkv = torch.zeros((0, 197, 3 * 64), device=dev)
+    assert ops.masked_attention(qkv, bits, 0, 197, 64, 1, 1, 0, F32).shape[0] == 0
+    assert tuple(ops.pack_mask(torch.zeros((0, 196), dtype=torch.int64, device=dev)).shape) == (0, 7)
+    x = torch.zeros((0, 192), device=dev)
+    y, _ = ops.layernorm(x, torch.ones(192, device=dev), torch.zeros(192, device=dev), 1e-12, F32, rows=0, ldx=192)
+    assert y.shape[0] == 0
