@@ -227,7 +227,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
     // 128^2 tiles unless they would leave most of the 256 CUs (2 workgroups each) without work: the training steps run
     // on a few images (M = B*T ~ 1.5 k rows) and their dW GEMMs have N x K outputs of a few dozen 128^2 tiles
     const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
-    if (tiles128 < 384) return launch_bt<T, EPI, 64>(a, s);
+    static const int bt_env = getenv("AG_GEMM_BT") ? atoi(getenv("AG_GEMM_BT")) : 0;
+    if (bt_env == 64 || (bt_env == 0 && tiles128 < 384)) return launch_bt<T, EPI, 64>(a, s);
     return launch_bt<T, EPI, 128>(a, s);
 }
 
