@@ -227,6 +227,7 @@ def main():
     assert bool(torch.isfinite(out).all())
 
     stats = {c: collect(c) for c in EPI_NAMES}
+    packed_rows = engine.LAST_PACKED_ROWS   # (BERT token pruning) visible tokens of the last timed step
 
     # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +
     # surrogate + explainer forwards on all-ones masks -> phi [B, C, P]); untimed by the contract's K steps.
@@ -301,7 +302,7 @@ def main():
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
-        frac = engine.LAST_PACKED_ROWS / float(R * T) if (kind == "vanilla_bert" and engine.LAST_PACKED_ROWS) else 1.0
+        frac = packed_rows / float(R * T) if (kind == "vanilla_bert" and packed_rows) else 1.0
         f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         # dominant kernel = the instrumented class with the largest total time
