@@ -56,6 +56,13 @@ __device__ __forceinline__ void glds16b(const char* gsrc, char* lds_wave_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
 
+// one LDS-DMA piece: 64 lanes x 16 B from (SGPR base + per-lane byte offset) to LDS at M0 (+ lane*16)
+__device__ __forceinline__ void glds16b_s(const char* sbase, uint32_t voff, uint32_t lds_off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+
 __device__ __forceinline__ int swz4(int q) { return (0x1320 >> (q * 4)) & 3; }  // {0,2,3,1}[q]
 
 // stage one operand's 256 x 64-B half-step: 16 pieces of 16 rows; wave w takes pieces 2w, 2w+1.
@@ -307,16 +314,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     AG_MARK(122)
     if (grp == 1) asm volatile("s_barrier" ::: "memory");
     // this wave's LDS-DMA pieces: 2 of A, 2 of W per half-step
-    auto refill = [&](int jn, int which) {  // which: 0,1 = A pieces, 2,3 = W pieces of half-step jn
-        char* dst = smem + (jn & 3) * SLOT_BYTES + (which >= 2 ? HALF_OP_BYTES : 0);
+    // refills: SGPR tile base (+ jn*64 B on the scalar unit) + a loop-invariant per-lane byte offset (rows clamped at the
+    // matrix edge): no address arithmetic on the vector unit inside the loop
+    uint32_t offA[2], offW[2];
+    {
         const int r_in = lane >> 2, chunk = (lane & 3) ^ swz4((lane >> 4) & 3);
-        const int piece = wave * 2 + (which & 1);
-        const int rows_total = which >= 2 ? p.N : p.M;
-        int grow = (which >= 2 ? n0 : m0) + piece * 16 + r_in;
-        grow = grow < rows_total ? grow : rows_total - 1;
-        const char* base = which >= 2 ? p.W : p.A;
-        const long ld = which >= 2 ? p.ldw_b : p.lda_b;
-        glds16b(base + (long)grow * ld + (long)jn * HROWB + chunk * 16, dst + piece * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ra = (wave * 2 + i) * 16 + r_in, rw = ra;
+            ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+            offA[i] = (uint32_t)(ra * (int)p.lda_b + chunk * 16);
+            offW[i] = (uint32_t)(rw * (int)p.ldw_b + chunk * 16);
+        }
+    }
+    const char* tileA = p.A + (long)m0 * p.lda_b;
+    const char* tileW = p.W + (long)n0 * p.ldw_b;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto refill = [&](int jn, int which) {  // which: 0,1 = A pieces, 2,3 = W pieces of half-step jn
+        const uint32_t dst = lds0 + (jn & 3) * SLOT_BYTES + (which >= 2 ? HALF_OP_BYTES : 0) + (wave * 2 + (which & 1)) * 1024;
+        if (which >= 2) glds16b_s(tileW + jn * HROWB, offW[which & 1], dst);
+        else glds16b_s(tileA + jn * HROWB, offA[which & 1], dst);
     };
 #define AG_STAMP(slot_)                                                                                   \
         if (DBG && (blockIdx.x == 0 || blockIdx.x == 777) && lane == 0) {                                      \
