@@ -342,25 +342,29 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
             p.dbg[(((blockIdx.x ? 1 : 0) * 8 + wave) * 128 + j) * 8 + (slot_)] = t_;                           \
         }
-    for (int j = 0; j < nh; ++j) {
+    // one half-step; `slot`, `do_refill`, `ahead` are literals at every call site below (the steady state is unrolled by the
+    // ring length), so the slot addresses fold into instruction offsets and the loop carries no compare/branch/select
+    // overhead: every scalar instruction here sits on the critical read phase of one wave group.
+    auto half_step = [&](const int j, const int slot, const bool do_refill, const int ahead) {
         AG_STAMP(0)
         asm volatile("s_barrier" ::: "memory");                        // "a": slot j is complete and visible
         AG_STAMP(1)
         // ---- read phase (the SIMD partner wave is in its MFMA phase) ----
-        const char* sA = smem + (j & 3) * SLOT_BYTES;
+        const char* sA = smem + slot * SLOT_BYTES;
         const char* sW = sA + HALF_OP_BYTES;
         uint4 fw[4], fx[8];
 #pragma unroll
         for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-        if (j >= 1 && j + 3 < nh) { refill(j + 3, 0); refill(j + 3, 2); refill(j + 3, 1); refill(j + 3, 3); }
+        if (do_refill) { refill(j + 3, 0); refill(j + 3, 2); refill(j + 3, 1); refill(j + 3, 3); }   // into slot (j-1)&3
         AG_STAMP(2)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my fragments are in registers
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my fragments are in registers (the builtin,
+        asm volatile("" ::: "memory");                                  // so hipcc does not add its own per-MFMA lgkmcnt waits)
         // Slot j+1 must be complete before barrier #2j+2 (group 0's next "a", group 1's "b" below).  Waiting
         // for it here keeps the MFMA phase free of waits; group 0 is one barrier early, which costs nothing:
-        // those pieces were issued two iterations ago.  Newer than j+1 at this point: j+2, j+3.
-        if (j + 1 < nh) wait_ahead(min(nh - 2 - j, 2));
+        // those pieces were issued two iterations ago.  Newer than j+1 at this point: j+2, j+3 (`ahead` of them).
+        if (ahead >= 0) wait_ahead(ahead);
         AG_STAMP(3)
         asm volatile("s_barrier" ::: "memory");                        // "b"
         AG_STAMP(4)
@@ -376,6 +380,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         AG_STAMP(5)
+    };
+    if (!DBG && (nh & 3) == 0 && nh >= 8) {
+        half_step(0, 0, false, 2);                                   // the prologue already filled slots 0..3
+        int j = 1;
+        for (; j + 7 <= nh; j += 4) {                                 // steady state: half-steps 1 .. nh-4 request j+3 (<= nh-1), 2 ahead
+            half_step(j, 1, true, 2);
+            half_step(j + 1, 2, true, 2);
+            half_step(j + 2, 3, true, 2);
+            half_step(j + 3, 0, true, 2);
+        }
+        // (nh - 4) % 4 == 0: the loop stops at j == nh - 3; the last three half-steps request nothing and drain the ring
+        half_step(j, 1, false, 1);
+        half_step(j + 1, 2, false, 0);
+        half_step(j + 2, 3, false, -1);
+    } else {
+        for (int j = 0; j < nh; ++j)
+            half_step(j, j & 3, j >= 1 && j + 3 < nh, j + 1 < nh ? min(nh - 2 - j, 2) : -1);
     }
 #undef AG_STAMP
     if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
