@@ -63,6 +63,20 @@ __device__ __forceinline__ void glds16b_s(const char* sbase, uint32_t voff, uint
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
 
+// this wave's four pieces of one half-step (A piece 0, W piece 0, A piece 1, W piece 1) in one statement: M0 saved and
+// restored once, no compiler-scheduled instructions in between
+__device__ __forceinline__ void glds16b_s_x4(const char* baseA, const char* baseW, uint32_t oA0, uint32_t oW0, uint32_t oA1,
+                                             uint32_t oW1, uint32_t ldsA0, uint32_t ldsW0) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                 "s_add_u32 m0, %7, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, %8, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(oA0), "v"(oW0), "v"(oA1), "v"(oW1), "s"(baseA), "s"(baseW), "s"(ldsA0), "s"(ldsW0) : "memory", "scc");
+}
+
 __device__ __forceinline__ int swz4(int q) { return (0x1320 >> (q * 4)) & 3; }  // {0,2,3,1}[q]
 
 // stage one operand's 256 x 64-B half-step: 16 pieces of 16 rows; wave w takes pieces 2w, 2w+1.
@@ -331,10 +345,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     const char* tileA = p.A + (long)m0 * p.lda_b;
     const char* tileW = p.W + (long)n0 * p.ldw_b;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto refill = [&](int jn, int which) {  // which: 0,1 = A pieces, 2,3 = W pieces of half-step jn
-        const uint32_t dst = lds0 + (jn & 3) * SLOT_BYTES + (which >= 2 ? HALF_OP_BYTES : 0) + (wave * 2 + (which & 1)) * 1024;
-        if (which >= 2) glds16b_s(tileW + jn * HROWB, offW[which & 1], dst);
-        else glds16b_s(tileA + jn * HROWB, offA[which & 1], dst);
+    const uint32_t ldsA_w = lds0 + wave * 2048, ldsW_w = ldsA_w + HALF_OP_BYTES;   // this wave's piece pair inside a slot
+    auto refill4 = [&](int jn, int slot) {  // this wave's A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of half-step jn into ring slot `slot`
+        glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
+                     ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
     };
 #define AG_STAMP(slot_)                                                                                   \
         if (DBG && (blockIdx.x == 0 || blockIdx.x == 777) && lane == 0) {                                      \
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
         for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-        if (do_refill) { refill(j + 3, 0); refill(j + 3, 2); refill(j + 3, 1); refill(j + 3, 3); }   // into slot (j-1)&3
+        if (do_refill) refill4(j + 3, (slot + 3) & 3);                  // into the slot read one half-step ago
         AG_STAMP(2)
         __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my fragments are in registers (the builtin,
         asm volatile("" ::: "memory");                                  // so hipcc does not add its own per-MFMA lgkmcnt waits)
