@@ -297,14 +297,32 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     }
     AG_MARK(120)
     const int nh = p.K / 32;  // half-steps
-    // prologue: half-steps 0..3 into slots 0..3 (4 glds per wave per half-step)
+    // refills: SGPR tile base (+ jn*64 B on the scalar unit) + a loop-invariant per-lane byte offset (rows clamped at the
+    // matrix edge): no address arithmetic on the vector unit inside the loop
+    uint32_t offA[2], offW[2];
+    {
+        const int r_in = lane >> 2, chunk = (lane & 3) ^ swz4((lane >> 4) & 3);
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-        if (j < nh) {
-            stage_half(p.A, p.lda_b, m0, p.M, (long)j * HROWB, smem + j * SLOT_BYTES, wave, lane);
-            stage_half(p.W, p.ldw_b, n0, p.N, (long)j * HROWB, smem + j * SLOT_BYTES + HALF_OP_BYTES, wave, lane);
+        for (int i = 0; i < 2; ++i) {
+            int ra = (wave * 2 + i) * 16 + r_in, rw = ra;
+            ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+            offA[i] = (uint32_t)(ra * (int)p.lda_b + chunk * 16);
+            offW[i] = (uint32_t)(rw * (int)p.ldw_b + chunk * 16);
         }
     }
+    const char* tileA = p.A + (long)m0 * p.lda_b;
+    const char* tileW = p.W + (long)n0 * p.ldw_b;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t ldsA_w = lds0 + wave * 2048, ldsW_w = ldsA_w + HALF_OP_BYTES;   // this wave's piece pair inside a slot
+    auto refill4 = [&](int jn, int slot) {  // this wave's A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of half-step jn into ring slot `slot`
+        glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
+                     ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
+    };
+    // prologue: half-steps 0..3 into slots 0..3 (4 pieces per wave per half-step)
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+        if (j < nh) refill4(j, j);
 
     // ---- main loop: two wave groups half a step out of phase ---------------------------------------
     // Waves w and w+4 share a SIMD.  Group 0 (waves 0-3) and group 1 (waves 4-7) run the same program, but
@@ -328,28 +346,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     AG_MARK(122)
     if (grp == 1) asm volatile("s_barrier" ::: "memory");
     // this wave's LDS-DMA pieces: 2 of A, 2 of W per half-step
-    // refills: SGPR tile base (+ jn*64 B on the scalar unit) + a loop-invariant per-lane byte offset (rows clamped at the
-    // matrix edge): no address arithmetic on the vector unit inside the loop
-    uint32_t offA[2], offW[2];
-    {
-        const int r_in = lane >> 2, chunk = (lane & 3) ^ swz4((lane >> 4) & 3);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int ra = (wave * 2 + i) * 16 + r_in, rw = ra;
-            ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
-            rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
-            offA[i] = (uint32_t)(ra * (int)p.lda_b + chunk * 16);
-            offW[i] = (uint32_t)(rw * (int)p.ldw_b + chunk * 16);
-        }
-    }
-    const char* tileA = p.A + (long)m0 * p.lda_b;
-    const char* tileW = p.W + (long)n0 * p.ldw_b;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t ldsA_w = lds0 + wave * 2048, ldsW_w = ldsA_w + HALF_OP_BYTES;   // this wave's piece pair inside a slot
-    auto refill4 = [&](int jn, int slot) {  // this wave's A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of half-step jn into ring slot `slot`
-        glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
-                     ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
-    };
 #define AG_STAMP(slot_)                                                                                   \
         if (DBG && (blockIdx.x == 0 || blockIdx.x == 777) && lane == 0) {                                      \
             unsigned long long t_;                                                                             \

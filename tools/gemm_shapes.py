@@ -3,6 +3,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autognothi_amd import _lib as L, ops
+if os.environ.get("GB_LIB"):   # A/B: an alternative build of the library (same box, same run)
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ["GB_LIB"])
 dev = torch.device("cuda:0"); M = int(os.environ.get("GB_M", 100864))
 ZERO = os.environ.get("GB_ZERO") == "1"
 def mk(n, k): return ((torch.rand((n, k), device=dev) * 2 - 1) / k ** 0.5).to(torch.bfloat16) * (0 if ZERO else 1)
