@@ -78,6 +78,7 @@ SIGNATURES = {
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),
     "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
     "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, C.POINTER(i32), vp]),
+    "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp]),
     "ag_seq_compact_plan": (i32, [vp, i32, i32, vp, vp, vp]),
     "ag_gather_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "ag_masked_attention_varlen": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -240,3 +240,40 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     }
     return AG_OK;
 }
+
+
+// BERT layers on PACKED rows (token pruning building block; the LTT-BERT ladder interleaves its map GEMMs between
+// such calls): x [N, H] holds the visible tokens of R sequences, cu_seqlens [R+1] their ranges; every packed token is a
+// visible key (mask-free varlen attention).  All tokens are processed (no CLS-only shortcut); out [N, H] must not alias x.
+extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const void* d_x, const int* d_cu_seqlens, int R, int N,
+                                             void* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    AG_REQUIRE(d && d_x && d_cu_seqlens && d_out && d_workspace, "ag_bert_layers_forward_packed: null pointer");
+    AG_REQUIRE(d->kind == AG_MASK_BERT_ADD, "ag_bert_layers_forward_packed: only the additive (BERT) mask prunes exactly");
+    AG_REQUIRE(d->n_layers >= 1 && d->layers && R >= 1 && N >= R && N <= R * d->T, "ag_bert_layers_forward_packed: bad shape (R=%d N=%d)", R, N);
+    AG_REQUIRE(workspace_bytes >= ag_encoder_workspace_bytes(d, R), "ag_bert_layers_forward_packed: workspace too small");
+    AG_REQUIRE(d_out != d_x, "ag_bert_layers_forward_packed: out must not alias x");
+    Ws ws;
+    carve(d, R, (char*)d_workspace, &ws);
+    const int T = d->T, H = d->H, I = d->I, dt = d->dtype;
+    const char* x = (const char*)d_x;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const ag_layer_weights& w = d->layers[l];
+        AG_REQUIRE(w.ln2_g, "ag_bert_layers_forward_packed: BERT output.LayerNorm missing in layer %d", l);
+        TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
+        TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        const char* a = ws.hx;
+        if (w.ln1_g) {
+            TRY(ag_layernorm(ws.hx, dt, H, N, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+            a = ws.ha;
+        }
+        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        char* pre = (a == ws.hx) ? ws.ha : ws.hx;
+        TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, N, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        // the last layer writes the caller's buffer; intermediate ones ping-pong through ws.xs (never an input of this loop)
+        char* dst = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
+        TRY(ag_layernorm(pre, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst, nullptr, dt, stream));
+        x = dst;
+    }
+    return AG_OK;
+}

@@ -186,6 +186,25 @@ class PackedEncoder:
         return out
 
 
+def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype: int) -> Tensor:
+    """(BERT kind) this encoder's layers on packed rows x [N, H] (visible tokens of `rows` sequences, cu_seqlens) -> [N, H]."""
+    L.require_gpu(x, cu)
+    if self.kind != L.AG_MASK_BERT_ADD:
+        raise ValueError("packed (token-pruned) layers exist for the additive BERT mask only")
+    x = x.contiguous()
+    d = self.desc(dtype)
+    out = torch.empty((n_packed, self.H), dtype=ops.storage_dtype(dtype), device=x.device)
+    with torch.cuda.device(x.device):
+        need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
+        ws = WORKSPACE.get(x.device, need)
+        L.check(L.lib().ag_bert_layers_forward_packed(C.byref(d), L.ptr(x), L.ptr(cu), rows, n_packed, L.ptr(out), L.ptr(ws),
+                                                      ws.numel(), L.stream()))
+    return out
+
+
+PackedEncoder.forward_packed = _forward_packed
+
+
 def ones_mask_bits(rows: int, n_players: int, device: torch.device) -> Tensor:
     """Key bits of an all-ones mask [rows, P] with CLS prepended (bits beyond T are zero)."""
     t = n_players + 1

@@ -165,6 +165,50 @@ class LttBertModel(nn.Module):
                 side[i_b] = self._side[(t, key)].forward(s_new.view(rows, t, c.s_attn_hidden_size), rows, 1, bits, False, dtype)
         return hidden, [side[i_b] for i_b in branches], bits, rows
 
+    def run_cls(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor],
+                side_layer_branches: Sequence[int]) -> Tuple[Tensor, List[Tensor], int]:
+        """CLS rows only: -> (hidden[:, 0:1] [R,1,H], [side_b[:, 0:1] [R,1,h]], R).  With token pruning (engine.PRUNE_BERT_TOKENS)
+        the additively masked tokens are dropped after layer 0 from the backbone AND the ladder: a masked key has exactly
+        zero weight in every backbone and side layer (models/vanilla_bert.py:523), the heads read the CLS rows only
+        (models/ltt_bert.py:108-116), so the masked tokens' rows of both streams are dead."""
+        dtype = engine.get_precision()
+        c, t = self.config, input_ids.shape[1]
+        enc = self.encoder
+        if not engine.PRUNE_BERT_TOKENS or enc.num_layers < 2:
+            hidden, sides, _, rows = self.run(input_ids, attention_mask, token_type_ids, side_layer_branches)
+            return hidden[:, 0:1].contiguous(), [s_[:, 0:1].contiguous() for s_ in sides], rows
+        bits = engine.to_mask_bits(attention_mask, t - 1)
+        rows, b = bits.shape[0], input_ids.shape[0]
+        if rows % b != 0:
+            raise ValueError(f"mask rows ({rows}) must be a multiple of input rows ({b})")
+        self._pack(t)
+        branches = sorted(set(int(x) for x in side_layer_branches))
+        # layer 0 on every token (its QKV is shared by the K masks of an input), then pack
+        hidden = self._bb[t][0].forward(self.embed(input_ids, token_type_ids, dtype), rows, rows // b, bits, False, dtype)
+        cu, src, n = ops.seq_compact_plan(bits, t)
+        side: Dict[int, Optional[Tensor]] = {i_b: None for i_b in branches}
+        if 0 < enc._ltt_freeze_layer:
+            flat = hidden.view(rows * t, c.hidden_size)
+            for i_b in branches:
+                w, bias = self._maps[f"{i_b}_0"].get(dtype)
+                s0 = ops.gemm(flat, w, bias, L.AG_EPI_BIAS_GELU, dtype)
+                s0 = self._side[(t, f"{i_b}_0")].forward(s0.view(rows, t, c.s_attn_hidden_size), rows, 1, bits, False, dtype)
+                side[i_b] = ops.gather_rows(s0, src, n, dtype)
+        hidden = ops.gather_rows(hidden, src, n, dtype)
+        for i_ly in range(1, enc.num_layers):
+            hidden = self._bb[t][i_ly].forward_packed(hidden, cu, rows, n, dtype)
+            if i_ly >= enc._ltt_freeze_layer:
+                continue
+            for i_b in branches:
+                key = f"{i_b}_{i_ly}"
+                w, bias = self._maps[key].get(dtype)
+                s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1)
+                side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype)
+        engine.LAST_PACKED_ROWS = n
+        h_cls = ops.gather_rows(hidden, cu, rows, dtype).view(rows, 1, c.hidden_size)
+        s_cls = [ops.gather_rows(side[i_b], cu, rows, dtype).view(rows, 1, c.s_attn_hidden_size) for i_b in branches]
+        return h_cls, s_cls, rows
+
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor],
                 side_layer_branches: List[int]) -> Tuple[Tensor, List[Tensor]]:
         hidden, outs, _, _ = self.run(input_ids, attention_mask, token_type_ids, side_layer_branches)
@@ -202,9 +246,13 @@ class LttBertSurrogate(nn.Module, ObservableModuleMixin, _BertHead):
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         _no_autograd(self)
         dtype = engine.get_precision()
-        output, (srg_output,), _, rows = self.bert.run(input_ids, attention_mask, token_type_ids, [0])
-        self.om_record_features(repr_cls=output, repr_srg=srg_output)
-        t = input_ids.shape[1]
+        if self.om_is_observing():
+            output, (srg_output,), _, rows = self.bert.run(input_ids, attention_mask, token_type_ids, [0])
+            self.om_record_features(repr_cls=output, repr_srg=srg_output)
+            t = input_ids.shape[1]
+        else:   # only the CLS rows are consumed (:108-116): token-pruned path
+            output, (srg_output,), rows = self.bert.run_cls(input_ids, attention_mask, token_type_ids, [0])
+            t = 1
         logits = self._pool_classify(output, rows, t, self.bert_pooler, self.classifier, "cls", True, dtype)
         srg_logits = self._pool_classify(srg_output, rows, t, self.bert_s_attn_pooler, self.s_attn_classifier, "side", True, dtype)
         return srg_logits, logits

@@ -286,6 +286,29 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
     return loss, d
 
 
+def seq_compact_plan(mask_bits: Tensor, t: int):
+    """BERT token pruning plan: key bits [R, Tw] -> (cu_seqlens int32 [R+1], packed-row source table int32 [R*t], N);
+    reads the packed row count back (one 4-byte device->host copy)."""
+    L.require_gpu(mask_bits)
+    rows = mask_bits.shape[0]
+    cu = torch.empty(rows + 1, dtype=torch.int32, device=mask_bits.device)
+    src = torch.empty(rows * t, dtype=torch.int32, device=mask_bits.device)
+    with torch.cuda.device(mask_bits.device):
+        L.check(L.lib().ag_seq_compact_plan(L.ptr(mask_bits.contiguous()), rows, t, L.ptr(cu), L.ptr(src), L.stream()))
+    return cu, src, int(cu[rows].item())
+
+
+def gather_rows(src: Tensor, index: Tensor, n: int, dtype: int) -> Tensor:
+    """dst[i, :] = src2d[index[i], :] for the first n entries of index (src viewed as [-1, H])."""
+    L.require_gpu(src, index)
+    h = src.shape[-1]
+    s2 = src.contiguous().view(-1, h)
+    out = torch.empty((n, h), dtype=s2.dtype, device=s2.device)
+    with torch.cuda.device(s2.device):
+        L.check(L.lib().ag_gather_rows(L.ptr(s2), h, L.ptr(index), L.ptr(out), h, n, h, dtype, L.stream()))
+    return out
+
+
 def mc_shapley_reduce(v: Tensor, rank: Tensor):
     """scripts/preview_text_shapley.py:112-153: v [reps, P+1, C] fp32, rank [reps, P] int32 -> (sv [C,P], v0 [C], vn [C])."""
     L.require_gpu(v, rank)

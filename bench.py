@@ -94,6 +94,15 @@ def flops_executed(kind, p, T, K, frac=1.0):
         f += frac * 6 * T * H * H + 4 * frac * T * H + 2 * H * H + 4 * H * I     # last: QKV packed, the rest CLS only
         f += 2 * H * H + 2 * H * p["num_labels"]
         return float(f)
+    if kind == "ltt_bert" and frac < 1.0 and Lr >= 2:                             # backbone + ladder, all packed after layer 0
+        h, i_s = p["s_attn_hidden_size"], p["s_attn_intermediate_size"]
+        layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
+        side = 2 * T * H * h + 8 * T * h * h + 4 * T * T * h + 4 * T * h * i_s
+        lin = lambda x, quad: frac * (x - quad) + frac * frac * quad               # noqa: E731  (GEMMs ~ frac, attention ~ frac^2)
+        f = layer - 6 * T * H * H * (K - 1) / K + side
+        f += (Lr - 1) * (lin(layer, 4 * T * T * H) + lin(side, 4 * T * T * h))
+        f += 2 * H * H + 2 * H * p["num_labels"] + 2 * h * h + 2 * h * p["num_labels"]
+        return float(f)
     f = flops_per_forward(kind, p, T)
     shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind.endswith("vit") else 0)
     f -= shared * (K - 1) / K
@@ -302,7 +311,7 @@ def main():
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
-        frac = packed_rows / float(R * T) if (kind == "vanilla_bert" and packed_rows) else 1.0
+        frac = packed_rows / float(R * T) if (kind in ("vanilla_bert", "ltt_bert") and packed_rows) else 1.0
         f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         # dominant kernel = the instrumented class with the largest total time

@@ -276,6 +276,10 @@ int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_index, void* 
                    int dtype, void* stream);
 int ag_masked_attention_varlen(const void* d_qkv, const int* d_cu_seqlens, void* d_ctx, int R, int t_max, int H,
                                int heads, int cls_only, int dtype, void* stream);
+/* desc's BERT layers on packed rows: x / out [N, H] (visible tokens of R sequences, ranges in cu_seqlens [R+1]), every packed
+ * token a visible key, all tokens processed.  Workspace as ag_encoder_workspace_bytes(desc, R).  out must not alias x. */
+int ag_bert_layers_forward_packed(const ag_encoder_desc* desc, const void* d_x, const int* d_cu_seqlens, int R, int N,
+                                  void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
 int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
                                    const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
                                    int* packed_rows_out, void* stream);
