@@ -24,6 +24,21 @@ from . import engine, ops
 F32 = L.AG_F32
 PAD = 32  # ag_gemm fp32 needs its K dimension to be a multiple of 32
 
+# Mixed precision for the training GEMMs (opt-in: AG_TRAIN_BF16=1 or training.MIXED_BF16 = True).  Activations, gradients,
+# parameters and every elementwise / attention kernel stay fp32; only the operands of the forward, dX and dW GEMMs are
+# rounded to bf16 (fp32 accumulate, fp32 output) — the semantics of torch.autocast(bf16) around nn.Linear.  The reference
+# trains in fp32, so this is a throughput mode like the bf16 inference path, off by default; the gradient-parity tests
+# run the exact-fp32 kernels.
+import os as _os
+MIXED_BF16 = _os.environ.get("AG_TRAIN_BF16", "0") == "1"
+
+
+def _mm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: int) -> Tensor:
+    """epilogue(a[m,K] @ w[N,K]^T + bias) -> fp32; bf16 operands when MIXED_BF16 (plain / fp32-output epilogues only)."""
+    if MIXED_BF16 and epilogue in (L.AG_EPI_BIAS, L.AG_EPI_BIAS_F32) and a.shape[-1] % 8 == 0:
+        return ops.gemm(ops.cast(a, L.AG_BF16), ops.cast(w, L.AG_BF16), bias, L.AG_EPI_BIAS_F32, L.AG_BF16, m=m)
+    return ops.gemm(a, w, bias, epilogue, F32, m=m)
+
 
 def _grad(p: Tensor) -> Tensor:
     if p.grad is None:
@@ -84,7 +99,7 @@ class Lin:
         w, b = self._w()
         if save:
             self.x = x
-        return ops.gemm(x, w, b, epilogue, F32, m=x.shape[0])
+        return _mm(x, w, b, epilogue, x.shape[0])
 
     def backward(self, dy: Tensor, need_dx: bool = True) -> Optional[Tensor]:
         w, _ = self._w()
@@ -98,14 +113,14 @@ class Lin:
                 dyp = torch.zeros((m, npad), dtype=torch.float32, device=dy.device)
                 dyp[:, :n].copy_(dy)
                 wt = ops.transpose(w, pad_cols_to=PAD)  # [K, Np]
-                dx = ops.gemm(dyp, wt, None, L.AG_EPI_BIAS, F32, m=m)
+                dx = _mm(dyp, wt, None, L.AG_EPI_BIAS, m)
             else:
-                dx = ops.gemm(dy, ops.transpose(w), None, L.AG_EPI_BIAS, F32, m=m)
+                dx = _mm(dy, ops.transpose(w), None, L.AG_EPI_BIAS, m)
         if self.trainable():
             # dW[N,K] = dYᵀ[N,M] · X[M,K]  ==  NT GEMM of dYᵀ [N,Mp] against Xᵀ [K,Mp]
             dyt = ops.transpose(dy, pad_cols_to=PAD)
             xt = ops.transpose(self.x, pad_cols_to=PAD)
-            dw = ops.gemm(dyt, xt, None, L.AG_EPI_BIAS, F32, m=n)
+            dw = _mm(dyt, xt, None, L.AG_EPI_BIAS, n)
             db = ops.colsum(dy)
             off = 0
             for mod in self.mods:

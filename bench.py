@@ -276,7 +276,9 @@ def main():
     # surrogate targets (bf16 inference path) + explainer forward/backward (fp32 training kernels) + AdamW step
     train_imgs_per_s = None
     if args.train_batch > 0:
+        from autognothi_amd import training as _tr
         from autognothi_amd.scripts import train_explainer as te
+        _tr.MIXED_BF16 = args.precision == "bf16"   # throughput mode: bf16 GEMM operands (autocast semantics), fp32 everything else
         m_exp = recipe.t_explainer(cfg)
         synth.load_synth_weights(m_exp, seed=1)
         m_exp = m_exp.to(dev)
@@ -366,7 +368,7 @@ def main():
             if train_imgs_per_s is not None:
                 line["secondary"]["train_explainer_step"] = {
                     "value": round(train_imgs_per_s, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (fp32 kernels) + AdamW, as scripts/train_explainer.py:128-207"}
+                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM operands, fp32 accumulate / activations / attention / optimizer state) + AdamW, as scripts/train_explainer.py:128-207"}
         if world == 1 and not args.no_cpu_baseline:
             sample_b = 1
             masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()

@@ -253,3 +253,45 @@ def test_ltt_train_epochs_run_and_reduce_loss(cuda_device, tag):
     assert np.isfinite(first) and last < first
     ev = te.explainer_epoch_eval(None, dev, 4, c["P"], v0, items[:1], recipe, srg, exp, 1, gen, seed=3407)
     assert np.isfinite(ev)
+
+
+def test_mixed_precision_training_step(cuda_device):
+    """Opt-in throughput mode (training.MIXED_BF16): bf16 GEMM operands, fp32 accumulate/activations.  Gradients stay within
+    bf16 operand-rounding distance of fp32 autograd and a few optimiser steps still lower the loss."""
+    from autognothi_amd import ops, training
+    from autognothi_amd.utils import synth
+    c = build_case("froyo_vit_tiny_l3")
+    dev, g, recipe = cuda_device, c["g"], c["recipe"]
+    prm = _zero_dropout(c["meta"])
+    cfg = recipe.t_config(**prm)
+    exp = recipe.t_explainer(cfg)
+    synth.load_synth_weights(exp, seed=1)
+    exp = exp.to(dev)
+    exp.train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    masks = torch.from_numpy(c["masks"])
+    bits = ops.pack_mask(masks.to(dev))
+    v0, vs, v1 = [torch.from_numpy(g[k]) for k in ("v_0", "v_s", "v_1")]
+    training.MIXED_BF16 = True
+    try:
+        tr = training.ExplainerTrainer(recipe, exp)
+        loss, phi = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], train=True)
+        sd = {k: v.detach().cpu().clone().requires_grad_(exp.state_dict(keep_vars=True)[k].requires_grad)
+              for k, v in exp.state_dict(keep_vars=True).items()}
+        ones = torch.ones((c["B"], c["P"]), dtype=torch.long)
+        phi_ref, _ = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, "vit")
+        loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref, c["P"])
+        loss_ref.backward()
+        np.testing.assert_allclose(loss.cpu().numpy()[0], loss_ref.item(), rtol=3e-2)
+        assert _check_grads(exp, sd, 6e-2) >= 10
+        opt = torch.optim.AdamW([p for p in exp.parameters() if p.requires_grad], lr=1e-3)
+        first = last = None
+        for step in range(6):
+            opt.zero_grad()
+            loss, _ = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], train=True, seed=step)
+            opt.step()
+            first = float(loss) if first is None else first
+            last = float(loss)
+        assert last < first
+    finally:
+        training.MIXED_BF16 = False
