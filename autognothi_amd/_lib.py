@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libautognothi_hip.so")
+LIB_PATH = os.environ.get("AG_HIP_LIB") or os.path.join(_HERE, "lib", "libautognothi_hip.so")   # AG_HIP_LIB: A/B another build
 
 AG_OK = 0
 AG_F32, AG_BF16 = 0, 1

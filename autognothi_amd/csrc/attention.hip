@@ -10,8 +10,12 @@
 //     XOR-swizzled so both the row reads and the transposed reads are bank-conflict free).
 //   * S^T = K·Q^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane owns one query column,
 //     so the soft-max row reductions are in-register plus one cross-half shuffle.
-//   * mask bits (one uint32 per 32-key block, bit = key) are applied BEFORE the running max:
-//     ViT  s = bit ? s : 0 ;  BERT s = bit ? s : -inf ;  padded keys (>= T) always -inf.
+//   * masking.  ViT (scores * mask): a masked key has logit exactly 0 for every query, so its K row is replaced by zeros at
+//     staging (the LDS-DMA source of its chunks is a zero chunk) and the scores need no mask work at all.  BERT fixed-length
+//     rows: mask bits (one uint32 per 32-key block) -> -inf, two VALU ops per score, before the running max.  Packed rows
+//     hold visible keys only.  Padded keys (>= T): -inf.
+//   * online soft-max with a lazily raised reference max (rescale only when a block beats it by 2^8), Q fragments requested
+//     before the K/V staging, 16-byte output pieces built by a lane-half swap.
 //   * the S^T accumulator tile, converted to bf16, is directly the B operand of the PV product
 //     O^T += V^T·P^T (no LDS round trip); V^T fragments come from the row-major V image through
 //     ds_read_b64_tr_b16.
@@ -40,11 +44,130 @@ struct AttnArgs {
     char* ctx;        // [R, T, H]
     int R, T, H, heads, share, mode, Tw, Tp, nq;
     float pdrop; uint32_t seed;  // fp32 training forward only
+    int dbg;          // dev ablations (AG_ATTN_DBG): 1 = no compute, 2 = no K/V staging, 4 = no stores, 8 = phase stamps
+    unsigned long long* stamps;  // [workgroup][wave][4] s_memrealtime (100 MHz) when dbg & 8
     const int* cu;    // packed (token-pruned) sequences: row r owns tokens [cu[r], cu[r+1]) of qkv / ctx, all visible; else null
 };
 
-template <int MODE>
-__global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
+// 16 zero bytes: the LDS-DMA source of every K chunk of a ViT-masked key (see the staging loop)
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+// One 32-key block of the online soft-max for one 32-query block.  kbyte = byte offset of the key block inside the K / V
+// images (a literal in the unrolled form: it lands in the ds_read offset field).  voff carries the V image base.
+//   * MASKOPS (BERT fixed-length rows only): masked logit := -inf, two VALU ops per score.  ViT rows need none: a masked
+//     key's K row was zeroed at staging, so its logit is exactly +0.0 and it still competes in the soft-max, as
+//     reference vanilla_vit.py:454 (scores * mask) has it.  Packed rows hold visible keys only.
+//   * keys >= T (ragged last block, wave-uniform branch): -inf.
+//   * the running max is raised only when a block beats it by more than TAU (2^8 in probability): the accumulators are
+//     rescaled a handful of times per row instead of every block; l and O always share the same reference max, so the
+//     quotient O/l is unchanged (probabilities up to 2^8 in between are exact in bf16's relative precision).
+// S^T tile of one 32-key block: four 32x32x16 MFMAs over the 64-wide head dim (K fragments by rows from the K image)
+__device__ __forceinline__ f32x16_t attn_scores(const char* smem, const int kbyte, const int (&koff)[4], const uint4 (&qf)[4]) {
+    f32x16_t s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(smem + koff[ks] + kbyte);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s, 0, 0, 0);
+    }
+    return s;
+}
+
+template <int MODE, bool MASKOPS, bool FIRST, bool FENCE = true>
+__device__ __forceinline__ void attn_softmax_pv(f32x16_t s, const char* smem, const int kbyte, const int (&voff)[2][2],
+                                                f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run,
+                                                const uint32_t mw, const int kvalid, const int lh, const float c2) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+    // key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh
+    if (MASKOPS) {
+        const uint32_t mwl = mw >> (4 * lh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
+            s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
+        }
+    }
+    if (kvalid < 32) {  // wave-uniform
+        const uint32_t vwl = ((1u << kvalid) - 1u) >> (4 * lh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vwl, kk, 1);
+            s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
+        }
+    }
+    float bmax = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) bmax = fmaxf(bmax, s[i]);
+    {   // both lane halves hold the same query: combine their maxima (VALU half-swap, no LDS)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+        bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (FIRST) {
+        m_run = bmax;       // O = 0, l = 0: nothing to rescale
+    } else {
+        const float TAU = 8.0f / c2;   // raw-score units
+        const bool need = bmax > m_run + TAU;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform; rare after the first blocks
+            const float m_new = need ? bmax : m_run;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+    }
+    const float mc = -m_run * c2;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c2, mc));  // raw v_exp_f32; -inf logits give exactly 0
+        s[i] = pv;
+        psum += pv;
+    }
+    l_run += psum;
+    // P^T fragments: regs 8st..8st+7 -> k-step st; element j <-> key 16st + 8(j>>2) + 4lh + (j&3)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        uint4 pf;
+        pf.x = pack_bf16x2(s[8 * st + 0], s[8 * st + 1]);
+        pf.y = pack_bf16x2(s[8 * st + 2], s[8 * st + 3]);
+        pf.z = pack_bf16x2(s[8 * st + 4], s[8 * st + 5]);
+        pf.w = pack_bf16x2(s[8 * st + 6], s[8 * st + 7]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            // V^T fragments via transposed reads (16-lane group g: d cols 16(g&1)+i, key half g>>1); k-step st is +2048 B
+            const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + voff[dt][0] + kbyte + 2048 * st));
+            const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + voff[dt][1] + kbyte + 2048 * st));
+            const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+            if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
+            else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o1, 0, 0, 0);
+        }
+    }
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled blocks from being interleaved into a spilling schedule
+}
+
+template <int MODE, bool MASKOPS, bool FIRST>
+__device__ __forceinline__ void attn_block(const char* smem, const int kbyte, const int (&koff)[4], const int (&voff)[2][2],
+                                           const uint4 (&qf)[4], f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run,
+                                           const uint32_t mw, const int kvalid, const int lh, const float c2) {
+    const f32x16_t s = attn_scores(smem, kbyte, koff, qf);
+    attn_softmax_pv<MODE, MASKOPS, FIRST>(s, smem, kbyte, voff, o0, o1, m_run, l_run, mw, kvalid, lh, c2);
+}
+
+#define ATTN_STAMP(i)                                                                                   \
+    if (p.dbg & 8) {                                                                                    \
+        unsigned long long t_;                                                                          \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        if (lane == 0) p.stamps[((long)blockIdx.x * 8 + wave) * 4 + (i)] = t_;                          \
+    }
+
+// NKB > 0: the key-block loop is unrolled for exactly NKB blocks (ViT's 197 tokens = 7 blocks); NKB = 0: runtime loop.
+template <int MODE, bool MASKOPS, int NKB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bf16_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,18 +189,39 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     const char* qbase = p.qkv + tok_in * rowstride + (long)head * HD * 2;
     const char* kbase = qbase + (long)p.H * 2;
     const char* vbase = qbase + (long)2 * p.H * 2;
+    // this row's mask words: lane w holds word w (Tw <= 16), fetched once; v_readlane per key block
+    const uint32_t mwords = p.cu ? 0xFFFFFFFFu : (lane < p.Tw ? p.mask[(long)row * p.Tw + lane] : 0u);
+
+    ATTN_STAMP(0)
+    const int lr = lane & 31, lh = lane >> 5;
+    // Q fragments of this wave's first query block (B operand: lane holds Q[q][16ks + 8lh .. +8]) are requested BEFORE the
+    // K/V staging so that their HBM round trip rides under it
+    uint4 qf[4];
+    {
+        const int q0 = wave * 32 + lr;
+        const int qc0 = q0 < nq ? q0 : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const uint4*>(qbase + (long)qc0 * rowstride + (2 * ks + lh) * 16);
+    }
 
     // ---- stage K, V by LDS-DMA: 8-row x 128-B pieces (whole cache lines), the slot swizzle applied on the
     // per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= T are clamped to row T-1 (finite
-    // data; those keys get weight exactly 0 below), never out-of-bounds.
+    // data; those keys get weight exactly 0 below), never out-of-bounds.  ViT: the K chunks of a masked key are
+    // fetched from a zero chunk instead, which makes its logit exactly +0.0 for every query.
     {
         const int npieces = Tp >> 3;
         const int r_in = lane >> 3, slot = lane & 7;
-        for (int pc = wave; pc < npieces; pc += nwaves) {
+        for (int pc = wave; pc < ((p.dbg & 2) ? 0 : npieces); pc += nwaves) {
             const int r = pc * 8 + r_in;
             const int rc = r < T ? r : T - 1;
             const long src = (long)rc * rowstride + ((slot ^ swz(r)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + src),
+            const char* ksrc = kbase + src;
+            if (MODE == AG_MASK_VIT_MUL) {
+                const uint32_t w = __builtin_amdgcn_readlane(mwords, pc >> 2);
+                if (!((w >> (r & 31)) & 1u)) ksrc = reinterpret_cast<const char*>(g_zero_chunk);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
                                              (__attribute__((address_space(3))) void*)(ldsK + pc * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + src),
                                              (__attribute__((address_space(3))) void*)(ldsV + pc * 1024), 16, 0, 0);
@@ -85,13 +229,10 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ATTN_STAMP(1)
 
     const int nkb = Tp >> 5;             // 32-key blocks
-    const int nqb = (nq + 31) >> 5;      // 32-query blocks
-    const int lr = lane & 31, lh = lane >> 5;
-    // this row's mask words: lane w holds word w (Tw <= 16), fetched once; v_readlane per key block
-    const uint32_t* mrow = p.mask + (long)row * p.Tw;
-    const uint32_t mwords = p.cu ? 0xFFFFFFFFu : (lane < p.Tw ? mrow[lane] : 0u);
+    const int nqb = (p.dbg & 1) ? 0 : (nq + 31) >> 5;      // 32-query blocks
     // soft-max in base 2 on the raw scores: p = exp2(s*c - m*c), c = log2(e)/sqrt(64); the 1/sqrt(d) scale
     // (exact power of two) is order-preserving, so the running max is tracked on the raw scores.
     const float c2 = 0.125f * 1.4426950408889634f;
@@ -100,114 +241,56 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
     int koff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = lr * ROWB + (((2 * ks + lh) ^ swz(lr)) << 4);
-    int voff[2][2][2];  // [k-step][d tile][first/second 4-key group]
+    int voff[2][2];  // [d tile][first/second 4-key group], V image base included; k-step 1 is +2048 B
     {
         const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const int k0 = 16 * st + 4 * (g >> 1) + tq, k1 = k0 + 8;
-                const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
-                voff[st][dt][0] = k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
-                voff[st][dt][1] = k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
-            }
+        for (int dt = 0; dt < 2; ++dt) {
+            const int k0 = 4 * (g >> 1) + tq, k1 = k0 + 8;
+            const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
+            voff[dt][0] = Tp * ROWB + k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
+            voff[dt][1] = Tp * ROWB + k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
+        }
     }
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
 
     for (int qb = wave; qb < nqb; qb += nwaves) {
         int q = qb * 32 + lr;
         const bool qvalid = q < nq;
         const int qc = qvalid ? q : T - 1;
-        uint4 qf[4];  // Q fragments (B operand): lane holds Q[q][16ks + 8lh .. +8]
+        if (qb != wave) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            qf[ks] = *reinterpret_cast<const uint4*>(qbase + (long)qc * rowstride + (2 * ks + lh) * 16);
+            for (int ks = 0; ks < 4; ++ks)
+                qf[ks] = *reinterpret_cast<const uint4*>(qbase + (long)qc * rowstride + (2 * ks + lh) * 16);
+        }
 
         f32x16_t o0, o1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
         float m_run = NEG_BIG, l_run = 0.f;
 
-        for (int kb = 0; kb < nkb; ++kb) {
-            const char* kblk = ldsK + kb * (32 * ROWB);
-            const char* vblk = ldsV + kb * (32 * ROWB);
-            f32x16_t s;
+        if (NKB > 0) {
+            attn_block<MODE, MASKOPS, true>(smem, 0, koff, voff, qf, o0, o1, m_run, l_run,
+                                            MASKOPS ? __builtin_amdgcn_readlane(mwords, 0) : 0u, NKB == 1 ? T : 32, lh, c2);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            for (int kb = 1; kb < NKB; ++kb)
+                attn_block<MODE, MASKOPS, false>(smem, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run,
+                                                 MASKOPS ? __builtin_amdgcn_readlane(mwords, kb) : 0u,
+                                                 kb == NKB - 1 ? T - kb * 32 : 32, lh, c2);
+        } else {
+            int ko[4], vo[2][2];   // walked by one key block per iteration
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kblk + koff[ks]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                            __builtin_bit_cast(bf16x8_t, qf[ks]), s, 0, 0, 0);
-            }
-            // Key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh — it depends on the lane only through lh, so
-            // the mask select uses a scalar-built 64-bit lane mask (low half: bit kk, high half: bit kk+4):
-            // one v_cndmask per score.  ViT: masked logit := 0 (still competes in the soft-max);
-            // BERT: masked logit := -inf.  Keys >= T (last block only): -inf in both modes.
-            // Key of register i: kb*32 + (i&3) + 8*(i>>2) + 4*lh.  The row's mask word is shifted per lane half
-            // once, then each score takes two VALU ops: v_bfe_i32 (bit -> 0 / ~0) and a bitwise select.
-            // ViT: masked logit := +0.0 (it still competes in the soft-max); BERT: masked logit := -inf;
-            // keys >= T (ragged last block only): -inf in both modes.
-            const uint32_t mw = __builtin_amdgcn_readlane(mwords, kb);
-            const uint32_t mwl = mw >> (4 * lh);
-            const int kvalid = T - kb * 32;
-            float bmax = NEG_BIG;
+            for (int ks = 0; ks < 4; ++ks) ko[ks] = koff[ks];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kk = (i & 3) + 8 * (i >> 2);
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
-                const uint32_t sb = __float_as_uint(s[i]);
-                s[i] = __uint_as_float(MODE == AG_MASK_VIT_MUL ? (sb & m) : ((sb & m) | (NEG_BIG_BITS & ~m)));
-            }
-            if (kvalid < 32) {  // wave-uniform
-                const uint32_t vwl = ((1u << kvalid) - 1u) >> (4 * lh);
+            for (int dt = 0; dt < 2; ++dt) { vo[dt][0] = voff[dt][0]; vo[dt][1] = voff[dt][1]; }
+            attn_block<MODE, MASKOPS, true>(smem, 0, ko, vo, qf, o0, o1, m_run, l_run,
+                                            MASKOPS ? __builtin_amdgcn_readlane(mwords, 0) : 0u, T, lh, c2);
+            for (int kb = 1; kb < nkb; ++kb) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kk = (i & 3) + 8 * (i >> 2);
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)vwl, kk, 1);
-                    s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
-                }
-            }
+                for (int ks = 0; ks < 4; ++ks) ko[ks] += 32 * ROWB;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bmax = fmaxf(bmax, s[i]);
-            {   // both lane halves hold the same query: combine their maxima (VALU half-swap, no LDS)
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
-                bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            const float m_new = fmaxf(m_run, bmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            const float mc = -m_new * c2;
-            float psum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c2, mc));  // raw v_exp_f32; -inf logits give exactly 0
-                s[i] = pv;
-                psum += pv;
-            }
-            l_run = fmaf(l_run, alpha, psum);
-            m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-
-            // P^T fragments: regs 8s..8s+7 -> k-step s; element j <-> key 16s + 8(j>>2) + 4lh + (j&3)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                uint4 pf;
-                pf.x = pack_bf16x2(s[8 * st + 0], s[8 * st + 1]);
-                pf.y = pack_bf16x2(s[8 * st + 2], s[8 * st + 3]);
-                pf.z = pack_bf16x2(s[8 * st + 4], s[8 * st + 5]);
-                pf.w = pack_bf16x2(s[8 * st + 6], s[8 * st + 7]);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    // V^T fragments via transposed reads (16-lane group g: d cols 16(g&1)+i, key half g>>1)
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + voff[st][dt][0]));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vblk + voff[st][dt][1]));
-                    const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
-                    else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o1, 0, 0, 0);
-                }
+                for (int dt = 0; dt < 2; ++dt) { vo[dt][0] += 32 * ROWB; vo[dt][1] += 32 * ROWB; }
+                attn_block<MODE, MASKOPS, false>(smem, 0, ko, vo, qf, o0, o1, m_run, l_run,
+                                                 MASKOPS ? __builtin_amdgcn_readlane(mwords, kb) : 0u, T - kb * 32, lh, c2);
             }
         }
         float l_tot;
@@ -216,17 +299,28 @@ __global__ __launch_bounds__(512) void attn_bf16_kernel(AttnArgs p) {
             l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
         const float inv = 1.0f / l_tot;
-        if (qvalid) {
+        ATTN_STAMP(2)
+        // accumulator regs 4g..4g+3 of lane (lr, lh) are d rows 8g + 4lh .. +3: a half-swap pairs them into 16-byte
+        // pieces (lane half 0: d 16j .. 16j+7, half 1: d 16j+8 .. 16j+15), four 16-byte stores per lane
+        uint4 piece[4];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const int g = 2 * (tj & 1);
+            const f32x16_t& o = tj < 2 ? o0 : o1;
+            const uint32_t x0 = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv), x1 = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            const uint32_t y0 = pack_bf16x2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), y1 = pack_bf16x2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            piece[tj] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        if (qvalid && !(p.dbg & 4)) {
             char* out = p.ctx + (tok_out + q) * p.H * 2 + (long)head * HD * 2;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = 8 * g4 + 4 * lh;  // within a 32-wide d tile
-                *reinterpret_cast<uint2*>(out + d * 2) =
-                    make_uint2(pack_bf16x2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv), pack_bf16x2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv));
-                *reinterpret_cast<uint2*>(out + (32 + d) * 2) =
-                    make_uint2(pack_bf16x2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv), pack_bf16x2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv));
-            }
+            for (int tj = 0; tj < 4; ++tj)
+                *reinterpret_cast<uint4*>(out + (tj >> 1) * 64 + (tj & 1) * 32 + lh * 16) = piece[tj];
         }
+        if (p.dbg & 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        ATTN_STAMP(3)
     }
 }
 
@@ -504,16 +598,43 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         static const int waves_env = getenv("AG_ATTN_WAVES") ? atoi(getenv("AG_ATTN_WAVES")) : 0;
         if (waves_env > 0 && nwaves > waves_env) nwaves = waves_env;
         if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_VIT_MUL>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_kernel<AG_MASK_BERT_ADD>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
+        // ViT: masked keys are zeroed K rows (no per-score mask work), 7 key blocks (T = 197) unrolled;
+        // BERT fixed-length rows: per-score -inf; packed rows: visible keys only
+        void (*kern)(AttnArgs);
+        if (mask_mode == AG_MASK_VIT_MUL && !a.cu) kern = a.Tp == 224 ? attn_bf16_kernel<AG_MASK_VIT_MUL, false, 7> : attn_bf16_kernel<AG_MASK_VIT_MUL, false, 0>;
+        else if (a.cu) kern = attn_bf16_kernel<AG_MASK_BERT_ADD, false, 0>;
+        else kern = attn_bf16_kernel<AG_MASK_BERT_ADD, true, 0>;
+        AG_REQUIRE(!(mask_mode == AG_MASK_VIT_MUL && a.cu), "masked attention: packed rows are a BERT-mode path");
+        if (lds > 64 * 1024)
+            AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t lds_k = lds;
+        if (a.dbg & 8) {   // dev: per-workgroup phase stamps, summarised on stderr
+            AttnArgs b = a;
+            const size_t nst = (size_t)a.R * a.heads * 8 * 4;
+            AG_HIP_CHECK(hipMalloc(&b.stamps, nst * 8));
+            AG_HIP_CHECK(hipMemsetAsync(b.stamps, 0, nst * 8, s));
+            hipLaunchKernelGGL(kern, dim3(a.R * a.heads), dim3(nwaves * 64), lds_k, s, b);
+            AG_HIP_CHECK(hipStreamSynchronize(s));
+            unsigned long long* h = (unsigned long long*)malloc(nst * 8);
+            AG_HIP_CHECK(hipMemcpy(h, b.stamps, nst * 8, hipMemcpyDeviceToHost));
+            double ph[3] = {0, 0, 0}, life = 0; long n = 0; unsigned long long tmin = ~0ull, tmax = 0;
+            for (long wg = 0; wg < (long)a.R * a.heads; ++wg) {
+                unsigned long long w0 = ~0ull, w3 = 0;
+                for (int w = 0; w < nwaves; ++w) {
+                    const unsigned long long* t = h + (wg * 8 + w) * 4;
+                    if (!t[0] || !t[3]) continue;
+                    ph[0] += t[1] - t[0]; ph[1] += t[2] - t[1]; ph[2] += t[3] - t[2]; ++n;
+                    if (t[0] < w0) w0 = t[0];
+                    if (t[3] > w3) w3 = t[3];
+                }
+                if (w3) { life += w3 - w0; if (w0 < tmin) tmin = w0; if (w3 > tmax) tmax = w3; }
+            }
+            fprintf(stderr, "[attn stamps] waves %ld: stage %.2f us | compute %.2f us | store %.2f us | wg life %.2f us | kernel %.1f us\n",
+                    n, ph[0] / n * 0.01, ph[1] / n * 0.01, ph[2] / n * 0.01, life / ((double)a.R * a.heads) * 0.01, (tmax - tmin) * 0.01);
+            free(h); AG_HIP_CHECK(hipFree(b.stamps));
+            return AG_OK;
         }
-        if (mask_mode == AG_MASK_VIT_MUL) hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_VIT_MUL>, dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
-        else hipLaunchKernelGGL(attn_bf16_kernel<AG_MASK_BERT_ADD>, dim3(a.R * a.heads), dim3(nwaves * 64), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.R * a.heads), dim3(nwaves * 64), lds_k, s, a);
     } else if (dtype == AG_F32) {
         return launch_valu<float>(a, hd, s);
     } else if (hd == 8 && !getenv("AG_ATTN_VALU")) {
@@ -544,6 +665,8 @@ extern "C" int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bit
     a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32;
     a.nq = (n_query > 0 && n_query < T) ? n_query : T;
     a.pdrop = 0.f; a.seed = 0; a.cu = nullptr;
+    static const int dbg_env = getenv("AG_ATTN_DBG") ? atoi(getenv("AG_ATTN_DBG")) : 0;
+    a.dbg = dbg_env; a.stamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == AG_BF16 ? 2.0 : 4.0;
     AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)a.nq * T * H,
@@ -564,7 +687,7 @@ extern "C" int ag_masked_attention_varlen(const void* d_qkv, const int* d_cu_seq
     a.R = R; a.T = t_max; a.H = H; a.heads = heads; a.share = 1; a.mode = AG_MASK_BERT_ADD;
     a.Tw = (t_max + 31) / 32; a.Tp = a.Tw * 32;
     a.nq = cls_only ? 1 : t_max;
-    a.pdrop = 0.f; a.seed = 0; a.cu = d_cu_seqlens;
+    a.pdrop = 0.f; a.seed = 0; a.cu = d_cu_seqlens; a.dbg = 0; a.stamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype == AG_BF16 ? 2.0 : 4.0;
     // work is data dependent: account the dense bound scaled by 1/4 (half the keys x half the queries on Shapley masks)
@@ -581,6 +704,6 @@ extern "C" int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_m
     AttnArgs a;
     a.qkv = (const char*)d_qkv; a.mask = d_mask_bits; a.ctx = (char*)d_ctx;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.share = 1; a.mode = mask_mode;
-    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed; a.cu = nullptr;
+    a.Tw = (T + 31) / 32; a.Tp = a.Tw * 32; a.nq = T; a.pdrop = p_drop; a.seed = seed; a.cu = nullptr; a.dbg = 0; a.stamps = nullptr;
     return launch_valu<float>(a, H / heads, (hipStream_t)stream);
 }

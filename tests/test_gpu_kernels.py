@@ -141,6 +141,13 @@ def test_masked_attention(cuda_device, dtype, mode, t, heads, rows, share, n_que
     _attention_case(cuda_device, dtype, mode, t, heads, rows, share, n_query, seed=t * 7 + heads)
 
 
+@pytest.mark.parametrize("t,heads,rows,share,n_query", [(197, 12, 56, 1, 0), (197, 12, 64, 8, 0), (100, 6, 96, 2, 0), (230, 4, 130, 1, 1)])
+def test_masked_attention_many_items(cuda_device, t, heads, rows, share, n_query):
+    """many (row, head) workgroups with every mask density: T = 197 runs the 7-block unrolled ViT kernel (masked keys =
+    zeroed K rows), other T the runtime loop; shared layer-0 rows; CLS-only queries."""
+    _attention_case(cuda_device, BF16, 0, t, heads, rows, share, n_query, seed=t + rows)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("d,t,heads,rows,share", [(8, 197, 12, 3, 1), (8, 128, 3, 4, 2), (16, 65, 2, 2, 1), (32, 197, 1, 2, 1)])
