@@ -58,6 +58,49 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_kernel(int iters, int zero,
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// the same measurement with v_mfma_f32_32x32x16_bf16 (2x2 tiles, 4 independent accumulators): same FLOPs per iteration
+// per wave as four 16x16x32 rows of the kernel above would be -> iters are scaled by the caller
+__global__ __launch_bounds__(512, 2) void mfma_probe32_kernel(int iters, int zero, float* sink, unsigned long long* clocks) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fa[i] = make_uint4(rand_bf16x2(gid * 64 + i * 8 + 0, zero), rand_bf16x2(gid * 64 + i * 8 + 1, zero),
+                           rand_bf16x2(gid * 64 + i * 8 + 2, zero), rand_bf16x2(gid * 64 + i * 8 + 3, zero));
+        fb[i] = make_uint4(rand_bf16x2(gid * 64 + i * 8 + 4, zero), rand_bf16x2(gid * 64 + i * 8 + 5, zero),
+                           rand_bf16x2(gid * 64 + i * 8 + 6, zero), rand_bf16x2(gid * 64 + i * 8 + 7, zero));
+    }
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    unsigned long long c0, c1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                        __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 123456.789f) sink[0] = s;
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 }  // namespace
 
 extern "C" int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream) {
@@ -75,9 +118,12 @@ extern "C" int ag_probe_mfma(int iters, int zero_operands, double* tflops, doubl
     AG_HIP_CHECK(hipEventCreate(&e0));
     AG_HIP_CHECK(hipEventCreate(&e1));
     // warm the clocks / reach the sustained power state, then measure
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(512), 0, s, iters, zero_operands, sink, clocks);
+    // zero_operands: bit 0 = all-zero operands, bit 1 = v_mfma_f32_32x32x16_bf16 instead of 16x16x32 (same FLOPs per iteration)
+    void (*kern)(int, int, float*, unsigned long long*) = (zero_operands & 2) ? mfma_probe32_kernel : mfma_probe_kernel;
+    const int zero = zero_operands & 1;
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, iters, zero, sink, clocks);
     AG_HIP_CHECK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(512), 0, s, iters, zero_operands, sink, clocks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, s, iters, zero, sink, clocks);
     AG_HIP_CHECK(hipEventRecord(e1, s));
     AG_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
