@@ -287,8 +287,9 @@ int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
  * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per
  * wave — the power-capped MFMA ceiling — and the effective shader clock during it (s_memtime ticks against
- * the constant 100 MHz s_memrealtime).  zero_operands != 0 runs the same loop on all-zero operands (no
- * data-dependent switching power).  Synchronous.  No reference counterpart. */
+ * the constant 100 MHz s_memrealtime).  zero_operands is a flag word: bit 0 runs the same loop on all-zero operands (no
+ * data-dependent switching power), bit 1 issues v_mfma_f32_32x32x16_bf16 instead (same FLOPs per iteration).
+ * Synchronous.  No reference counterpart. */
 int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream);
 
 #ifdef __cplusplus

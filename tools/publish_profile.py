@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Copy a profiling round from gpurun_out/ into profiles/ and refresh profiles/traffic.json (what bench.py reports as
+roofline.traffic).  usage: publish_profile.py <tag> <workload> <batch> <masks>   e.g.  r01_h vit_base 48 32"""
+import glob, json, os, shutil, sys
+
+tag, workload, batch, masks = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+suffix = f"{workload}_B{batch}_K{masks}"
+stats = glob.glob(os.path.join(go, f"prof_{tag}", "stats", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(pr, f"{tag}_kernel_stats_{suffix}.csv"))
+summ = json.load(open(os.path.join(go, f"prof_{tag}_summary.json")))
+json.dump(summ, open(os.path.join(pr, f"{tag}_pmc_summary_{suffix}.json"), "w"), indent=1)
+# bench.py kernel labels <- profiled kernel names (bf16 ViT hot path: LN-folded QKV / fc1+GELU, residual GEMMs with row stats)
+names = {"gemm<bias>": "gemm_ring_kernel<0, 1, false>", "gemm<bias+gelu>": "gemm_ring_kernel<1, 1, false>",
+         "gemm<bias+residual>": "gemm_ring_kernel<2, 2, false>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
+attn = [k for k in summ if k.startswith("attn_bf16_kernel")]
+if attn:
+    names["masked_attention"] = attn[0]
+out = {"workload": workload, "batch": batch, "masks": masks, "precision": "bf16",
+       "source": f"profiles/{tag}_pmc_summary_{suffix}.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
+                 "bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per MI355X_MICROARCH.md HBM section)",
+       "traffic_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
+for label, k in names.items():
+    if k in summ:
+        for f in ("traffic_bytes_per_launch", "l2_hit_rate", "mfma_busy_frac"):
+            if f in summ[k]:
+                out[f][label] = summ[k][f]
+json.dump(out, open(os.path.join(pr, "traffic.json"), "w"), indent=1)
+print(json.dumps(out["traffic_bytes_per_launch"]))
