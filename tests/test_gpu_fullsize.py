@@ -1,0 +1,110 @@
+"""BASELINE.json full-size configurations (ViT-base K=32 bf16; BERT-base L=128 K=32), checked through properties that do not
+need an oracle run at that size: the hot path must be invariant to how the (input x mask) rows are sharded, batched and
+ordered, an all-visible mask must reproduce the unmasked forward, and the Shapley normalisation must be efficient.
+
+Not bit-exact by design where noted: the LayerNorm-fold row statistics are accumulated with float atomics (order varies
+between launches), which moves a bf16 activation by one rounding step here and there; twelve random-init layers carry that
+to a few 1e-3 on the output probabilities, while a row mix-up shows up at >= 5e-2 (asserted below)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+K = 32
+TOL = 2e-2   # bf16 mode, 12 layers, random-init weights: the tolerance of the bf16-vs-reference model tests (test_gpu_models.py)
+
+
+def _setup(workload, dev, batch, seed=0):
+    import bench
+    from autognothi_amd import engine
+    from autognothi_amd.recipes import get_recipe
+    from autognothi_amd.utils import synth
+    kind, params, _ = bench.WORKLOADS[workload]
+    recipe = get_recipe(kind)
+    cfg = recipe.t_config(**params)
+    engine.set_precision("bf16")
+    m = recipe.t_surrogate(cfg)
+    synth.load_synth_weights(m, seed=0)
+    m = m.to(dev).eval()
+    if kind.endswith("vit"):
+        xs = synth.synth_images(batch, params["img_px_size"], params["img_channels"], seed=seed)
+    else:
+        xs = synth.synth_token_ids(batch, params["max_position_embeddings"], params["vocab_size"], seed=seed)
+    return recipe, cfg, m, torch.from_numpy(xs).to(dev)
+
+
+def _probs(recipe, model, xs, mask):
+    with torch.no_grad():
+        v, _ = recipe.fw_surrogate(model, xs, mask)
+    return v.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("workload", ["vit_base", "bert_base"])
+def test_sharding_and_order_invariance(cuda_device, workload):
+    """rows shard by input across ranks: forwarding inputs [0:2] and [2:4] separately, or the inputs in reverse
+    order, gives the joint result; so does a permutation of the K masks of an input (the outputs permute with them)."""
+    from autognothi_amd import ops
+    recipe, cfg, m, xs = _setup(workload, cuda_device, 4)
+    P = recipe.n_players(cfg)
+    rng = ops.DeviceMT19937(cuda_device, 11)
+    masks, _ = ops.mask_shapley_new(rng, 4 * K, P, want_i64=True, want_bits=False)
+    joint = _probs(recipe, m, xs, masks)
+    assert joint.shape == (4 * K, cfg.num_labels) and np.isfinite(joint).all()
+    np.testing.assert_allclose(joint.sum(-1), 1.0, atol=1e-3)
+    halves = np.concatenate([_probs(recipe, m, xs[:2], masks[:2 * K]), _probs(recipe, m, xs[2:], masks[2 * K:])])
+    np.testing.assert_allclose(halves, joint, rtol=0, atol=TOL)
+    rev = _probs(recipe, m, xs.flip(0), masks.view(4, K, P).flip(0).reshape(4 * K, P))
+    np.testing.assert_allclose(rev.reshape(4, K, -1)[::-1].reshape(4 * K, -1), joint, rtol=0, atol=TOL)
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(5)).to(cuda_device)
+    shuffled = _probs(recipe, m, xs, masks.view(4, K, P)[:, perm].reshape(4 * K, P))
+    np.testing.assert_allclose(shuffled, joint.reshape(4, K, -1)[:, perm.cpu().numpy()].reshape(4 * K, -1), rtol=0, atol=TOL)
+    # masks matter: the K rows of an input are not all alike
+    assert float(np.abs(joint.reshape(4, K, -1) - joint.reshape(4, K, -1)[:, :1]).max()) > 5e-2
+    assert float(np.abs(joint.reshape(4, K, -1)[0] - joint.reshape(4, K, -1)[1]).max()) > 5e-2   # and so do inputs
+
+
+@pytest.mark.parametrize("workload", ["vit_base", "bert_base"])
+def test_all_visible_equals_single_unmasked_forward(cuda_device, workload):
+    """K all-ones masks (layer-0 sharing, and for BERT the token-pruned path with nothing pruned) == the K=1 forward."""
+    recipe, cfg, m, xs = _setup(workload, cuda_device, 3, seed=1)
+    P = recipe.n_players(cfg)
+    ones = torch.ones((3 * K, P), dtype=torch.int64, device=cuda_device)
+    many = _probs(recipe, m, xs, ones).reshape(3, K, -1)
+    single = _probs(recipe, m, xs, ones[:3])
+    np.testing.assert_allclose(many, np.repeat(single[:, None], K, axis=1), rtol=0, atol=TOL)
+
+
+def test_bert_pruned_equals_unpruned_full_size(cuda_device):
+    """token pruning against the same kernels without it, at BERT-base L=128 K=32."""
+    from autognothi_amd import engine, ops
+    recipe, cfg, m, xs = _setup("bert_base", cuda_device, 4, seed=2)
+    P = recipe.n_players(cfg)
+    rng = ops.DeviceMT19937(cuda_device, 23)
+    masks, _ = ops.mask_shapley_new(rng, 4 * K, P, want_i64=True, want_bits=False)
+    keep = engine.PRUNE_BERT_TOKENS
+    try:
+        engine.PRUNE_BERT_TOKENS = True
+        a = _probs(recipe, m, xs, masks)
+        engine.PRUNE_BERT_TOKENS = False
+        b = _probs(recipe, m, xs, masks)
+    finally:
+        engine.PRUNE_BERT_TOKENS = keep
+    np.testing.assert_allclose(a, b, rtol=0, atol=TOL)
+
+
+def test_shapley_normalize_full_size_and_efficiency(cuda_device):
+    """ag_shapley_normalize at B=64 inputs x T=197 tokens x C=10 classes against the oracle (numpy, milliseconds at this
+    size), and the reference's efficiency property WITH its quirk (models/shapley.py:82-93 divides by T = P+1 and the CLS
+    row is dropped afterwards): sum_p phi + (adjusted CLS row) == grand - null."""
+    from autognothi_amd import ops
+    from oracle import shapley as osh
+    g = np.random.default_rng(17)
+    pred = g.standard_normal((64, 197, 10)).astype(np.float32) * 0.05
+    grand = g.random((64, 10)).astype(np.float32)
+    null = np.full((1, 10), 0.1, dtype=np.float32)
+    phi = ops.shapley_normalize(torch.from_numpy(pred).to(cuda_device), torch.from_numpy(grand).to(cuda_device),
+                                torch.from_numpy(null).to(cuda_device)).cpu().numpy()          # [B, C, P]
+    ref = osh.normalize_shapley_explanation(pred, grand, null)                                 # [B, T, C]
+    np.testing.assert_allclose(phi, ref[:, 1:].transpose(0, 2, 1), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(phi.sum(-1) + ref[:, 0], grand - null, rtol=0, atol=2e-5)
