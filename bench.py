@@ -167,7 +167,9 @@ def main():
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per explainer training step of the secondary block (0 = skip)")
-    ap.add_argument("--attr-batch", type=int, default=128, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
+    # 220 images x 197 tokens = 170 M-tiles: 510 / 1530 / 2040 tiles for N = 768 / 2304 / 3072 = 1.99 / 5.98 / 7.97 rounds of 256 CUs
+    # (128 images leave 42 % of the second round of the N = 768 GEMMs idle: 6.3 k -> 7.6 k attributions/s)
+    ap.add_argument("--attr-batch", type=int, default=220, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
