@@ -61,6 +61,7 @@ SIGNATURES = {
     "ag_shapley_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "ag_transpose_f32": (i32, [vp, i32, i32, i64, vp, i64, vp]),
+    "ag_transpose_f32_bf16": (i32, [vp, i32, i32, i64, vp, i64, vp]),
     "ag_colsum_f32": (i32, [vp, i32, i32, i64, vp, i32, vp]),
     "ag_gelu_f32": (i32, [vp, vp, i64, vp]),
     "ag_gelu_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
@@ -126,5 +127,29 @@ def ptr(t) -> Optional[int]:
 
 
 def stream() -> int:
+    """raw hipStream_t of torch's current stream on the current device (the C accessors: this runs once per kernel launch)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on(device):
+    """Device guard for a launch: a no-op object when ``device`` is already current (one process per GPU: always, after
+    start-up), ``torch.cuda.device(device)`` otherwise.  torch's own guard costs ~8 us per launch in Python."""
+    import torch
+    idx = device.index if hasattr(device, "index") else device
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NO_GUARD
+    return torch.cuda.device(idx)

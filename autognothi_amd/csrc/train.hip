@@ -26,6 +26,23 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, i
     }
 }
 
+// the same with a bf16 destination (mixed-precision dW operands: transpose and cast in one pass); the WHOLE padded
+// destination [Cc, ldd] is written (zeros beyond R), so the caller needs no memset
+__global__ void transpose_bf16_kernel(const float* __restrict__ src, int R, int Cc, int64_t lds_, bf16_t* __restrict__ dst, int64_t ldd) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = by + i, c = bx + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = bx + i, r = by + tx;
+        if (c < Cc && r < ldd) dst[(int64_t)c * ldd + r] = (bf16_t)(pack_bf16x2(tile[tx][i], 0.f) & 0xFFFFu);
+    }
+}
+
 // ---- column sums: out[n] (+)= sum_m x[m][n] ; block = 64 columns x one row slab (gridDim.y slabs), 4 row lanes ----
 // One slab: plain store / read-modify-write.  Several slabs (tall inputs: a 64-column block alone would walk all M rows
 // on one CU): partial sums are combined with float atomics into an output the launcher zeroed (or that accumulates).
@@ -82,45 +99,91 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ y, const float* __r
     for (int c = lane; c < Cc; c += 64) dx[(int64_t)row * Cc + c] = y[(int64_t)row * Cc + c] * (dy[(int64_t)row * Cc + c] - s);
 }
 
-// LayerNorm backward.  One wave per row: dx; per-block partial dgamma/dbeta written to part[block][2][H].
+// LayerNorm backward.  One wave per row, the row held in registers (NC = H/64 columns per lane, one read of x and dy);
+// dgamma/dbeta partials are carried in registers across the wave's rows and folded once per wave through LDS into
+// part[block][2][H].  NC = 0: any H (<= 4096), columns re-read from L2 and LDS atomics per row.
+template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ dy,
                                                      int rows, int H, float eps, float* __restrict__ dx, float* __restrict__ part) {
     extern __shared__ float sacc[];  // [2][H] per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) sacc[i] = 0.f;
     __syncthreads();
-    for (int row = blockIdx.x * nw + wave; row < rows; row += gridDim.x * nw) {
-        const float* xr = x + (int64_t)row * H;
-        const float* dr = dy + (int64_t)row * H;
-        float s = 0.f;
-        for (int c = lane; c < H; c += 64) s += xr[c];
-        const float mean = wave_sum(s) / (float)H;
-        float sq = 0.f;
-        for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; sq += d * d; }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
-        float a = 0.f, b = 0.f;  // mean(dy*g), mean(dy*g*xhat)
-        for (int c = lane; c < H; c += 64) {
-            const float xh = (xr[c] - mean) * rstd, dg = dr[c] * (g ? g[c] : 1.f);
-            a += dg; b += dg * xh;
+    if (NC > 0) {
+        float gv[NC > 0 ? NC : 1], ag[NC > 0 ? NC : 1], ab[NC > 0 ? NC : 1];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { gv[i] = g ? g[lane + 64 * i] : 1.f; ag[i] = 0.f; ab[i] = 0.f; }
+        for (int row = blockIdx.x * nw + wave; row < rows; row += gridDim.x * nw) {
+            const float* xr = x + (int64_t)row * H;
+            const float* dr = dy + (int64_t)row * H;
+            float xv[NC > 0 ? NC : 1], dv[NC > 0 ? NC : 1];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { xv[i] = xr[lane + 64 * i]; dv[i] = dr[lane + 64 * i]; s += xv[i]; }
+            const float mean = wave_sum(s) / (float)H;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { xv[i] -= mean; sq += xv[i] * xv[i]; }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+            float a = 0.f, b = 0.f;  // mean(dy*g), mean(dy*g*xhat)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) { xv[i] *= rstd; const float dg = dv[i] * gv[i]; a += dg; b += dg * xv[i]; }
+            a = wave_sum(a) / (float)H; b = wave_sum(b) / (float)H;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                dx[(int64_t)row * H + lane + 64 * i] = rstd * (dv[i] * gv[i] - a - xv[i] * b);
+                ag[i] = fmaf(dv[i], xv[i], ag[i]);
+                ab[i] += dv[i];
+            }
         }
-        a = wave_sum(a) / (float)H; b = wave_sum(b) / (float)H;
-        for (int c = lane; c < H; c += 64) {
-            const float xh = (xr[c] - mean) * rstd, dg = dr[c] * (g ? g[c] : 1.f);
-            dx[(int64_t)row * H + c] = rstd * (dg - a - xh * b);
-            atomicAdd(&sacc[c], dr[c] * xh);        // LDS atomics: waves of one block only
-            atomicAdd(&sacc[H + c], dr[c]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {   // LDS atomics: waves of one block only, once per wave
+            atomicAdd(&sacc[lane + 64 * i], ag[i]);
+            atomicAdd(&sacc[H + lane + 64 * i], ab[i]);
+        }
+    } else {
+        for (int row = blockIdx.x * nw + wave; row < rows; row += gridDim.x * nw) {
+            const float* xr = x + (int64_t)row * H;
+            const float* dr = dy + (int64_t)row * H;
+            float s = 0.f;
+            for (int c = lane; c < H; c += 64) s += xr[c];
+            const float mean = wave_sum(s) / (float)H;
+            float sq = 0.f;
+            for (int c = lane; c < H; c += 64) { const float d = xr[c] - mean; sq += d * d; }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+            float a = 0.f, b = 0.f;
+            for (int c = lane; c < H; c += 64) {
+                const float xh = (xr[c] - mean) * rstd, dg = dr[c] * (g ? g[c] : 1.f);
+                a += dg; b += dg * xh;
+            }
+            a = wave_sum(a) / (float)H; b = wave_sum(b) / (float)H;
+            for (int c = lane; c < H; c += 64) {
+                const float xh = (xr[c] - mean) * rstd, dg = dr[c] * (g ? g[c] : 1.f);
+                dx[(int64_t)row * H + c] = rstd * (dg - a - xh * b);
+                atomicAdd(&sacc[c], dr[c] * xh);
+                atomicAdd(&sacc[H + c], dr[c]);
+            }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) part[(int64_t)blockIdx.x * 2 * H + i] = sacc[i];
 }
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int H, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
+// block = 64 columns x 4 partial lanes: each lane walks a quarter of the per-block partials, LDS folds the four
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int H, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate) {
+    __shared__ float sa[4][64], sb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < nblocks; ++i) { a += part[(int64_t)i * 2 * H + c]; b += part[(int64_t)i * 2 * H + H + c]; }
-    dgamma[c] = accumulate ? dgamma[c] + a : a;
-    dbeta[c] = accumulate ? dbeta[c] + b : b;
+    if (c < H)
+        for (int i = q; i < nblocks; i += 4) { a += part[(int64_t)i * 2 * H + c]; b += part[(int64_t)i * 2 * H + H + c]; }
+    sa[q][threadIdx.x & 63] = a; sb[q][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (q == 0 && c < H) {
+        a = (sa[0][threadIdx.x] + sa[1][threadIdx.x]) + (sa[2][threadIdx.x] + sa[3][threadIdx.x]);
+        b = (sb[0][threadIdx.x] + sb[1][threadIdx.x]) + (sb[2][threadIdx.x] + sb[3][threadIdx.x]);
+        dgamma[c] = accumulate ? dgamma[c] + a : a;
+        dbeta[c] = accumulate ? dbeta[c] + b : b;
+    }
 }
 
 // ---- masked attention backward (fp32), head_dim 64, T <= 1024 ---------------------------------------
@@ -300,6 +363,14 @@ extern "C" int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t 
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
+extern "C" int ag_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_dst, int64_t ldd, void* stream) {
+    AG_REQUIRE(d_src && d_dst && rows >= 0 && cols >= 0 && lds >= cols && ldd >= rows, "ag_transpose_f32_bf16: bad arguments");
+    if (rows == 0 || cols == 0) return AG_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(ldd, 32)), dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, lds,
+                       (bf16_t*)d_dst, ldd);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
 extern "C" int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream) {
     AG_REQUIRE(d_x && d_out && M >= 0 && N >= 1, "ag_colsum_f32: bad arguments");
     int slabs = M / 128;                       // >= 128 rows per slab; enough blocks to cover the chip
@@ -351,11 +422,18 @@ extern "C" int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const fl
                                 float* d_dx, float* d_dgamma, float* d_dbeta, int accumulate, float* d_scratch, void* stream) {
     AG_REQUIRE(d_x && d_dy && d_dx && d_scratch && rows >= 0 && H >= 1 && H <= 4096, "ag_layernorm_bwd: bad arguments");
     if (rows == 0) return AG_OK;
-    const int nblocks = rows / 4 + 1 < 128 ? rows / 4 + 1 : 128;  // scratch: nblocks*2*H floats (<= 128*2*H)
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblocks), dim3(256), (size_t)2 * H * 4, (hipStream_t)stream, d_x, d_gamma, d_dy, rows, H, eps, d_dx, d_scratch);
+    const int nblocks = rows / 16 + 1 < 256 ? rows / 16 + 1 : 256;  // >= 4 rows per wave; scratch: nblocks*2*H floats (<= 256*2*H)
+    void (*kern)(const float*, const float*, const float*, int, int, float, float*, float*) = ln_bwd_kernel<0>;
+    switch (H % 64 == 0 ? H / 64 : 0) {   // the hidden sizes of the shipped configurations keep the row in registers
+        case 3: kern = ln_bwd_kernel<3>; break;      // 192 (ViT-tiny)
+        case 12: kern = ln_bwd_kernel<12>; break;    // 768
+        case 16: kern = ln_bwd_kernel<16>; break;    // 1024
+        default: break;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), (size_t)2 * H * 4, (hipStream_t)stream, d_x, d_gamma, d_dy, rows, H, eps, d_dx, d_scratch);
     AG_LAUNCH_CHECK();
     if (d_dgamma && d_dbeta) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream, d_scratch, nblocks, H, d_dgamma, d_dbeta, accumulate);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, (hipStream_t)stream, d_scratch, nblocks, H, d_dgamma, d_dbeta, accumulate);
         AG_LAUNCH_CHECK();
     }
     return AG_OK;

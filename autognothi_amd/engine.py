@@ -171,7 +171,7 @@ class PackedEncoder:
         h0 = h0.contiguous()
         d = self.desc(dtype)
         out = torch.empty((rows, self.T, self.H), dtype=ops.storage_dtype(dtype), device=h0.device)
-        with torch.cuda.device(h0.device):
+        with L.on(h0.device):
             need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
             ws = WORKSPACE.get(h0.device, need)
             if self.kind == L.AG_MASK_BERT_ADD and cls_only_last and len(self.layers) >= 2 and PRUNE_BERT_TOKENS:
@@ -194,7 +194,7 @@ def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype
     x = x.contiguous()
     d = self.desc(dtype)
     out = torch.empty((n_packed, self.H), dtype=ops.storage_dtype(dtype), device=x.device)
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
         ws = WORKSPACE.get(x.device, need)
         L.check(L.lib().ag_bert_layers_forward_packed(C.byref(d), L.ptr(x), L.ptr(cu), rows, n_packed, L.ptr(out), L.ptr(ws),
@@ -205,8 +205,21 @@ def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype
 PackedEncoder.forward_packed = _forward_packed
 
 
+_ONES_BITS = {}
+
+
 def ones_mask_bits(rows: int, n_players: int, device: torch.device) -> Tensor:
-    """Key bits of an all-ones mask [rows, P] with CLS prepended (bits beyond T are zero)."""
+    """Key bits of an all-ones mask [rows, P] with CLS prepended (bits beyond T are zero).  Cached per shape: building it
+    is a pageable host-to-device copy, i.e. a stream synchronisation in the middle of every training step."""
+    key = (rows, n_players, str(device))
+    if key not in _ONES_BITS:
+        if len(_ONES_BITS) > 64:
+            _ONES_BITS.clear()
+        _ONES_BITS[key] = _ones_mask_bits(rows, n_players, device)
+    return _ONES_BITS[key]
+
+
+def _ones_mask_bits(rows: int, n_players: int, device: torch.device) -> Tensor:
     t = n_players + 1
     tw = ops.mask_words(n_players)
     words = []

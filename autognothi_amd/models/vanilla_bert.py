@@ -169,7 +169,7 @@ class VanillaBertModel(nn.Module):
         word = e.word_embeddings.weight.detach().float().contiguous()
         type0 = e.token_type_embeddings.weight.detach().float()[0].contiguous()
         pos = e.position_embeddings.weight.detach().float().contiguous()
-        with torch.cuda.device(ids.device):
+        with L.on(ids.device):
             L.check(L.lib().ag_bert_embed(L.ptr(ids), b, t, c.hidden_size, L.ptr(word), c.vocab_size, L.ptr(type0),
                                           L.ptr(pos), L.ptr(e.LayerNorm.weight.detach().float().contiguous()),
                                           L.ptr(e.LayerNorm.bias.detach().float().contiguous()), c.layer_norm_eps,

@@ -168,7 +168,7 @@ class VanillaViTModel(nn.Module):
         self.packed()
         p, kdim = self.n_players, ch * c.img_patch_size ** 2
         cols = torch.empty((b * p, kdim), dtype=ops.storage_dtype(dtype), device=x.device)
-        with torch.cuda.device(x.device):
+        with L.on(x.device):
             L.check(L.lib().ag_vit_im2col(L.ptr(x), b, ch, hh, c.img_patch_size, L.ptr(cols), dtype, L.stream()))
             w, bias = self._patch.get(dtype)
             pe = ops.gemm(cols, w, bias, L.AG_EPI_BIAS_F32, dtype)

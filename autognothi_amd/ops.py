@@ -36,7 +36,7 @@ class DeviceMT19937:
             self.seed(seed)
 
     def seed(self, seed: int) -> "DeviceMT19937":
-        with torch.cuda.device(self.device):
+        with L.on(self.device):
             L.check(L.lib().ag_mt19937_seed(L.ptr(self.state), seed & 0xFFFFFFFF, L.stream()))
         return self
 
@@ -48,7 +48,7 @@ class DeviceMT19937:
         nxt = int(st[16:24].view(np.uint64)[0])
         mt = np.ascontiguousarray(st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32))
         pos = 624 if left == 1 else nxt  # left==1: the next draw twists first
-        with torch.cuda.device(self.device):
+        with L.on(self.device):
             L.check(L.lib().ag_mt19937_import(L.ptr(self.state), mt.ctypes.data, pos, L.stream()))
         return self
 
@@ -57,7 +57,7 @@ class DeviceMT19937:
         mt = np.zeros(624, dtype=np.uint32)
         import ctypes as C
         pos = C.c_int(0)
-        with torch.cuda.device(self.device):
+        with L.on(self.device):
             L.check(L.lib().ag_mt19937_export(L.ptr(self.state), mt.ctypes.data, C.byref(pos), L.stream()))
         st = (gen.get_state() if gen is not None else torch.get_rng_state()).clone()
         a = st.numpy()
@@ -70,7 +70,7 @@ class DeviceMT19937:
 
     def raw(self, n: int) -> Tensor:
         out = torch.empty(n, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with L.on(self.device):
             L.check(L.lib().ag_mt19937_raw(L.ptr(self.state), L.ptr(out), n, L.stream()))
         return out
 
@@ -103,7 +103,7 @@ def mask_shapley_new(rng: DeviceMT19937, n_mask_samples: int, n_players: int, wa
     mi = torch.empty((n_mask_samples, n_players), dtype=torch.int64, device=dev) if want_i64 else None
     mb = torch.empty((n_mask_samples, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
     scratch = torch.empty(max(1, n_mask_samples // 2 * (n_players + 1)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(L.lib().ag_mask_shapley_new(L.ptr(rng.state), n_mask_samples, n_players, L.ptr(prefix),
                                             L.ptr(mi), L.ptr(mb), L.ptr(scratch), L.stream()))
     return mi, mb
@@ -116,7 +116,7 @@ def mask_purely_uniform(rng: DeviceMT19937, batch: int, n_players: int, want_i64
     mi = torch.empty((batch, n_players), dtype=torch.int64, device=dev) if want_i64 else None
     mb = torch.empty((batch, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
     scratch = torch.empty(max(1, batch * (n_players + 1)), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with L.on(dev):
         L.check(L.lib().ag_mask_purely_uniform(L.ptr(rng.state), batch, n_players, L.ptr(mi), L.ptr(mb),
                                                L.ptr(scratch), L.stream()))
     return mi, mb
@@ -131,7 +131,7 @@ def pack_mask(mask_i64: Tensor) -> Tensor:
         m = m.to(torch.int64)
     rows, p = m.shape
     bits = torch.empty((rows, mask_words(p)), dtype=torch.int32, device=m.device)
-    with torch.cuda.device(m.device):
+    with L.on(m.device):
         L.check(L.lib().ag_pack_mask(L.ptr(m), rows, p, L.ptr(bits), L.stream()))
     return bits
 
@@ -144,7 +144,7 @@ def perturbed_masks(attr: Tensor, steps: int, mask_base: int) -> Tuple[Tensor, T
     s = min(p, steps)
     stops = torch.empty(s, dtype=torch.int64, device=a.device)
     masks = torch.empty((n_attr, s, p), dtype=torch.int64, device=a.device)
-    with torch.cuda.device(a.device):
+    with L.on(a.device):
         L.check(L.lib().ag_perturbed_masks(L.ptr(a), n_attr, p, steps, mask_base, L.ptr(stops), L.ptr(masks), L.stream()))
     return stops, masks
 
@@ -154,7 +154,7 @@ def cast(src: Tensor, dtype: int) -> Tensor:
     L.require_gpu(src)
     s = src.contiguous().float()
     out = torch.empty(s.shape, dtype=storage_dtype(dtype), device=s.device)
-    with torch.cuda.device(s.device):
+    with L.on(s.device):
         L.check(L.lib().ag_cast_f32(L.ptr(s), L.ptr(out), s.numel(), dtype, L.stream()))
     return out
 
@@ -171,7 +171,7 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, ro
     ldx = h if ldx is None else ldx
     ys = torch.empty((rows, h), dtype=storage_dtype(dtype), device=x.device) if want_store else None
     yf = torch.empty((rows, h), dtype=torch.float32, device=x.device) if want_f32 else None
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         L.check(L.lib().ag_layernorm(L.ptr(x), x_dtype, ldx, rows, h, L.ptr(gamma), L.ptr(beta), eps, L.ptr(ys), L.ptr(yf),
                                      dtype, L.stream()))
     return ys, yf
@@ -196,7 +196,7 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
         out = torch.empty((m, n), dtype=torch.float32 if out_f32 else storage_dtype(dtype), device=a.device)
     ldc = n if ldc is None else ldc
     ldr = (n if ldr is None else ldr) if resid is not None else 0
-    with torch.cuda.device(a.device):
+    with L.on(a.device):
         L.check(L.lib().ag_gemm(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr,
                                 rows_per_seq, resid_share, m, n, k, epilogue, dtype, L.ptr(ln_stats), L.ptr(ln_colsum),
                                 float(ln_eps), L.ptr(stats_out), L.stream()))
@@ -209,7 +209,7 @@ def row_stats(x: Tensor) -> Tensor:
     x = x.contiguous()
     rows, h = x.shape
     st = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         L.check(L.lib().ag_row_stats_bf16(L.ptr(x), h, rows, h, L.ptr(st), L.stream()))
     return st
 
@@ -220,7 +220,7 @@ def masked_attention(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, 
     ctx = torch.empty((rows, t, h), dtype=storage_dtype(dtype), device=qkv.device)
     if n_query:
         ctx.zero_()
-    with torch.cuda.device(qkv.device):
+    with L.on(qkv.device):
         L.check(L.lib().ag_masked_attention(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, share,
                                             mask_mode, n_query, dtype, L.stream()))
     return ctx
@@ -230,7 +230,7 @@ def softmax_rows(x: Tensor) -> Tensor:
     L.require_gpu(x)
     x = x.contiguous().float()
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         L.check(L.lib().ag_softmax_rows(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], L.stream()))
     return y
 
@@ -244,7 +244,7 @@ def shapley_normalize(pred: Tensor, grand: Optional[Tensor], null: Optional[Tens
     phi = torch.empty((b, c, t - 1), dtype=torch.float32, device=pred.device)
     g = grand.contiguous().float() if grand is not None else None
     n = null.contiguous().float() if null is not None else None
-    with torch.cuda.device(pred.device):
+    with L.on(pred.device):
         L.check(L.lib().ag_shapley_normalize(L.ptr(pred), L.ptr(g), L.ptr(n), b, t, c, 1 if normalize else 0,
                                              L.ptr(phi), L.stream()))
     return phi
@@ -255,7 +255,7 @@ def shapley_normalize_bwd(dphi: Tensor, t: int, normalize: bool = True) -> Tenso
     dphi = dphi.contiguous().float()
     b, c, p = dphi.shape
     dpred = torch.empty((b, t, c), dtype=torch.float32, device=dphi.device)
-    with torch.cuda.device(dphi.device):
+    with L.on(dphi.device):
         L.check(L.lib().ag_shapley_normalize_bwd(L.ptr(dphi), b, t, c, 1 if normalize else 0, L.ptr(dpred), L.stream()))
     return dpred
 
@@ -269,7 +269,7 @@ def shapley_loss(mask_bits: Tensor, v0: Tensor, vs: Tensor, phi: Tensor, batch: 
     loss = torch.empty(1, dtype=torch.float32, device=phi.device)
     dphi = torch.empty_like(phi) if want_grad else None
     scratch = torch.empty(batch * k * c, dtype=torch.float32, device=phi.device)
-    with torch.cuda.device(phi.device):
+    with L.on(phi.device):
         L.check(L.lib().ag_shapley_loss(L.ptr(mask_bits), L.ptr(v0.contiguous().float()), L.ptr(vs.contiguous().float()),
                                         L.ptr(phi), batch, k, p, c, L.ptr(loss), L.ptr(dphi), L.ptr(scratch), L.stream()))
     return loss, dphi
@@ -281,7 +281,7 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
     ref, cur = ref.contiguous().float(), cur.contiguous().float()
     loss = torch.empty(1, dtype=torch.float32, device=ref.device)
     d = torch.empty_like(cur) if want_grad else None
-    with torch.cuda.device(ref.device):
+    with L.on(ref.device):
         L.check(L.lib().ag_kl_loss(L.ptr(ref), L.ptr(cur), ref.shape[0], ref.shape[1], L.ptr(loss), L.ptr(d), L.stream()))
     return loss, d
 
@@ -293,7 +293,7 @@ def seq_compact_plan(mask_bits: Tensor, t: int):
     rows = mask_bits.shape[0]
     cu = torch.empty(rows + 1, dtype=torch.int32, device=mask_bits.device)
     src = torch.empty(rows * t, dtype=torch.int32, device=mask_bits.device)
-    with torch.cuda.device(mask_bits.device):
+    with L.on(mask_bits.device):
         L.check(L.lib().ag_seq_compact_plan(L.ptr(mask_bits.contiguous()), rows, t, L.ptr(cu), L.ptr(src), L.stream()))
     return cu, src, int(cu[rows].item())
 
@@ -304,7 +304,7 @@ def gather_rows(src: Tensor, index: Tensor, n: int, dtype: int) -> Tensor:
     h = src.shape[-1]
     s2 = src.contiguous().view(-1, h)
     out = torch.empty((n, h), dtype=s2.dtype, device=s2.device)
-    with torch.cuda.device(s2.device):
+    with L.on(s2.device):
         L.check(L.lib().ag_gather_rows(L.ptr(s2), h, L.ptr(index), L.ptr(out), h, n, h, dtype, L.stream()))
     return out
 
@@ -317,7 +317,7 @@ def mc_shapley_reduce(v: Tensor, rank: Tensor):
     sv = torch.empty((c, p1 - 1), dtype=torch.float32, device=v.device)
     v0 = torch.empty(c, dtype=torch.float32, device=v.device)
     vn = torch.empty(c, dtype=torch.float32, device=v.device)
-    with torch.cuda.device(v.device):
+    with L.on(v.device):
         L.check(L.lib().ag_mc_shapley_reduce(L.ptr(v), L.ptr(rank), reps, p1 - 1, c, L.ptr(sv), L.ptr(v0), L.ptr(vn), L.stream()))
     return sv, v0, vn
 
@@ -336,8 +336,19 @@ def transpose(src: Tensor, pad_cols_to: int = 1) -> Tensor:
     r, c = s.shape
     rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
     dst = torch.zeros((c, rp), dtype=torch.float32, device=s.device) if rp != r else torch.empty((c, rp), dtype=torch.float32, device=s.device)
-    with torch.cuda.device(s.device):
+    with L.on(s.device):
         L.check(L.lib().ag_transpose_f32(L.ptr(s), r, c, c, L.ptr(dst), rp, L.stream()))
+    return dst
+
+
+def transpose_bf16(src: Tensor, pad_cols_to: int = 1) -> Tensor:
+    """[R,C] fp32 -> [C, Rp] bf16 (transpose + round in one pass, zero padded)."""
+    s = _f32c(src)
+    r, c = s.shape
+    rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    dst = torch.empty((c, rp), dtype=torch.bfloat16, device=s.device)
+    with L.on(s.device):
+        L.check(L.lib().ag_transpose_f32_bf16(L.ptr(s), r, c, c, L.ptr(dst), rp, L.stream()))
     return dst
 
 
@@ -347,7 +358,7 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=x.device)
         accumulate = False
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         L.check(L.lib().ag_colsum_f32(L.ptr(x), m, n, n, L.ptr(out), 1 if accumulate else 0, L.stream()))
     return out
 
@@ -355,7 +366,7 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
 def _unary(name: str, *tensors: Tensor) -> Tensor:
     ts = [_f32c(t) for t in tensors]
     out = torch.empty_like(ts[0])
-    with torch.cuda.device(out.device):
+    with L.on(out.device):
         L.check(getattr(L.lib(), name)(*[L.ptr(t) for t in ts], L.ptr(out), out.numel(), L.stream()))
     return out
 
@@ -382,7 +393,7 @@ def dropout(x: Tensor, p: float, seed: int) -> Tensor:
         return x
     x = _f32c(x)
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with L.on(x.device):
         L.check(L.lib().ag_dropout_f32(L.ptr(x), L.ptr(y), x.numel(), float(p), seed & 0xFFFFFFFF, L.stream()))
     return y
 
@@ -390,7 +401,7 @@ def dropout(x: Tensor, p: float, seed: int) -> Tensor:
 def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
     y, dy = _f32c(y), _f32c(dy)
     dx = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with L.on(y.device):
         L.check(L.lib().ag_softmax_rows_bwd(L.ptr(y), L.ptr(dy), L.ptr(dx), y.shape[0], y.shape[1], L.stream()))
     return dx
 
@@ -402,8 +413,8 @@ def layernorm_bwd(x: Tensor, gamma: Optional[Tensor], dy: Tensor, eps: float, dg
     h = x.shape[-1]
     rows = x.numel() // h
     dx = torch.empty_like(x)
-    scratch = torch.empty(128 * 2 * h, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    scratch = torch.empty(256 * 2 * h, dtype=torch.float32, device=x.device)
+    with L.on(x.device):
         L.check(L.lib().ag_layernorm_bwd(L.ptr(x), L.ptr(gamma), L.ptr(dy), rows, h, eps, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
                                          1 if accumulate else 0, L.ptr(scratch), L.stream()))
     return dx
@@ -413,7 +424,7 @@ def masked_attention_train(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h:
                            p_drop: float = 0.0, seed: int = 0) -> Tensor:
     qkv = _f32c(qkv)
     ctx = torch.empty((rows, t, h), dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with L.on(qkv.device):
         L.check(L.lib().ag_masked_attention_train(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, mask_mode,
                                                   float(p_drop), seed & 0xFFFFFFFF, L.stream()))
     return ctx
@@ -424,7 +435,7 @@ def masked_attention_bwd(qkv: Tensor, mask_bits: Tensor, ctx: Tensor, dctx: Tens
     qkv, ctx, dctx = _f32c(qkv), _f32c(ctx), _f32c(dctx)
     dqkv = torch.empty_like(qkv)
     stats = torch.empty(rows * heads * t * 3, dtype=torch.float32, device=qkv.device)
-    with torch.cuda.device(qkv.device):
+    with L.on(qkv.device):
         L.check(L.lib().ag_masked_attention_bwd(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), L.ptr(dctx), L.ptr(dqkv), L.ptr(stats),
                                                 rows, t, h, heads, mask_mode, float(p_drop), seed & 0xFFFFFFFF, L.stream()))
     return dqkv

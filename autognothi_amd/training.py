@@ -33,10 +33,12 @@ import os as _os
 MIXED_BF16 = _os.environ.get("AG_TRAIN_BF16", "0") == "1"
 
 
-def _mm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: int) -> Tensor:
-    """epilogue(a[m,K] @ w[N,K]^T + bias) -> fp32; bf16 operands when MIXED_BF16 (plain / fp32-output epilogues only)."""
+def _mm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: int, w_bf16: Optional[Tensor] = None) -> Tensor:
+    """epilogue(a[m,K] @ w[N,K]^T + bias) -> fp32; bf16 operands when MIXED_BF16 (plain / fp32-output epilogues only).
+    ``w_bf16``: an already cast copy of ``w`` (Lin caches one per parameter version)."""
     if MIXED_BF16 and epilogue in (L.AG_EPI_BIAS, L.AG_EPI_BIAS_F32) and a.shape[-1] % 8 == 0:
-        return ops.gemm(ops.cast(a, L.AG_BF16), ops.cast(w, L.AG_BF16), bias, L.AG_EPI_BIAS_F32, L.AG_BF16, m=m)
+        wb = w_bf16 if w_bf16 is not None else ops.cast(w, L.AG_BF16)
+        return ops.gemm(ops.cast(a, L.AG_BF16), wb, bias, L.AG_EPI_BIAS_F32, L.AG_BF16, m=m)
     return ops.gemm(a, w, bias, epilogue, F32, m=m)
 
 
@@ -46,9 +48,20 @@ def _grad(p: Tensor) -> Tensor:
     return p.grad
 
 
+def _acc_grad(p: Tensor, src: Tensor, fresh: bool = False) -> None:
+    """p.grad += src.  After ``zero_grad(set_to_none=True)`` (torch's default) the first contribution of a step becomes the
+    gradient buffer itself (``fresh``: src is a whole tensor nobody else holds) or one copy of it — instead of a zero fill
+    plus an add per parameter and step."""
+    src = src.reshape(p.shape)
+    if p.grad is None:
+        p.grad = src if (fresh and src.is_contiguous()) else src.clone(memory_format=torch.contiguous_format)
+    else:
+        _acc(p.grad, src)
+
+
 def _acc(dst: Tensor, src: Tensor) -> None:
     """dst += src through the add kernel (no torch arithmetic)."""
-    with torch.cuda.device(dst.device):
+    with L.on(dst.device):
         L.check(L.lib().ag_add_f32(L.ptr(dst), L.ptr(src.contiguous()), L.ptr(dst), dst.numel(), L.stream()))
 
 
@@ -85,12 +98,35 @@ class Lin:
         self.mods = list(mods)
         self.x: Optional[Tensor] = None
 
+    def _key(self):
+        return tuple((p.data_ptr(), p._version) for m in self.mods for p in (m.weight, m.bias))
+
     def _w(self) -> Tuple[Tensor, Tensor]:
-        if len(self.mods) == 1:
-            m = self.mods[0]
-            return m.weight.detach().reshape(m.weight.shape[0], -1).float().contiguous(), m.bias.detach().float().contiguous()
-        return (torch.cat([m.weight.detach() for m in self.mods], 0).float().contiguous(),
-                torch.cat([m.bias.detach() for m in self.mods], 0).float().contiguous())
+        """fused fp32 [N,K] weight and [N] bias, rebuilt only when a parameter changed (optimizer step / load): the forward
+        and the backward of a step, and every step of a frozen module, share one copy."""
+        key = self._key()
+        if getattr(self, "_wkey", None) != key:
+            if len(self.mods) == 1:
+                m = self.mods[0]
+                self._wb = (m.weight.detach().reshape(m.weight.shape[0], -1).float().contiguous(), m.bias.detach().float().contiguous())
+            else:
+                self._wb = (torch.cat([m.weight.detach() for m in self.mods], 0).float().contiguous(),
+                            torch.cat([m.bias.detach() for m in self.mods], 0).float().contiguous())
+            self._wkey, self._derived = key, {}
+        return self._wb
+
+    def _w_form(self, form: str) -> Optional[Tensor]:
+        """derived operand forms of the current weight, cached with it: "bf16" [N,K], "t" fp32 [K,Np], "t_bf16"."""
+        w, _ = self._w()
+        d = self._derived
+        if form not in d:
+            if form == "bf16":
+                d[form] = ops.cast(w, L.AG_BF16)
+            elif form == "t":
+                d[form] = ops.transpose(w, pad_cols_to=PAD) if w.shape[0] % PAD else ops.transpose(w)
+            elif form == "t_bf16":
+                d[form] = ops.cast(self._w_form("t"), L.AG_BF16)
+        return d[form]
 
     def trainable(self) -> bool:
         return any(p.requires_grad for m in self.mods for p in (m.weight, m.bias))
@@ -99,7 +135,8 @@ class Lin:
         w, b = self._w()
         if save:
             self.x = x
-        return _mm(x, w, b, epilogue, x.shape[0])
+        mixed = MIXED_BF16 and epilogue in (L.AG_EPI_BIAS, L.AG_EPI_BIAS_F32) and x.shape[-1] % 8 == 0
+        return _mm(x, w, b, epilogue, x.shape[0], self._w_form("bf16") if mixed else None)
 
     def backward(self, dy: Tensor, need_dx: bool = True) -> Optional[Tensor]:
         w, _ = self._w()
@@ -108,27 +145,30 @@ class Lin:
         dx = None
         if need_dx:
             # dX[M,K] = dY[M,N] · W[N,K]  ==  NT GEMM against Wᵀ [K, N]; pad N (the contraction) to 32
+            wt = self._w_form("t")
             if n % PAD:
                 npad = (n + PAD - 1) // PAD * PAD
                 dyp = torch.zeros((m, npad), dtype=torch.float32, device=dy.device)
                 dyp[:, :n].copy_(dy)
-                wt = ops.transpose(w, pad_cols_to=PAD)  # [K, Np]
-                dx = _mm(dyp, wt, None, L.AG_EPI_BIAS, m)
+                dx = _mm(dyp, wt, None, L.AG_EPI_BIAS, m, self._w_form("t_bf16") if MIXED_BF16 else None)
             else:
-                dx = _mm(dy, ops.transpose(w), None, L.AG_EPI_BIAS, m)
+                dx = _mm(dy, wt, None, L.AG_EPI_BIAS, m, self._w_form("t_bf16") if MIXED_BF16 else None)
         if self.trainable():
             # dW[N,K] = dYᵀ[N,M] · X[M,K]  ==  NT GEMM of dYᵀ [N,Mp] against Xᵀ [K,Mp]
-            dyt = ops.transpose(dy, pad_cols_to=PAD)
-            xt = ops.transpose(self.x, pad_cols_to=PAD)
-            dw = _mm(dyt, xt, None, L.AG_EPI_BIAS, n)
+            if MIXED_BF16:   # (Mp % 32 == 0 keeps the bf16 rows 16-byte aligned)
+                dw = ops.gemm(ops.transpose_bf16(dy, pad_cols_to=PAD), ops.transpose_bf16(self.x, pad_cols_to=PAD), None,
+                              L.AG_EPI_BIAS_F32, L.AG_BF16, m=n)
+            else:
+                dw = _mm(ops.transpose(dy, pad_cols_to=PAD), ops.transpose(self.x, pad_cols_to=PAD), None, L.AG_EPI_BIAS, n)
             db = ops.colsum(dy)
             off = 0
             for mod in self.mods:
                 rows = mod.weight.shape[0]
+                whole = len(self.mods) == 1
                 if mod.weight.requires_grad:
-                    _acc(_grad(mod.weight), dw[off:off + rows].reshape(mod.weight.shape))
+                    _acc_grad(mod.weight, dw[off:off + rows] if not whole else dw, fresh=whole)
                 if mod.bias.requires_grad:
-                    _acc(_grad(mod.bias), db[off:off + rows])
+                    _acc_grad(mod.bias, db[off:off + rows] if not whole else db, fresh=whole)
                 off += rows
         self.x = None
         return dx
@@ -152,8 +192,12 @@ class Norm:
         if self.identity:
             return dy
         train = self.mod.weight.requires_grad
+        fresh = train and self.mod.weight.grad is None and self.mod.bias.grad is None
+        if fresh:   # first contribution of the step: the kernel stores instead of accumulating (no zero fill)
+            self.mod.weight.grad = torch.empty_like(self.mod.weight, dtype=torch.float32)
+            self.mod.bias.grad = torch.empty_like(self.mod.bias, dtype=torch.float32)
         dx = ops.layernorm_bwd(self.x, self.mod.weight.detach().float(), dy, self.eps,
-                               _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=True)
+                               _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=not fresh)
         self.x = None
         return dx
 
@@ -244,7 +288,7 @@ class ViTBackboneTrainer:
             pass
         x = x.contiguous().float()
         cols = torch.empty((b * p, c.img_channels * c.img_patch_size ** 2), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with L.on(x.device):
             L.check(L.lib().ag_vit_im2col(L.ptr(x), b, c.img_channels, c.img_px_size, c.img_patch_size, L.ptr(cols), F32, L.stream()))
             pe = self.proj.forward(cols, L.AG_EPI_BIAS_F32)
             h0 = torch.empty((b, t, h), dtype=torch.float32, device=x.device)
@@ -270,9 +314,9 @@ class ViTBackboneTrainer:
         d = ops.dropout(d, ph, s_emb).view(b, t, h)
         e = self.vit.embeddings
         if e.position_embeddings.requires_grad:
-            _acc(_grad(e.position_embeddings), ops.colsum(d.reshape(b, t * h)).view(1, t, h))
+            _acc_grad(e.position_embeddings, ops.colsum(d.reshape(b, t * h)), fresh=True)
         if e.cls_token.requires_grad:
-            _acc(_grad(e.cls_token), ops.colsum(d[:, 0, :].contiguous()).view(1, 1, h))
+            _acc_grad(e.cls_token, ops.colsum(d[:, 0, :].contiguous()), fresh=True)
         if self.proj.trainable():
             self.proj.backward(d[:, 1:, :].contiguous().view(b * p, h), need_dx=False)
         self.saved = None

@@ -222,6 +222,9 @@ int ag_encoder_forward(const ag_encoder_desc* desc, const void* d_h0, int R, int
  * ---------------------------------------------------------------------------------------------- */
 /* dst[c, r] = src[r, c]; src row stride lds, dst row stride ldd (>= rows; padding untouched). */
 int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t lds, float* d_dst, int64_t ldd, void* stream);
+/* The same with a bf16 destination (mixed-precision training: the dW operands dYᵀ, Xᵀ are transposed and rounded in one
+ * pass); every element of dst [cols, ldd] is written, zeros beyond `rows`. */
+int ag_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_dst, int64_t ldd, void* stream);
 /* out[n] (+)= sum_m x[m, n]  (bias gradients). */
 int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream);
 /* exact-erf GELU (nn.GELU default) and its derivative: du = dy * gelu'(u). */
@@ -236,7 +239,7 @@ int ag_dropout_f32(const float* d_x, float* d_y, int64_t n, float p, uint32_t se
 /* dx = y * (dy - sum_c y*dy)  for y = softmax(x) rows. */
 int ag_softmax_rows_bwd(const float* d_y, const float* d_dy, float* d_dx, int rows, int C, void* stream);
 /* LayerNorm backward: dx [rows,H]; dgamma/dbeta [H] (= or += when accumulate); gamma may be NULL (ones).
- * d_scratch: >= 128*2*H floats. */
+ * d_scratch: >= 256*2*H floats. */
 int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const float* d_dy, int rows, int H, float eps,
                      float* d_dx, float* d_dgamma, float* d_dbeta, int accumulate, float* d_scratch, void* stream);
 /* fp32 masked attention forward WITH attention-probability dropout (training); p_drop = 0 is the plain
