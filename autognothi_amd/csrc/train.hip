@@ -354,6 +354,291 @@ __global__ __launch_bounds__(256) void attn_bwd_key_kernel(AttnBwdArgs p) {
 
 int grid_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096); }
 
+
+// ---- masked attention backward on the matrix cores (mixed-precision training: bf16 operands, fp32 accumulate / I/O) ----
+// One workgroup per (row, head), head dim 64, T <= 256.  Q, K, V, dO head slices are converted to bf16 once into four
+// swizzled LDS images (the forward's layout: 128-byte rows, 16-byte chunk c of row r at slot c ^ swz(r), so rows can be
+// read as MFMA row fragments and, through ds_read_b64_tr_b16, as transposed fragments).  ViT: the K rows of masked keys are
+// zero (logit exactly 0, as forward).  D_i = dO_i . O_i per query.
+//   pass 1 (a lane owns a QUERY, wave = query block): S^T = K.Q^T per key block -> row max / sum -> LSE_i (base 2);
+//   pass 2 (same layout): S^T and dP^T = V.dO^T again, P = exp2(c S - LSE), dS = P (keep/(1-p) dP - D) (ViT: x mask_j);
+//           the dS^T accumulator tile is the B operand of dQ^T += K^T.dS^T (K^T by transposed reads) -> dQ, no reduction
+//           across waves;
+//   pass 3 (a lane owns a KEY, wave = key block): S = Q.K^T and dP = dO.V^T per query block; the P~ and dS tiles are the B
+//           operands of dV^T += dO^T.P~ and dK^T += Q^T.dS (dO^T, Q^T by transposed reads) -> dK, dV, no reduction across
+//           waves and nothing but LSE / D (2 KiB) crosses LDS.
+// Dropout: the forward's counter hash on (workgroup, query, key).  Recomputing S, dP in pass 3 instead of staging dS through
+// LDS costs 8 MFMAs per tile pair and keeps the kernel free of cross-wave protocols.
+constexpr int BROW = 128;
+__device__ __forceinline__ int bswz(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1);
+}
+__device__ __forceinline__ uint4 pack8_bf16(const float4 a, const float4 b) {
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int row = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+    const int T = p.T, Tp = (T + 31) & ~31, nb = Tp >> 5;
+    const int img = Tp * BROW;
+    char* iQ = smem; char* iK = smem + img; char* iV = smem + 2 * img; char* iO = smem + 3 * img;
+    float* sD = reinterpret_cast<float*>(smem + 4 * img);   // [Tp] dO_i . O_i
+    float* sL = sD + Tp;                                    // [Tp] LSE_i in base-2 units of the scaled scores
+    const long ts = (long)3 * p.H;
+    const float* base = p.qkv + (long)row * T * ts + (long)head * 64;
+    const float* dob = p.dctx + (long)row * T * p.H + (long)head * 64;
+    const uint32_t* mrow = p.mask + (long)row * p.Tw;
+    const float c2 = 0.125f * 1.4426950408889634f;
+    const float keep_sc = 1.0f / (1.0f - p.pdrop);
+    const bool drop = p.pdrop > 0.f;
+    const uint64_t hbase = (uint64_t)blockIdx.x * T;
+
+    // ---- images
+    for (int c = tid; c < Tp * 8; c += blockDim.x) {
+        const int t = c >> 3, ch = c & 7;
+        const int tc = t < T ? t : T - 1;
+        const float* src = base + (long)tc * ts + ch * 8;
+        const int dst = t * BROW + ((ch ^ bswz(t)) << 4);
+        *reinterpret_cast<uint4*>(iQ + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
+        uint4 kv = pack8_bf16(*reinterpret_cast<const float4*>(src + p.H), *reinterpret_cast<const float4*>(src + p.H + 4));
+        if (MODE == AG_MASK_VIT_MUL && !((mrow[tc >> 5] >> (tc & 31)) & 1u)) kv = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(iK + dst) = kv;
+        *reinterpret_cast<uint4*>(iV + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src + 2 * p.H), *reinterpret_cast<const float4*>(src + 2 * p.H + 4));
+        uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+        if (t < T) {
+            const float* ds_ = dob + (long)t * p.H + ch * 8;
+            dv = pack8_bf16(*reinterpret_cast<const float4*>(ds_), *reinterpret_cast<const float4*>(ds_ + 4));
+        }
+        *reinterpret_cast<uint4*>(iO + dst) = dv;
+    }
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    // row-fragment offsets (8 consecutive head-dim elements 16ks + 8lh .. of row lr of a 32-row block)
+    int roff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) roff[ks] = lr * BROW + (((2 * ks + lh) ^ bswz(lr)) << 4);
+    // transposed-fragment offsets (forward's V^T recipe): [d tile][first / second 4-row group]; k-step 1 is +2048 B
+    int toff[2][2];
+    {
+        const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int k0 = 4 * (g >> 1) + tq, k1 = k0 + 8;
+            const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
+            toff[dt][0] = k0 * BROW + ((chunk ^ bswz(k0)) << 4) + 8 * (tp & 1);
+            toff[dt][1] = k1 * BROW + ((chunk ^ bswz(k1)) << 4) + 8 * (tp & 1);
+        }
+    }
+    auto row_frag = [&](const char* image, int blk, int ks) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(image + blk * 32 * BROW + roff[ks]));
+    };
+    auto tr_frag = [&](const char* image, int blk, int st, int dt) -> bf16x8_t {
+        const char* b = image + blk * 32 * BROW + 2048 * st;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + toff[dt][0]));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + toff[dt][1]));
+        return __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto pack_step = [&](const f32x16_t& x, int st) -> bf16x8_t {
+        return __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(x[8 * st + 0], x[8 * st + 1]), pack_bf16x2(x[8 * st + 2], x[8 * st + 3]),
+                                                       pack_bf16x2(x[8 * st + 4], x[8 * st + 5]), pack_bf16x2(x[8 * st + 6], x[8 * st + 7])));
+    };
+    auto zero16 = [](f32x16_t& x) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = 0.f;
+    };
+
+    // ================= passes 1 + 2: a lane owns a query =================
+    for (int qb = wave; qb < nb; qb += nwaves) {
+        const int q = qb * 32 + lr;
+        bf16x8_t qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(iQ, qb, ks); dof[ks] = row_frag(iO, qb, ks); }
+        // scores of one key block, keys in registers: reg i <-> key kb*32 + (i&3) + 8(i>>2) + 4lh; masked / padded -> -inf
+        auto scores_t = [&](int kb) -> f32x16_t {
+            f32x16_t s; zero16(s);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(iK, kb, ks), qf[ks], s, 0, 0, 0);
+            uint32_t vis = 0xFFFFFFFFu;
+            if (MODE == AG_MASK_BERT_ADD) vis = mrow[kb];
+            const int kvalid = T - kb * 32;
+            if (kvalid < 32) vis &= (1u << kvalid) - 1u;
+            if (vis != 0xFFFFFFFFu) {   // wave-uniform
+                const uint32_t vl = vis >> (4 * lh);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (!((vl >> ((i & 3) + 8 * (i >> 2))) & 1u)) s[i] = -3.0e38f;
+            }
+            return s;
+        };
+        // pass 1 = the forward on the SAME bf16 operands: LSE_i, and D_i = dO_i . O'_i with O' = sum_j P~_ij V_j from the
+        // matrix cores, so that dP_ij - D_i cancels exactly where it should (an fp32 D against bf16 dP would not)
+        float m = -3.0e38f, l = 0.f;
+        f32x16_t o0, o1; zero16(o0); zero16(o1);
+        for (int kb = 0; kb < nb; ++kb) {
+            f32x16_t s = scores_t(kb);
+            float bm = s[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) bm = fmaxf(bm, s[i]);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bm), __float_as_uint(bm), false, false);
+                bm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float mn = fmaxf(m, bm);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f((s[i] - mn) * c2);
+                acc += pv;
+                s[i] = pv;
+                if (drop) s[i] = keep_elem(p.seed, (hbase + q) * T + (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh), p.pdrop) ? pv : 0.f;   // the 1/(1-p) scale is applied in fp32 below: it would not survive the bf16 rounding of the fragment exactly
+            }
+            l = fmaf(l, alpha, acc);
+            m = mn;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t pf = pack_step(s, st);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iV, kb, st, 0), pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iV, kb, st, 1), pf, o1, 0, 0, 0);
+            }
+        }
+        {   // the two lane halves hold disjoint key subsets of the same query (same reference max)
+            const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+            l = __uint_as_float(sl[0]) + __uint_as_float(sl[1]);
+        }
+        const float lse2 = fmaf(m, c2, __builtin_amdgcn_logf(l));
+        float Dq = 0.f;
+        {   // regs 4g..4g+3 of lane (query, lh) are head-dim elements 8g + 4lh .. +3 (second tile: +32); dO from its bf16 image
+            const char* drow = iO + q * BROW + 8 * lh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint2 a = *reinterpret_cast<const uint2*>(drow + ((g4 ^ bswz(q)) << 4));
+                const uint2 b = *reinterpret_cast<const uint2*>(drow + (((4 + g4) ^ bswz(q)) << 4));
+                Dq = fmaf(__uint_as_float(a.x << 16), o0[4 * g4], Dq); Dq = fmaf(__uint_as_float(a.x & 0xFFFF0000u), o0[4 * g4 + 1], Dq);
+                Dq = fmaf(__uint_as_float(a.y << 16), o0[4 * g4 + 2], Dq); Dq = fmaf(__uint_as_float(a.y & 0xFFFF0000u), o0[4 * g4 + 3], Dq);
+                Dq = fmaf(__uint_as_float(b.x << 16), o1[4 * g4], Dq); Dq = fmaf(__uint_as_float(b.x & 0xFFFF0000u), o1[4 * g4 + 1], Dq);
+                Dq = fmaf(__uint_as_float(b.y << 16), o1[4 * g4 + 2], Dq); Dq = fmaf(__uint_as_float(b.y & 0xFFFF0000u), o1[4 * g4 + 3], Dq);
+            }
+            const auto sd = __builtin_amdgcn_permlane32_swap(__float_as_uint(Dq), __float_as_uint(Dq), false, false);
+            Dq = (__uint_as_float(sd[0]) + __uint_as_float(sd[1])) * keep_sc / l;
+        }
+        if (lh == 0) { sL[q] = lse2; sD[q] = Dq; }
+        f32x16_t dq0, dq1; zero16(dq0); zero16(dq1);
+        for (int kb = 0; kb < nb; ++kb) {
+            const f32x16_t s = scores_t(kb);
+            f32x16_t dp; zero16(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(iV, kb, ks), dof[ks], dp, 0, 0, 0);
+            const uint32_t mvit = MODE == AG_MASK_VIT_MUL ? (mrow[kb] >> (4 * lh)) : 0xFFFFFFFFu;
+            f32x16_t ds;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = (i & 3) + 8 * (i >> 2);
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lse2));
+                float dpv = dp[i];
+                if (drop) dpv = keep_elem(p.seed, (hbase + q) * T + (kb * 32 + kk + 4 * lh), p.pdrop) ? dpv * keep_sc : 0.f;
+                float v = pr * (dpv - Dq);
+                if (MODE == AG_MASK_VIT_MUL && !((mvit >> kk) & 1u)) v = 0.f;   // d(s * 0) / ds = 0
+                ds[i] = v;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8_t pf = pack_step(ds, st);
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iK, kb, st, 0), pf, dq0, 0, 0, 0);
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iK, kb, st, 1), pf, dq1, 0, 0, 0);
+            }
+        }
+        if (q < T) {   // accumulator regs 4g..4g+3 of lane (query, lh) are head-dim elements 8g + 4lh .. +3 (second tile: +32)
+            float* out = p.dqkv + ((long)row * T + q) * ts + (long)head * 64;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 8 * g4 + 4 * lh;
+                *reinterpret_cast<float4*>(out + d) = make_float4(dq0[4 * g4] * 0.125f, dq0[4 * g4 + 1] * 0.125f, dq0[4 * g4 + 2] * 0.125f, dq0[4 * g4 + 3] * 0.125f);
+                *reinterpret_cast<float4*>(out + 32 + d) = make_float4(dq1[4 * g4] * 0.125f, dq1[4 * g4 + 1] * 0.125f, dq1[4 * g4 + 2] * 0.125f, dq1[4 * g4 + 3] * 0.125f);
+            }
+        }
+    }
+    __syncthreads();   // every LSE is in LDS
+
+    // ================= pass 3: a lane owns a key =================
+    for (int kb = wave; kb < nb; kb += nwaves) {
+        const int key = kb * 32 + lr;
+        const bool kvalid = key < T;
+        const bool kvis = (mrow[key >> 5] >> (key & 31)) & 1u;
+        const bool kon = kvalid && (MODE == AG_MASK_VIT_MUL || kvis);   // BERT: a masked key has weight exactly 0
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = row_frag(iK, kb, ks); vf[ks] = row_frag(iV, kb, ks); }
+        f32x16_t dv0, dv1, dk0, dk1; zero16(dv0); zero16(dv1); zero16(dk0); zero16(dk1);
+        for (int qb = 0; qb < nb; ++qb) {
+            f32x16_t s, dp; zero16(s); zero16(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(iQ, qb, ks), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(iO, qb, ks), vf[ks], dp, 0, 0, 0);
+            }
+            // reg i <-> query qb*32 + (i&3) + 8(i>>2) + 4lh; one 16-query k-step (regs 8st .. 8st+7) at a time
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float ptv8[8], dsv8[8];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int g4 = 2 * st + gg;
+                    const int q0 = qb * 32 + 8 * g4 + 4 * lh;
+                    const float4 ls = *reinterpret_cast<const float4*>(sL + q0), dd = *reinterpret_cast<const float4*>(sD + q0);
+                    const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g4 + e, qi = q0 + e;
+                        float pr = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -lsv[e]));
+                        if (!kon || qi >= T) pr = 0.f;
+                        float ptv = pr, dpv = dp[i];
+                        if (drop) {
+                            const bool keep = keep_elem(p.seed, (hbase + qi) * T + key, p.pdrop);
+                            ptv = keep ? pr : 0.f;             // dV is scaled by 1/(1-p) once, in fp32, at the store
+                            dpv = keep ? dpv * keep_sc : 0.f;
+                        }
+                        float v = pr * (dpv - ddv[e]);
+                        if (MODE == AG_MASK_VIT_MUL && !kvis) v = 0.f;
+                        ptv8[4 * gg + e] = ptv; dsv8[4 * gg + e] = v;
+                    }
+                }
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(ptv8[0], ptv8[1]), pack_bf16x2(ptv8[2], ptv8[3]),
+                                                                            pack_bf16x2(ptv8[4], ptv8[5]), pack_bf16x2(ptv8[6], ptv8[7])));
+                const bf16x8_t sf = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(dsv8[0], dsv8[1]), pack_bf16x2(dsv8[2], dsv8[3]),
+                                                                            pack_bf16x2(dsv8[4], dsv8[5]), pack_bf16x2(dsv8[6], dsv8[7])));
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iO, qb, st, 0), pf, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iO, qb, st, 1), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iQ, qb, st, 0), sf, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(iQ, qb, st, 1), sf, dk1, 0, 0, 0);
+            }
+        }
+        if (kvalid) {
+            float* outk = p.dqkv + ((long)row * T + key) * ts + p.H + (long)head * 64;
+            float* outv = outk + p.H;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 8 * g4 + 4 * lh;
+                *reinterpret_cast<float4*>(outk + d) = make_float4(dk0[4 * g4] * 0.125f, dk0[4 * g4 + 1] * 0.125f, dk0[4 * g4 + 2] * 0.125f, dk0[4 * g4 + 3] * 0.125f);
+                *reinterpret_cast<float4*>(outk + 32 + d) = make_float4(dk1[4 * g4] * 0.125f, dk1[4 * g4 + 1] * 0.125f, dk1[4 * g4 + 2] * 0.125f, dk1[4 * g4 + 3] * 0.125f);
+                *reinterpret_cast<float4*>(outv + d) = make_float4(dv0[4 * g4] * keep_sc, dv0[4 * g4 + 1] * keep_sc, dv0[4 * g4 + 2] * keep_sc, dv0[4 * g4 + 3] * keep_sc);
+                *reinterpret_cast<float4*>(outv + 32 + d) = make_float4(dv1[4 * g4] * keep_sc, dv1[4 * g4 + 1] * keep_sc, dv1[4 * g4 + 2] * keep_sc, dv1[4 * g4 + 3] * keep_sc);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t lds, float* d_dst, int64_t ldd, void* stream) {
@@ -436,6 +721,26 @@ extern "C" int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const fl
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, (hipStream_t)stream, d_scratch, nblocks, H, d_dgamma, d_dbeta, accumulate);
         AG_LAUNCH_CHECK();
     }
+    return AG_OK;
+}
+extern "C" int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
+                                             float* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed,
+                                             void* stream) {
+    AG_REQUIRE(d_qkv && d_mask_bits && d_ctx && d_dctx && d_dqkv, "ag_masked_attention_bwd_mixed: null pointer");
+    AG_REQUIRE(heads > 0 && H == heads * 64 && R >= 0 && T >= 1 && T <= 256 && p_drop >= 0.f && p_drop < 1.f,
+               "ag_masked_attention_bwd_mixed: needs head_dim 64 and T <= 256 (T=%d, H=%d, heads=%d)", T, H, heads);
+    AG_REQUIRE(mask_mode == AG_MASK_VIT_MUL || mask_mode == AG_MASK_BERT_ADD, "ag_masked_attention_bwd_mixed: bad mask mode %d", mask_mode);
+    if (R == 0) return AG_OK;
+    AttnBwdArgs a;
+    a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = d_ctx; a.dctx = d_dctx; a.dqkv = d_dqkv; a.stats = nullptr;
+    a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
+    const int Tp = (T + 31) & ~31;
+    const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
+    void (*kern)(AttnBwdArgs) = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD>;
+    if (lds > 64 * 1024)
+        AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(R * heads), dim3(512), lds, (hipStream_t)stream, a);
+    AG_LAUNCH_CHECK();
     return AG_OK;
 }
 extern "C" int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,

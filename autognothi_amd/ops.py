@@ -431,9 +431,15 @@ def masked_attention_train(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h:
 
 
 def masked_attention_bwd(qkv: Tensor, mask_bits: Tensor, ctx: Tensor, dctx: Tensor, rows: int, t: int, h: int, heads: int,
-                         mask_mode: int, p_drop: float = 0.0, seed: int = 0) -> Tensor:
+                         mask_mode: int, p_drop: float = 0.0, seed: int = 0, mixed: bool = False) -> Tensor:
+    """dqkv [rows,t,3h] fp32.  ``mixed``: bf16 MFMA operands (head dim 64, t <= 256), else the exact-fp32 kernels."""
     qkv, ctx, dctx = _f32c(qkv), _f32c(ctx), _f32c(dctx)
     dqkv = torch.empty_like(qkv)
+    if mixed and h == heads * 64 and t <= 256:
+        with L.on(qkv.device):
+            L.check(L.lib().ag_masked_attention_bwd_mixed(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), L.ptr(dctx), L.ptr(dqkv),
+                                                          rows, t, h, heads, mask_mode, float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+        return dqkv
     stats = torch.empty(rows * heads * t * 3, dtype=torch.float32, device=qkv.device)
     with L.on(qkv.device):
         L.check(L.lib().ag_masked_attention_bwd(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), L.ptr(dctx), L.ptr(dqkv), L.ptr(stats),

@@ -245,7 +245,7 @@ class Block:
             dhx = ops.add(dhx, self.n2.backward(du2))
             dctx = self.o.backward(ops.dropout(dhx, ph, s_o))
             dqkv = ops.masked_attention_bwd(qkv.view(rows, t, 3 * hdim), bits, ctx.view(rows, t, hdim), dctx.view(rows, t, hdim),
-                                            rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, 3 * hdim)
+                                            rows, t, hdim, self.heads, self.kind, pa, s_att, mixed=MIXED_BF16).view(rows * t, 3 * hdim)
             du1 = self.qkv.backward(dqkv)
             dh = ops.add(dhx, self.n1.backward(du1))
         else:
@@ -255,7 +255,7 @@ class Block:
             dpre = self.n1.backward(da)                         # d(ao + h)
             dctx = self.o.backward(ops.dropout(dpre, ph, s_o))
             dqkv = ops.masked_attention_bwd(qkv.view(rows, t, 3 * hdim), bits, ctx.view(rows, t, hdim), dctx.view(rows, t, hdim),
-                                            rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, 3 * hdim)
+                                            rows, t, hdim, self.heads, self.kind, pa, s_att, mixed=MIXED_BF16).view(rows * t, 3 * hdim)
             dh = ops.add(dpre, self.qkv.backward(dqkv))
         self.saved = None
         return dh

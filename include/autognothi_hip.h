@@ -251,6 +251,13 @@ int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, f
 int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
                             float* d_dqkv, float* d_stats, int R, int T, int H, int heads, int mask_mode,
                             float p_drop, uint32_t seed, void* stream);
+/* The same gradients on the matrix cores for mixed-precision training (head dim 64, T <= 256): Q, K, V, dO are rounded to
+ * bf16 operands, accumulation, soft-max statistics and I/O stay fp32; same dropout decisions (p_drop, seed) as
+ * ag_masked_attention_train.  No statistics scratch.  Reference: torch.autograd through models/vanilla_vit.py:436-465 /
+ * models/vanilla_bert.py:503-537 under autocast(bf16). */
+int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
+                                  float* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * In-library kernel timing (used by bench.py for the roofline block): when enabled, every launch of

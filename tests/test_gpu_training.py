@@ -295,3 +295,28 @@ def test_mixed_precision_training_step(cuda_device):
         assert last < first
     finally:
         training.MIXED_BF16 = False
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("t,heads,rows,p_drop", [(197, 3, 4, 0.0), (197, 2, 3, 0.1), (128, 2, 4, 0.1), (33, 1, 2, 0.0), (256, 1, 2, 0.0)])
+def test_attention_backward_mixed_matches_fp32(cuda_device, mode, t, heads, rows, p_drop):
+    """the matrix-core backward (bf16 operands) against the exact-fp32 kernels on the same inputs, masks and dropout
+    decisions: dQ, dK, dV within bf16 operand rounding."""
+    from autognothi_amd import ops
+    h = heads * 64
+    g = torch.Generator().manual_seed(t * 3 + heads + mode)
+    qkv = torch.randn((rows, t, 3 * h), generator=g).to(cuda_device)
+    dctx = torch.randn((rows, t, h), generator=g).to(cuda_device)
+    mask = (torch.rand((rows, t - 1), generator=g) < 0.6).to(torch.int64)
+    mask[0] = 0
+    mask[-1] = 1
+    bits = ops.pack_mask(mask.to(cuda_device))
+    ctx = ops.masked_attention_train(qkv, bits, rows, t, h, heads, mode, p_drop, 77)
+    ref = ops.masked_attention_bwd(qkv, bits, ctx, dctx, rows, t, h, heads, mode, p_drop, 77).cpu().numpy()
+    got = ops.masked_attention_bwd(qkv, bits, ctx, dctx, rows, t, h, heads, mode, p_drop, 77, mixed=True).cpu().numpy()
+    assert np.isfinite(got).all()
+    for name, sl in (("dQ", slice(0, h)), ("dK", slice(h, 2 * h)), ("dV", slice(2 * h, 3 * h))):
+        r, o = ref[..., sl], got[..., sl]
+        scale = float(np.abs(r).max())
+        assert float(np.abs(o - r).max()) <= 3e-2 * scale, (name, float(np.abs(o - r).max()), scale)
+        assert float(np.abs(o - r).mean()) <= 4e-3 * scale, name
