@@ -72,6 +72,7 @@ SIGNATURES = {
     "ag_layernorm_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, vp]),
     "ag_masked_attention_train": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_masked_attention_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
+    "ag_masked_attention_train_mixed": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_masked_attention_bwd_mixed": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_mc_shapley_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ag_probe_mfma": (i32, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),

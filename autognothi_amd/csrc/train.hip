@@ -378,7 +378,8 @@ __device__ __forceinline__ uint4 pack8_bf16(const float4 a, const float4 b) {
     return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
 }
 
-template <int MODE>
+// FWD: only pass 1 runs and its O' (the training forward on bf16 operands, dropout included) is stored to p.dqkv as ctx [R,T,H].
+template <int MODE, bool FWD>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<uint4*>(iK + dst) = kv;
         *reinterpret_cast<uint4*>(iV + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src + 2 * p.H), *reinterpret_cast<const float4*>(src + 2 * p.H + 4));
         uint4 dv = make_uint4(0u, 0u, 0u, 0u);
-        if (t < T) {
+        if (!FWD && t < T) {
             const float* ds_ = dob + (long)t * p.H + ch * 8;
             dv = pack8_bf16(*reinterpret_cast<const float4*>(ds_), *reinterpret_cast<const float4*>(ds_ + 4));
         }
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int q = qb * 32 + lr;
         bf16x8_t qf[4], dof[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(iQ, qb, ks); dof[ks] = row_frag(iO, qb, ks); }
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = row_frag(iQ, qb, ks); dof[ks] = row_frag(FWD ? iQ : iO, qb, ks); }
         // scores of one key block, keys in registers: reg i <-> key kb*32 + (i&3) + 8(i>>2) + 4lh; masked / padded -> -inf
         auto scores_t = [&](int kb) -> f32x16_t {
             f32x16_t s; zero16(s);
@@ -517,6 +518,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const auto sl = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
             l = __uint_as_float(sl[0]) + __uint_as_float(sl[1]);
         }
+        if (FWD) {   // ctx = O' / l with the dropout scale, fp32
+            if (q < T) {
+                const float sc = keep_sc / l;
+                float* out = p.dqkv + ((long)row * T + q) * p.H + (long)head * 64;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 8 * g4 + 4 * lh;
+                    *reinterpret_cast<float4*>(out + d) = make_float4(o0[4 * g4] * sc, o0[4 * g4 + 1] * sc, o0[4 * g4 + 2] * sc, o0[4 * g4 + 3] * sc);
+                    *reinterpret_cast<float4*>(out + 32 + d) = make_float4(o1[4 * g4] * sc, o1[4 * g4 + 1] * sc, o1[4 * g4 + 2] * sc, o1[4 * g4 + 3] * sc);
+                }
+            }
+            continue;
+        }
         const float lse2 = fmaf(m, c2, __builtin_amdgcn_logf(l));
         float Dq = 0.f;
         {   // regs 4g..4g+3 of lane (query, lh) are head-dim elements 8g + 4lh .. +3 (second tile: +32); dO from its bf16 image
@@ -569,6 +583,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+    if (FWD) return;
     __syncthreads();   // every LSE is in LDS
 
     // ================= pass 3: a lane owns a key =================
@@ -723,6 +738,25 @@ extern "C" int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const fl
     }
     return AG_OK;
 }
+extern "C" int ag_masked_attention_train_mixed(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H, int heads,
+                                               int mask_mode, float p_drop, uint32_t seed, void* stream) {
+    AG_REQUIRE(d_qkv && d_mask_bits && d_ctx, "ag_masked_attention_train_mixed: null pointer");
+    AG_REQUIRE(heads > 0 && H == heads * 64 && R >= 0 && T >= 1 && T <= 256 && p_drop >= 0.f && p_drop < 1.f,
+               "ag_masked_attention_train_mixed: needs head_dim 64 and T <= 256 (T=%d, H=%d, heads=%d)", T, H, heads);
+    AG_REQUIRE(mask_mode == AG_MASK_VIT_MUL || mask_mode == AG_MASK_BERT_ADD, "ag_masked_attention_train_mixed: bad mask mode %d", mask_mode);
+    if (R == 0) return AG_OK;
+    AttnBwdArgs a;
+    a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = nullptr; a.dctx = nullptr; a.dqkv = d_ctx; a.stats = nullptr;
+    a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
+    const int Tp = (T + 31) & ~31;
+    const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
+    void (*kern)(AttnBwdArgs) = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL, true> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD, true>;
+    if (lds > 64 * 1024)
+        AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(R * heads), dim3(512), lds, (hipStream_t)stream, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
 extern "C" int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
                                              float* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed,
                                              void* stream) {
@@ -736,7 +770,7 @@ extern "C" int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t*
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
     const int Tp = (T + 31) & ~31;
     const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
-    void (*kern)(AttnBwdArgs) = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD>;
+    void (*kern)(AttnBwdArgs) = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL, false> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD, false>;
     if (lds > 64 * 1024)
         AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(R * heads), dim3(512), lds, (hipStream_t)stream, a);

@@ -421,9 +421,14 @@ def layernorm_bwd(x: Tensor, gamma: Optional[Tensor], dy: Tensor, eps: float, dg
 
 
 def masked_attention_train(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, heads: int, mask_mode: int,
-                           p_drop: float = 0.0, seed: int = 0) -> Tensor:
+                           p_drop: float = 0.0, seed: int = 0, mixed: bool = False) -> Tensor:
     qkv = _f32c(qkv)
     ctx = torch.empty((rows, t, h), dtype=torch.float32, device=qkv.device)
+    if mixed and h == heads * 64 and t <= 256:
+        with L.on(qkv.device):
+            L.check(L.lib().ag_masked_attention_train_mixed(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, mask_mode,
+                                                            float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+        return ctx
     with L.on(qkv.device):
         L.check(L.lib().ag_masked_attention_train(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, mask_mode,
                                                   float(p_drop), seed & 0xFFFFFFFF, L.stream()))

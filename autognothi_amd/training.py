@@ -223,7 +223,7 @@ class Block:
         vit = self.kind == L.AG_MASK_VIT_MUL
         u1 = self.n1.forward(h) if vit else h
         qkv = self.qkv.forward(u1)
-        ctx = ops.masked_attention_train(qkv, bits, rows, t, hdim, self.heads, self.kind, pa, s_att).view(rows * t, hdim)
+        ctx = ops.masked_attention_train(qkv, bits, rows, t, hdim, self.heads, self.kind, pa, s_att, mixed=MIXED_BF16).view(rows * t, hdim)
         ao = ops.dropout(self.o.forward(ctx), ph, s_o)
         hx = ops.add(h, ao)
         u2 = self.n2.forward(hx) if vit else self.n1.forward(hx)

@@ -255,6 +255,9 @@ int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, con
  * bf16 operands, accumulation, soft-max statistics and I/O stay fp32; same dropout decisions (p_drop, seed) as
  * ag_masked_attention_train.  No statistics scratch.  Reference: torch.autograd through models/vanilla_vit.py:436-465 /
  * models/vanilla_bert.py:503-537 under autocast(bf16). */
+/* Training forward of the same mode: ctx [R,T,H] fp32 from bf16 MFMA operands, dropout as ag_masked_attention_train. */
+int ag_masked_attention_train_mixed(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H, int heads,
+                                    int mask_mode, float p_drop, uint32_t seed, void* stream);
 int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
                                   float* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed,
                                   void* stream);

@@ -312,6 +312,8 @@ def test_attention_backward_mixed_matches_fp32(cuda_device, mode, t, heads, rows
     mask[-1] = 1
     bits = ops.pack_mask(mask.to(cuda_device))
     ctx = ops.masked_attention_train(qkv, bits, rows, t, h, heads, mode, p_drop, 77)
+    ctx_mixed = ops.masked_attention_train(qkv, bits, rows, t, h, heads, mode, p_drop, 77, mixed=True)
+    np.testing.assert_allclose(ctx_mixed.cpu().numpy(), ctx.cpu().numpy(), rtol=0, atol=3e-2)   # the forward of the same mode
     ref = ops.masked_attention_bwd(qkv, bits, ctx, dctx, rows, t, h, heads, mode, p_drop, 77).cpu().numpy()
     got = ops.masked_attention_bwd(qkv, bits, ctx, dctx, rows, t, h, heads, mode, p_drop, 77, mixed=True).cpu().numpy()
     assert np.isfinite(got).all()
