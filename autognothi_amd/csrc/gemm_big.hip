@@ -496,6 +496,10 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
         const double wbytes = (double)N * K * 2.0;
         int groups = (wbytes > 4.0 * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (2.5 * 1024 * 1024) + 0.999) : 1;
         int g = ngrp_env > 0 ? ngrp_env : ceil_div(tiles_n, groups);
+        // wide outputs (16 or more N-tiles: none in the encoder): the 32 tiles an XCD runs at a time would be ONE row of
+        // tiles (1 A slice + 32 W slices per half-step); groups of 4 columns make them an 8 x 4 block (8 + 4 slices) that
+        // walks K in step and shares its slices in L2 (tools/gemm_square.py: 8192^3 935 -> 1385 TFLOP/s, 4096^3 1224 -> 1296)
+        if (ngrp_env <= 0 && tiles_n >= 16 && g > 4) g = 4;
         if (g < 1) g = 1;
         if (g > tiles_n) g = tiles_n;
         a.ngrp = g;
