@@ -370,7 +370,7 @@ def main():
             if train_imgs_per_s is not None:
                 line["secondary"]["train_explainer_step"] = {
                     "value": round(train_imgs_per_s, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM operands, fp32 accumulate / activations / attention / optimizer state) + AdamW, as scripts/train_explainer.py:128-207"}
+                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 accumulate / activations / optimizer state) + AdamW, as scripts/train_explainer.py:128-207"}
         if world == 1 and not args.no_cpu_baseline:
             sample_b = 1
             masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()
