@@ -8,7 +8,9 @@ math couples rows:
   * gather_rows      — all-gather of v_s / phi when a caller wants the global tensor (tiny, latency-bound);
   * allreduce_grads  — explainer training: sum of gradients over ranks, bucketed so each bucket is one large
                        RCCL call (xGMI is 7 point-to-point links per GPU: few large collectives, not many small);
-  * reduce_scalars   — loss / count accumulators.
+  * reduce_scalars   — loss / count accumulators;
+  * shard_masks_within_inputs / gather_masks_within_inputs — fewer inputs than ranks: the K masks of every input are split
+                       across ranks instead (reductions over k are additive).
 Masks never travel: every rank seeds an identical device generator and slices (bit-exact, cheap).
 """
 from __future__ import annotations
@@ -41,6 +43,45 @@ def shard_rows(masks: Tensor, n_inputs: int, k: int, rank: Optional[int] = None,
     (all k masks of its inputs) and its input range."""
     lo, hi = shard_range(n_inputs, rank, world_size)
     return masks[lo * k:hi * k], lo, hi
+
+
+def shard_masks_within_inputs(masks: Tensor, n_inputs: int, k: int, rank: Optional[int] = None,
+                              world_size: Optional[int] = None) -> Tuple[Tensor, int, int]:
+    """Fewer inputs than ranks (C4 with one input per step): every rank takes a contiguous slice [klo, khi) of the
+    K masks of EVERY input -> (rows [n_inputs*(khi-klo), ...] in the reference's input-major order, klo, khi).  Each rank then
+    embeds every input (layer-0 sharing still holds inside a rank); row results are rank-local, and the reductions over k
+    (the Shapley loss, sums of v_s) are additive: all-reduce the partial sums (reduce_scalars / allreduce)."""
+    klo, khi = shard_range(k, rank, world_size)
+    m = masks.reshape(n_inputs, k, *masks.shape[1:])[:, klo:khi]
+    return m.reshape(n_inputs * (khi - klo), *masks.shape[1:]).contiguous(), klo, khi
+
+
+def gather_masks_within_inputs(local: Tensor, n_inputs: int, k: int) -> Tensor:
+    """Inverse exchange of shard_masks_within_inputs: all-gather the per-rank [n_inputs*kl_r, ...] row blocks and interleave
+    them back into the global [n_inputs*k, ...] input-major order."""
+    r, w = world()
+    if w == 1:
+        return local
+    spans = [shard_range(k, q, w) for q in range(w)]
+    width = max(hi - lo for lo, hi in spans)
+    tail = tuple(local.shape[1:])
+    pad = torch.zeros((n_inputs, width) + tail, dtype=local.dtype, device=local.device)
+    lo, hi = spans[r]
+    pad[:, :hi - lo] = local.reshape(n_inputs, hi - lo, *tail)
+    out = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:, :h - l] for o, (l, h) in zip(out, spans)], dim=1).reshape(n_inputs * k, *tail)
+
+
+def shard_auto(masks: Tensor, n_inputs: int, k: int):
+    """by input when there is at least one input per rank, else by mask inside every input -> (rows, mode, lo, hi) with mode
+    "input" (lo, hi = input range) or "mask" (lo, hi = mask range of every input)."""
+    _, w = world()
+    if n_inputs >= w:
+        rows, lo, hi = shard_rows(masks, n_inputs, k)
+        return rows, "input", lo, hi
+    rows, lo, hi = shard_masks_within_inputs(masks, n_inputs, k)
+    return rows, "mask", lo, hi
 
 
 def gather_rows(local: Tensor, counts: Sequence[int]) -> Tensor:

@@ -35,6 +35,22 @@ def _worker(rank, world, port, out):
         assert torch.allclose(a.grad, torch.full((10,), 1.5)) and torch.allclose(b.grad, torch.full((3, 5), 15.0))
         tot = D.reduce_scalars([1.0 + rank, 2.0], torch.device("cpu"))
         assert tot == [3.0, 4.0]
+        # fewer inputs than ranks: the K masks of every input are split across ranks (SURVEY 8e fallback)
+        n1, k1 = 1, 5
+        m1 = torch.arange(n1 * k1 * p).reshape(n1 * k1, p)
+        rows, mode, klo, khi = D.shard_auto(m1, n1, k1)
+        assert mode == "mask" and rows.shape[0] == n1 * (khi - klo)
+        assert torch.equal(rows, m1.view(n1, k1, p)[:, klo:khi].reshape(-1, p))
+        back = D.gather_masks_within_inputs(rows.float() * 3.0, n1, k1)
+        assert torch.equal(back, m1.float() * 3.0)
+        n2, k2 = 3, 4   # several inputs, still split by mask: interleaving back into input-major order
+        m2 = torch.arange(n2 * k2 * 2).reshape(n2 * k2, 2)
+        r2, lo2, hi2 = D.shard_masks_within_inputs(m2, n2, k2)
+        assert torch.equal(D.gather_masks_within_inputs(r2, n2, k2), m2)
+        # the Shapley-loss partial sums over k are additive across ranks
+        part = float((r2.double() ** 2).sum())
+        assert abs(D.reduce_scalars([part], torch.device("cpu"))[0] - float((m2.double() ** 2).sum())) < 1e-9
+        assert D.shard_auto(masks, n_inputs, k)[1] == "input"
         out[rank] = 1
     finally:
         dist.destroy_process_group()
