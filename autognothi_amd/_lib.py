@@ -80,6 +80,7 @@ SIGNATURES = {
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),
     "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
+    "ag_encoder_forward_chained": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp, i32, i32, C.POINTER(i32), vp]),
     "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, C.POINTER(i32), vp]),
     "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp]),
     "ag_seq_compact_plan": (i32, [vp, i32, i32, vp, vp, vp]),

@@ -59,9 +59,13 @@ extern "C" size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R)
     return carve(desc, R, nullptr, nullptr);
 }
 
-extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, int R, int share,
-                                  const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
-                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+// chain: caller-owned row statistics [R*T, 2] handed from one call to the next (a model that runs the layers one call at
+// a time, e.g. to tap the stream after each: the LTT ladder): stats_in_ready = they describe d_h0 (written by the previous
+// call's last fc2), want_stats_out = the last layer's fc2 accumulates the statistics of d_h into them.
+static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int R, int share,
+                                const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
+                                void* d_workspace, size_t workspace_bytes, float* chain_stats, bool stats_in_ready,
+                                bool want_stats_out, int* stats_written, void* stream) {
     AG_REQUIRE(d && d_h0 && d_mask_bits && d_h && d_workspace, "ag_encoder_forward: null pointer");
     AG_REQUIRE(d->kind == AG_MASK_VIT_MUL || d->kind == AG_MASK_BERT_ADD, "ag_encoder_forward: bad kind %d", d->kind);
     AG_REQUIRE(d->dtype == AG_BF16 || d->dtype == AG_F32, "ag_encoder_forward: bad dtype %d", d->dtype);
@@ -75,10 +79,12 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
     const size_t es = dtype_size(dt);
     const int M = R * T;
     const bool vit = d->kind == AG_MASK_VIT_MUL;
+    if (chain_stats) ws.st1 = chain_stats;
+    if (stats_written) *stats_written = 0;
 
     const char* h_in = (const char*)d_h0;  // residual stream entering the layer (storage dtype)
     int in_share = share;                  // how many rows share one h_in sequence
-    bool st1_ready = false;                // ws.st1 holds the row statistics of h_in (written by the previous fc2)
+    bool st1_ready = chain_stats && stats_in_ready && share == 1;   // ws.st1 holds the row statistics of h_in (written by the previous fc2)
     hipStream_t hs = (hipStream_t)stream;
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
@@ -94,8 +100,9 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
                            ag_gemm_supports_ln_fold(Mo, H, H, ld_tok, H, ld_tok, AG_EPI_BIAS_RESID, dt);
         // will the NEXT layer fold its LN1?  then this layer's fc2 accumulates the statistics of what it writes
         bool next_fold1 = false;
-        if (vit && l + 1 < d->n_layers && !last_cls) {
-            const ag_layer_weights& wn = d->layers[l + 1];
+        const bool chain_out = chain_stats && want_stats_out && l + 1 == d->n_layers;   // the consumer is the next CALL (same shape)
+        if (vit && (l + 1 < d->n_layers || chain_out) && !last_cls) {
+            const ag_layer_weights& wn = chain_out ? d->layers[l] : d->layers[l + 1];
             next_fold1 = wn.ln1_g && wn.w_qkv_ln && ag_gemm_supports_ln_fold(M, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt) &&
                          ag_gemm_supports_ln_fold(Mo, H, I, I, ld_tok, H, AG_EPI_BIAS_RESID, dt);
         }
@@ -134,6 +141,7 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, stream));
             st1_ready = next_fold1;
+            if (chain_out && stats_written) *stats_written = next_fold1 ? 1 : 0;
         } else {
             const char* a = ws.hx;  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
             if (w.ln1_g) {
@@ -160,6 +168,21 @@ extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, in
         in_share = 1;
     }
     return AG_OK;
+}
+
+extern "C" int ag_encoder_forward(const ag_encoder_desc* d, const void* d_h0, int R, int share,
+                                  const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
+                                  void* d_workspace, size_t workspace_bytes, void* stream) {
+    return encoder_forward_impl(d, d_h0, R, share, d_mask_bits, d_h, cls_only_last, d_workspace, workspace_bytes, nullptr, false, false, nullptr, stream);
+}
+
+extern "C" int ag_encoder_forward_chained(const ag_encoder_desc* d, const void* d_h0, int R, int share,
+                                          const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
+                                          void* d_workspace, size_t workspace_bytes, float* d_row_stats, int stats_in_ready,
+                                          int want_stats_out, int* stats_written, void* stream) {
+    AG_REQUIRE(d_row_stats && stats_written, "ag_encoder_forward_chained: null statistics buffer / flag");
+    return encoder_forward_impl(d, d_h0, R, share, d_mask_bits, d_h, cls_only_last, d_workspace, workspace_bytes, d_row_stats,
+                                stats_in_ready != 0, want_stats_out != 0, stats_written, stream);
 }
 
 

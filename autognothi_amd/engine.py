@@ -163,8 +163,12 @@ class PackedEncoder:
         self._keep = [keep, arr]
         return d
 
-    def forward(self, h0: Tensor, rows: int, share: int, mask_bits: Tensor, cls_only_last: bool, dtype: int) -> Tensor:
-        """h0 [rows/share, T, H] -> hidden [rows, T, H], both in the storage dtype (the residual stream)."""
+    def forward(self, h0: Tensor, rows: int, share: int, mask_bits: Tensor, cls_only_last: bool, dtype: int,
+                chain: Optional[list] = None) -> Tensor:
+        """h0 [rows/share, T, H] -> hidden [rows, T, H], both in the storage dtype (the residual stream).
+        ``chain`` = [row_stats fp32 [rows*T*2], stats_ready, want_stats_out]: layer-by-layer callers hand the LayerNorm-fold
+        row statistics from one call to the next (ag_encoder_forward_chained); chain[1] is updated in place with whether
+        this call left valid statistics of its output behind."""
         L.require_gpu(h0, mask_bits)
         if h0.dtype != ops.storage_dtype(dtype):
             h0 = ops.cast(h0, dtype)
@@ -180,6 +184,14 @@ class PackedEncoder:
                 L.check(L.lib().ag_bert_encoder_forward_pruned(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
                                                                L.ptr(ws), ws.numel(), C.byref(n_packed), L.stream()))
                 LAST_PACKED_ROWS = int(n_packed.value)
+                return out
+            if chain is not None:
+                st, st_in, st_out = chain
+                written = C.c_int32(0)
+                L.check(L.lib().ag_encoder_forward_chained(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
+                                                           1 if cls_only_last else 0, L.ptr(ws), ws.numel(), L.ptr(st),
+                                                           1 if st_in else 0, 1 if st_out else 0, C.byref(written), L.stream()))
+                chain[1] = bool(written.value)
                 return out
             L.check(L.lib().ag_encoder_forward(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
                                                1 if cls_only_last else 0, L.ptr(ws), ws.numel(), L.stream()))

@@ -164,9 +164,12 @@ class LttViTModel(nn.Module):
                 raise ValueError(f"side branch {i_b} out of range (model has {self.num_side_branches})")
         side: Dict[int, Optional[Tensor]] = {i_b: None for i_b in branches}
         enc = self.encoder
+        # LayerNorm-fold row statistics of the stream, produced by layer i's fc2 epilogue for layer i+1's QKV (one call per layer)
+        chain = [torch.empty(rows * t * 2, dtype=torch.float32, device=hidden.device), False, True]
         for i_ly in range(enc.num_layers):
             share = rows // b if i_ly == 0 else 1
-            hidden = self._bb[i_ly].forward(hidden, rows, share, bits, False, dtype)
+            chain[2] = i_ly + 1 < enc.num_layers
+            hidden = self._bb[i_ly].forward(hidden, rows, share, bits, False, dtype, chain=chain)
             if i_ly >= enc._ltt_freeze_layer:
                 continue
             flat = hidden.view(rows * t, c.hidden_size)

@@ -213,6 +213,16 @@ size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R);
 int ag_encoder_forward(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
                        const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
                        void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same forward for callers that run the layers one call at a time (the LTT ladder taps the stream after every backbone
+ * layer, reference models/ltt_vit.py:423-436): d_row_stats [R*T, 2] floats, caller-owned, carries the LayerNorm-fold row
+ * statistics from one call to the next.  stats_in_ready: they describe d_h0 (written by the previous call with
+ * want_stats_out that reported *stats_written = 1, same R, share == 1); want_stats_out: the last layer's fc2 accumulates the
+ * statistics of d_h into them when the shapes fold (ViT, bf16, large GEMMs) and *stats_written (host int) says whether it
+ * did: pass that value as the next call's stats_in_ready. */
+int ag_encoder_forward_chained(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
+                               const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
+                               void* d_workspace, size_t workspace_bytes, float* d_row_stats, int stats_in_ready,
+                               int want_stats_out, int* stats_written, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward-pass building blocks (fp32) for explainer / surrogate training — what torch.autograd does
