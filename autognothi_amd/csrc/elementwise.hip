@@ -71,6 +71,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
     }
 }
 
+// Narrow rows (H <= 128: the 96-wide LTT side network): 8 lanes per row, 8 rows per wave — a 96-element row would leave 40
+// of a wave's 64 lanes idle in the kernel above.  Reductions are three xor-shuffles inside the 8-lane group.
+template <typename XT, typename T>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const XT* __restrict__ x, int64_t ldx, int rows, int H,
+                                                               const float* __restrict__ g, const float* __restrict__ b,
+                                                               float eps, T* __restrict__ ys, float* __restrict__ yf) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
+    const bool live = row < rows;
+    const XT* xr = x + (int64_t)(live ? row : 0) * ldx;
+    const int nv = H >> 2;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 8;
+        if (c < nv) {
+            v[i] = load4_as_f32(xr + c * 4);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 8;
+        if (c < nv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 8;
+        if (c < nv) {
+            const float4 gv = *reinterpret_cast<const float4*>(g + c * 4);
+            const float4 bv = *reinterpret_cast<const float4*>(b + c * 4);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gv.x + bv.x; o.y = (v[i].y - mean) * rstd * gv.y + bv.y;
+            o.z = (v[i].z - mean) * rstd * gv.z + bv.z; o.w = (v[i].w - mean) * rstd * gv.w + bv.w;
+            if (yf) *reinterpret_cast<float4*>(yf + (int64_t)row * H + c * 4) = o;
+            if (ys) {
+                T* yp = ys + (int64_t)row * H + c * 4;
+                if (sizeof(T) == 2) *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+                else *reinterpret_cast<float4*>(yp) = o;
+            }
+        }
+    }
+}
+
 // im2col for Conv2d(k = s = patch): cols[(b*gh + py)*gw + px][c*patch*patch + iy*patch + ix]
 template <typename T>
 __global__ void im2col_kernel(const float* __restrict__ img, int B, int C, int px, int patch, T* __restrict__ cols) {
@@ -272,15 +328,23 @@ extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows,
     AG_REQUIRE(x_dtype == AG_F32 || x_dtype == AG_BF16, "ag_layernorm: bad x_dtype %d", x_dtype);
     AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * ((double)dtype_size(x_dtype) + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s);
     if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
+    const bool narrow = H <= 128;                      // 8 lanes per row, 32 rows per block
+    const int nblk = narrow ? ceil_div(rows, 32) : blocks;
+#define AG_LN_LAUNCH(XT_, T_, X_, Y_)                                                                                              \
+    do {                                                                                                                           \
+        if (narrow) hipLaunchKernelGGL((layernorm_narrow_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32); \
+        else hipLaunchKernelGGL((layernorm_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32);               \
+    } while (0)
     if (x_dtype == AG_F32) {
         const float* x = (const float*)d_x;
-        if (dtype == AG_BF16) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
-        else hipLaunchKernelGGL((layernorm_kernel<float, float>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
+        if (dtype == AG_BF16) AG_LN_LAUNCH(float, bf16_t, x, (bf16_t*)d_y_store);
+        else AG_LN_LAUNCH(float, float, x, (float*)d_y_store);
     } else {
         const bf16_t* x = (const bf16_t*)d_x;
-        if (dtype == AG_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
-        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (float*)d_y_store, d_y_f32);
+        if (dtype == AG_BF16) AG_LN_LAUNCH(bf16_t, bf16_t, x, (bf16_t*)d_y_store);
+        else AG_LN_LAUNCH(bf16_t, float, x, (float*)d_y_store);
     }
+#undef AG_LN_LAUNCH
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -82,7 +82,7 @@ def test_gemm_rejects_bad_k(cuda_device):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("h", [192, 768, 1024])
+@pytest.mark.parametrize("h", [96, 128, 20, 192, 768, 1024])   # <= 128: the 8-lanes-per-row kernel (96 = the LTT side width)
 def test_layernorm(cuda_device, dtype, h):
     from autognothi_amd import ops
     g = np.random.default_rng(h)
