@@ -463,7 +463,10 @@ __global__ __launch_bounds__(512) void attn_narrow_bf16_kernel(AttnArgs p) {
         const int kc = k < T ? k : T - 1;
 #pragma unroll
         for (int c = 0; c < D / 8; ++c) {
-            *reinterpret_cast<uint4*>(ldsK + k * KROW + c * 16) = *reinterpret_cast<const uint4*>(kbase + (long)kc * rowstride + c * 16);
+            uint4 kv = *reinterpret_cast<const uint4*>(kbase + (long)kc * rowstride + c * 16);
+            // ViT: a masked key has logit exactly 0 for every query (scores * mask): zero its K row, no per-score mask work
+            if (MODE == AG_MASK_VIT_MUL && !p.cu && !((p.mask[(long)row * p.Tw + (kc >> 5)] >> (kc & 31)) & 1u)) kv = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(ldsK + k * KROW + c * 16) = kv;
             const uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)kc * rowstride + c * 16);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -503,12 +506,13 @@ __global__ __launch_bounds__(512) void attn_narrow_bf16_kernel(AttnArgs p) {
             const uint32_t mwl = mw >> (4 * lh);
             const int kvalid = T - kb * 32;
             float bmax = NEG_BIG;
+            if (MODE == AG_MASK_BERT_ADD && !p.cu) {   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kk = (i & 3) + 8 * (i >> 2);
-                const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
-                const uint32_t sb = __float_as_uint(s[i]);
-                s[i] = __uint_as_float(MODE == AG_MASK_VIT_MUL ? (sb & m) : ((sb & m) | (NEG_BIG_BITS & ~m)));
+                for (int i = 0; i < 16; ++i) {
+                    const int kk = (i & 3) + 8 * (i >> 2);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)mwl, kk, 1);
+                    s[i] = __uint_as_float((__float_as_uint(s[i]) & m) | (NEG_BIG_BITS & ~m));
+                }
             }
             if (kvalid < 32) {
                 const uint32_t vwl = ((1u << kvalid) - 1u) >> (4 * lh);
@@ -525,9 +529,20 @@ __global__ __launch_bounds__(512) void attn_narrow_bf16_kernel(AttnArgs p) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
                 bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            const float m_new = fmaxf(m_run, bmax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            const float mc = -m_new * c2;
+            if (kb == 0) {
+                m_run = bmax;
+            } else {   // the reference max is raised only when a block beats it by 2^8 (as attn_softmax_pv)
+                const bool need = bmax > m_run + 8.0f / c2;
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                    const float m_new = need ? bmax : m_run;
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                    l_run *= alpha;
+                    m_run = m_new;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o0[i] *= alpha;
+                }
+            }
+            const float mc = -m_run * c2;
             float psum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -535,10 +550,7 @@ __global__ __launch_bounds__(512) void attn_narrow_bf16_kernel(AttnArgs p) {
                 s[i] = pv;
                 psum += pv;
             }
-            l_run = fmaf(l_run, alpha, psum);
-            m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o0[i] *= alpha;
+            l_run += psum;
             // P^T fragments: regs 8st..8st+7 -> k-step st; element j <-> key 16st + 8(j>>2) + 4lh + (j&3)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
