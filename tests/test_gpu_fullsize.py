@@ -108,3 +108,35 @@ def test_shapley_normalize_full_size_and_efficiency(cuda_device):
     ref = osh.normalize_shapley_explanation(pred, grand, null)                                 # [B, T, C]
     np.testing.assert_allclose(phi, ref[:, 1:].transpose(0, 2, 1), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(phi.sum(-1) + ref[:, 0], grand - null, rtol=0, atol=2e-5)
+
+
+def test_chained_per_layer_forward_equals_one_call(cuda_device):
+    """ag_encoder_forward_chained (one call per layer, LayerNorm-fold row statistics handed from call to call: the LTT
+    backbone) against ag_encoder_forward over all layers, on the ViT-base encoder with layer-0 sharing."""
+    from autognothi_amd import _lib as L, engine, ops
+    recipe, cfg, m, xs = _setup("vit_base", cuda_device, 2, seed=5)
+    P = recipe.n_players(cfg)
+    T = P + 1
+    rng = ops.DeviceMT19937(cuda_device, 31)
+    _, bits = ops.mask_shapley_new(rng, 2 * K, P, want_i64=False, want_bits=True)
+    dtype = engine.get_precision()
+    vit = m.vit
+    vit.packed()                      # (builds the patch-embedding pack that embed() uses)
+    layers = list(vit.encoder.layers)
+    c = cfg
+    whole = engine.PackedEncoder(layers, L.AG_MASK_VIT_MUL, T, c.hidden_size, c.intermediate_size, c.num_attention_heads, c.layer_norm_eps)
+    singles = [engine.PackedEncoder([ly], L.AG_MASK_VIT_MUL, T, c.hidden_size, c.intermediate_size, c.num_attention_heads, c.layer_norm_eps)
+               for ly in layers]
+    h0 = vit.embed(xs, dtype)
+    rows = 2 * K
+    ref = whole.forward(h0, rows, K, bits, False, dtype).float().cpu().numpy()
+    chain = [torch.empty(rows * T * 2, dtype=torch.float32, device=cuda_device), False, True]
+    h, used = h0, []
+    for i, enc in enumerate(singles):
+        chain[2] = i + 1 < len(singles)
+        used.append(chain[1])
+        h = enc.forward(h, rows, K if i == 0 else 1, bits, False, dtype, chain=chain)
+    assert used[0] is False and all(used[1:]), used      # every layer after the first consumed its predecessor's statistics
+    got = h.float().cpu().numpy()
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(got - ref).max()) <= 3e-2 * scale and float(np.abs(got - ref).mean()) <= 2e-3 * scale
