@@ -71,6 +71,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
     }
 }
 
+// bf16 -> bf16 rows of 8*k elements, k <= 128: half a wave per row, 16-byte loads and stores (the 8-byte groups of the generic
+// kernel leave the memory pipeline with twice the instructions per byte)
+__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __restrict__ x, int64_t ldx, int rows, int H,
+                                                               const float* __restrict__ g, const float* __restrict__ b,
+                                                               float eps, bf16_t* __restrict__ ys, float* __restrict__ yf) {
+    const int lane = threadIdx.x & 63, sub = lane & 31;
+    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = row < rows;
+    const bf16_t* xr = x + (int64_t)(live ? row : 0) * ldx;
+    const int nc = H >> 3;       // 8-element chunks per row (<= 128)
+    uint4 raw[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 32;
+        raw[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (c < nc) {
+            raw[i] = *reinterpret_cast<const uint4*>(xr + c * 8);
+            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xFFFF0000u);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 32;
+        if (c < nc) {
+            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __uint_as_float(w[e] << 16) - mean, bb = __uint_as_float(w[e] & 0xFFFF0000u) - mean;
+                sq += a * a + bb * bb;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)H + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + i * 32;
+        if (c < nc) {
+            const uint32_t w[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            const float4 g0 = *reinterpret_cast<const float4*>(g + c * 8), g1 = *reinterpret_cast<const float4*>(g + c * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] = (__uint_as_float(w[e] << 16) - mean) * rstd * gv[2 * e] + bv[2 * e];
+                o[2 * e + 1] = (__uint_as_float(w[e] & 0xFFFF0000u) - mean) * rstd * gv[2 * e + 1] + bv[2 * e + 1];
+            }
+            if (yf) {
+                *reinterpret_cast<float4*>(yf + (int64_t)row * H + c * 8) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(yf + (int64_t)row * H + c * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+            if (ys) *reinterpret_cast<uint4*>(ys + (int64_t)row * H + c * 8) =
+                        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+    }
+}
+
 // Narrow rows (H <= 128: the 96-wide LTT side network): 8 lanes per row, 8 rows per wave — a 96-element row would leave 40
 // of a wave's 64 lanes idle in the kernel above.  Reductions are three xor-shuffles inside the 8-lane group.
 template <typename XT, typename T>
@@ -341,7 +408,10 @@ extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows,
         else AG_LN_LAUNCH(float, float, x, (float*)d_y_store);
     } else {
         const bf16_t* x = (const bf16_t*)d_x;
-        if (dtype == AG_BF16) AG_LN_LAUNCH(bf16_t, bf16_t, x, (bf16_t*)d_y_store);
+        static const bool wide_off = getenv("AG_LN_WIDE") && atoi(getenv("AG_LN_WIDE")) == 0;
+        if (dtype == AG_BF16 && !narrow && !wide_off && H % 8 == 0 && H <= 1024 && ldx % 8 == 0)
+            hipLaunchKernelGGL(layernorm_bf16x8_kernel, dim3(ceil_div(rows, 8)), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
+        else if (dtype == AG_BF16) AG_LN_LAUNCH(bf16_t, bf16_t, x, (bf16_t*)d_y_store);
         else AG_LN_LAUNCH(bf16_t, float, x, (float*)d_y_store);
     }
 #undef AG_LN_LAUNCH
