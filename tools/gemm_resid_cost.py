@@ -3,6 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autognothi_amd import _lib as L, ops
+if os.environ.get("GB_LIB"): L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ["GB_LIB"])
 dev = torch.device("cuda:0"); M = int(os.environ.get("GB_M", 302592))
 def mk(n, k): return ((torch.rand((n, k), device=dev) * 2 - 1) / k ** 0.5).to(torch.bfloat16)
 out = torch.empty((M, 768), dtype=torch.bfloat16, device=dev)
