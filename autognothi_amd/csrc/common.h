@@ -69,17 +69,16 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, uint64_t idx, float p) 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float fast_gelu(float x) {
-    // bf16-mode GELU: erf(z) ~= clamp(z * Q(min(z^2, 9)), -1, 1), Q = degree-8 minimax-style fit on [0, 9]
-    // (|erf err| <= 4e-5, |gelu err| <= 9.3e-5: below bf16 resolution of the O(1) activations).  Pure FMA
-    // chain: no transcendental, packs into v_pk_fma_f32.
-    const float z = x * 0.70710678118654752440f;
-    const float u = fminf(z * z, 9.0f);
-    float q = 4.817588014e-08f;
-    q = fmaf(q, u, -2.219400514e-06f); q = fmaf(q, u, 4.523251628e-05f); q = fmaf(q, u, -5.446516761e-04f);
-    q = fmaf(q, u, 4.389698035e-03f); q = fmaf(q, u, -2.550513516e-02f); q = fmaf(q, u, 1.116382379e-01f);
-    q = fmaf(q, u, -3.756677550e-01f); q = fmaf(q, u, 1.128335659e+00f);
-    const float e = fminf(fmaxf(z * q, -1.0f), 1.0f);
-    return 0.5f * x * (1.0f + e);
+    // bf16-mode GELU:  x * Phi(x) ~= x * sigmoid(x * (c0 + c1 x^2 + c2 x^4))  =  x / (1 + exp2(x * P(min(x^2, 50)))),
+    // P's coefficients carry the -log2(e).  Minimax fit against the erf form (nn.GELU() default, reference
+    // models/vanilla_vit.py:491): |err| <= 2.6e-5 on the whole line (the degree-8 erf polynomial this replaces: 9.3e-5),
+    // far below the bf16 resolution of the activations it produces.  7 plain VALU ops + v_exp_f32 + v_rcp_f32 per element
+    // instead of 16: the fc1 epilogue runs with the matrix cores idle (it was 22 % of that kernel).  The clamp keeps P
+    // positive (c2 < 0) so the sigmoid saturates the right way for |x| > 7; exp2 overflow gives 1/inf = 0 -> -0.0.
+    const float u = fminf(x * x, 50.0f);
+    float p = fmaf(0.0010142630198970437f, u, -0.10677572339773178f);
+    p = fmaf(p, u, -2.301121234893799f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
