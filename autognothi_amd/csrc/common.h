@@ -68,17 +68,38 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, uint64_t idx, float p) 
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// bf16-mode GELU with ONE transcendental:  with a = min(|x|, 9) and Q(a) = 1 - Phi(a),
+//     x Phi(x) = max(x, 0) - a Q(a),        Q(a) ~= 0.5 * exp2(a * (c0 + c1 a + c2 a^2 + c3 a^3))
+// (log2(2Q) is smooth: a cubic times a is a minimax fit to |gelu err| <= 1.7e-5 on the whole line against the erf form the
+// reference uses, nn.GELU() in models/vanilla_vit.py:491; the degree-8 erf polynomial this replaces had 9.3e-5 and cost 16
+// VALU per element).  6 plain VALU + v_exp_f32 per element: the fc1 epilogue runs with the matrix cores idle, where a
+// transcendental costs about four plain instructions.  The clamp keeps the cubic negative; the 0.5 is the -1 in the last FMA.
 __device__ __forceinline__ float fast_gelu(float x) {
-    // bf16-mode GELU:  x * Phi(x) ~= x * sigmoid(x * (c0 + c1 x^2 + c2 x^4))  =  x / (1 + exp2(x * P(min(x^2, 50)))),
-    // P's coefficients carry the -log2(e).  Minimax fit against the erf form (nn.GELU() default, reference
-    // models/vanilla_vit.py:491): |err| <= 2.6e-5 on the whole line (the degree-8 erf polynomial this replaces: 9.3e-5),
-    // far below the bf16 resolution of the activations it produces.  7 plain VALU ops + v_exp_f32 + v_rcp_f32 per element
-    // instead of 16: the fc1 epilogue runs with the matrix cores idle (it was 22 % of that kernel).  The clamp keeps P
-    // positive (c2 < 0) so the sigmoid saturates the right way for |x| > 7; exp2 overflow gives 1/inf = 0 -> -0.0.
-    const float u = fminf(x * x, 50.0f);
-    float p = fmaf(0.0010142630198970437f, u, -0.10677572339773178f);
-    p = fmaf(p, u, -2.301121234893799f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+    const float a = fminf(fabsf(x), 9.0f);
+    float p = fmaf(0.003938046284019947f, a, -0.044971074908971786f);
+    p = fmaf(p, a, -0.46572810411453247f);
+    p = fmaf(p, a, -1.1492576599121094f);
+    const float e = __builtin_amdgcn_exp2f(fmaf(p, a, -1.0f));
+    return fmaf(-a, e, fmaxf(x, 0.0f));
+}
+
+// the same on two elements at a time: the Horner chain and the last FMA run as packed fp32 instructions (two elements per
+// issue slot in an epilogue that has no MFMAs to share the slots with)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ f32x2_t fast_gelu2(f32x2_t x) {
+    f32x2_t a, r;
+    a.x = fminf(fabsf(x.x), 9.0f); a.y = fminf(fabsf(x.y), 9.0f);
+    r.x = fmaxf(x.x, 0.0f); r.y = fmaxf(x.y, 0.0f);
+    const f32x2_t c3 = {0.003938046284019947f, 0.003938046284019947f}, c2 = {-0.044971074908971786f, -0.044971074908971786f},
+                  c1 = {-0.46572810411453247f, -0.46572810411453247f}, c0 = {-1.1492576599121094f, -1.1492576599121094f},
+                  m1 = {-1.0f, -1.0f};
+    f32x2_t p = __builtin_elementwise_fma(c3, a, c2);
+    p = __builtin_elementwise_fma(p, a, c1);
+    p = __builtin_elementwise_fma(p, a, c0);
+    const f32x2_t q = __builtin_elementwise_fma(p, a, m1);
+    f32x2_t e;
+    e.x = __builtin_amdgcn_exp2f(q.x); e.y = __builtin_amdgcn_exp2f(q.y);
+    return __builtin_elementwise_fma(-a, e, r);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -205,8 +205,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 v[2] += __uint_as_float(rcur[sn].y << 16); v[3] += __uint_as_float(rcur[sn].y & 0xFFFF0000u);
             }
             if (EPI == AG_EPI_BIAS_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fast_gelu(v[e]);
+                const f32x2_t g0 = fast_gelu2(f32x2_t{v[0], v[1]}), g1 = fast_gelu2(f32x2_t{v[2], v[3]});
+                v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
             }
             if (EPI == AG_EPI_BIAS_TANH) {
 #pragma unroll

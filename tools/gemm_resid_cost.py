@@ -11,12 +11,13 @@ r = (torch.rand((M, 768), device=dev) * 2 - 1).to(torch.bfloat16)
 bias = torch.rand(768, device=dev)
 for k in (768, 3072):
     a = (torch.rand((M, k), device=dev) * 2 - 1).to(torch.bfloat16); w = mk(768, k)
-    for name, epi, rr in (("bias", L.AG_EPI_BIAS, None), ("bias+resid", L.AG_EPI_BIAS_RESID, r)):
-        for _ in range(10): ops.gemm(a, w, bias, epi, L.AG_BF16, resid=rr, out=out)
+    st = torch.zeros((M, 2), dtype=torch.float32, device=dev)
+    for name, epi, rr, so in (("bias", L.AG_EPI_BIAS, None, None), ("bias+resid", L.AG_EPI_BIAS_RESID, r, None), ("bias+resid+stats", L.AG_EPI_BIAS_RESID, r, st)):
+        for _ in range(10): ops.gemm(a, w, bias, epi, L.AG_BF16, resid=rr, out=out, stats_out=so)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(30): ops.gemm(a, w, bias, epi, L.AG_BF16, resid=rr, out=out)
+        for _ in range(30): ops.gemm(a, w, bias, epi, L.AG_BF16, resid=rr, out=out, stats_out=so)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 30 * 1e3
-        print(f"K={k} N=768 {name:11s}: {us:7.1f} us  {2.0 * M * 768 * k / us / 1e6:6.0f} TF", flush=True)
+        print(f"K={k} N=768 {name:17s}: {us:7.1f} us  {2.0 * M * 768 * k / us / 1e6:6.0f} TF", flush=True)
