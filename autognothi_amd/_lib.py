@@ -58,6 +58,8 @@ SIGNATURES = {
     "ag_softmax_rows": (i32, [vp, vp, i32, i32, vp]),
     "ag_shapley_normalize": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ag_shapley_normalize_bwd": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "ag_shapley_normalize_rows": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "ag_shapley_normalize_rows_bwd": (i32, [vp, i32, i32, i32, vp, vp]),
     "ag_shapley_loss": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "ag_transpose_f32": (i32, [vp, i32, i32, i64, vp, i64, vp]),

@@ -290,20 +290,25 @@ __global__ __launch_bounds__(256) void bert_embed_kernel(const int64_t* __restri
 }
 
 // (sum, sumsq) of each row of the bf16 stream — LayerNorm statistics for the folded GEMM epilogue when the
-// producing GEMM did not accumulate them (layer 0's embeddings)
+// producing GEMM did not emit them (layer 0's embeddings).  Same slab-major partial-sum layout as the GEMM producer
+// (gemm_big.hip): stats[s][row] covers columns [256 s, 256 s + 256); one loop iteration of the wave = one slab.
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, int64_t ldx, int rows, int H, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const bf16_t* xr = x + (int64_t)row * ldx;
-    float s = 0.f, q = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-        const float4 v = load4_as_f32(xr + c);
-        s += (v.x + v.y) + (v.z + v.w);
-        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    const int64_t slab = 2 * (int64_t)rows;
+    for (int c0 = 0, s_i = 0; c0 < H; c0 += 256, ++s_i) {
+        float s = 0.f, q = 0.f;
+        const int c = c0 + lane * 4;
+        if (c < H) {
+            const float4 v = load4_as_f32(xr + c);
+            s = (v.x + v.y) + (v.z + v.w);
+            q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        s = wave_sum(s); q = wave_sum(q);
+        if (lane == 0) { stats[s_i * slab + 2 * (int64_t)row] = s; stats[s_i * slab + 2 * (int64_t)row + 1] = q; }
     }
-    s = wave_sum(s); q = wave_sum(q);
-    if (lane == 0) { stats[2 * (int64_t)row] = s; stats[2 * (int64_t)row + 1] = q; }
 }
 
 __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int C) {

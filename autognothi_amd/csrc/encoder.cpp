@@ -24,8 +24,8 @@ struct Ws {
     char* inter;   // [M, I]
     char* hx;      // [M, H]   residual stream after the attention block
     char* ha;      // [M, H]   BERT: post-attention LayerNorm output
-    float* st1;    // [M, 2]   (sum, sumsq) of the rows entering LN1 (folded into the QKV GEMM)
-    float* st2;    // [M, 2]   same for LN2 (folded into fc1)
+    float* st1;    // [S, M, 2]  per-256-column partial (sum, sumsq) of the rows entering LN1 (folded into the QKV GEMM), S = ceil(H/256)
+    float* st2;    // [S, M, 2]  same for LN2 (folded into fc1)
     int* idx;      // [R+1 + M] token pruning plan
 };
 
@@ -42,8 +42,9 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* inter = take(M * d->I * es);
     char* hx = take(M * d->H * es);
     char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * es) : nullptr;
-    char* st1 = take(M * 2 * sizeof(float));
-    char* st2 = take(M * 2 * sizeof(float));
+    const size_t S = ((size_t)d->H + 255) / 256;
+    char* st1 = take(S * M * 2 * sizeof(float));
+    char* st2 = take(S * M * 2 * sizeof(float));
     char* idx = take((M + (size_t)R + 1) * sizeof(int));   // token pruning: cu_seqlens [R+1] + packed-row sources [M]
     if (ws) ws->idx = (int*)idx;
     if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; ws->st1 = (float*)st1; ws->st2 = (float*)st2; }
@@ -59,7 +60,7 @@ extern "C" size_t ag_encoder_workspace_bytes(const ag_encoder_desc* desc, int R)
     return carve(desc, R, nullptr, nullptr);
 }
 
-// chain: caller-owned row statistics [R*T, 2] handed from one call to the next (a model that runs the layers one call at
+// chain: caller-owned row statistics [ceil(H/256), R*T, 2] handed from one call to the next (a model that runs the layers one call at
 // a time, e.g. to tap the stream after each: the LTT ladder): stats_in_ready = they describe d_h0 (written by the previous
 // call's last fc2), want_stats_out = the last layer's fc2 accumulates the statistics of d_h into them.
 static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int R, int share,
@@ -124,7 +125,6 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
         // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
-        if (fold2) AG_HIP_CHECK(hipMemsetAsync(ws.st2, 0, (size_t)Mo * 2 * sizeof(float), hs));
         TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
                     nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, stream));
         if (vit) {
@@ -137,7 +137,6 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                             nullptr, nullptr, 0.f, nullptr, stream));
             }
             // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
-            if (next_fold1) AG_HIP_CHECK(hipMemsetAsync(ws.st1, 0, (size_t)M * 2 * sizeof(float), hs));
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, stream));
             st1_ready = next_fold1;

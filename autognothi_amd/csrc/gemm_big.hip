@@ -36,8 +36,14 @@ struct BigArgs {
     int M, N, K;
     // LayerNorm folding (ViT pre-LN, bf16 mode): consumer side  out = rstd[m]*(acc - mean[m]*ln_s[n]) + bias[n]
     // with (sum, sumsq) of row m in ln_stats[2m..]; producer side accumulates (sum, sumsq) of the rows it writes.
+    // Row statistics travel as per-256-column partial sums, slab-major: stats[s][m] = (sum, sumsq) of columns
+    // [256 s, 256 s + 256) of row m, S = ceil(H / 256) slabs of 2 M floats.  Every element is written exactly once by the
+    // producing tile (plain stores: no zero fill, no atomics) and the consumer adds the slabs in a fixed order, so the
+    // folded LayerNorm is bit-reproducible from run to run.
     const float* ln_stats; const float* ln_s; float ln_eps; float ln_inv_h;
     float* stats_out;
+    long stats_slab;   // floats between slabs (= 2 M)
+    int ln_nslab;      // slabs of ln_stats (= ceil(K / 256))
     unsigned long long* dbg;  // diagnostic build only
     int ngrp;      // N-tiles per tile-order group (>= 1)
     int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
@@ -109,11 +115,12 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
 // Out-of-range rows / columns are clamped for the loads and masked at the stores; no divergent branches.
 template <int EPI, bool LNF, bool STATS>
 __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
-                                              char* stg, const int lane) {
+                                              char* stg, const int lane, const char* smem_base, const int tile_n) {
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
     constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
     constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
+    constexpr int STAT_OFF = 8192;  // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its 16 KB
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
 
     // ---- column constants ----
@@ -135,13 +142,38 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         for (int sn = 0; sn < 4; ++sn) sv[sn] = *reinterpret_cast<const float4*>(p.ln_s + ncl[sn]);
     }
     // ---- row constants ----
+    // The four lanes that share a row (fq = 0..3) each fetch ONE slab's partial of it; two xor-shuffles add the four
+    // partials in the same order on every lane: (p0 + p1) + (p2 + p3).  More than four slabs (H > 1024): further rounds.
     float2 st[8];
     if (LNF) {
+        const bool have = fq < p.ln_nslab;
+        const float* sp = p.ln_stats + (have ? fq : 0) * p.stats_slab;
 #pragma unroll
         for (int sm = 0; sm < 8; ++sm) {
             int m = mw0 + sm * 16 + frow;
             m = m < p.M ? m : p.M - 1;
-            st[sm] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m);
+            st[sm] = *reinterpret_cast<const float2*>(sp + 2 * (long)m);
+        }
+#pragma unroll
+        for (int sm = 0; sm < 8; ++sm) {
+            float sx = have ? st[sm].x : 0.f, sy = have ? st[sm].y : 0.f;
+            sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
+            sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
+            st[sm] = make_float2(sx, sy);
+        }
+        for (int s0 = 4; s0 < p.ln_nslab; s0 += 4) {      // (not reached by the shipped widths)
+            const bool hv = s0 + fq < p.ln_nslab;
+            const float* sq = p.ln_stats + (hv ? s0 + fq : 0) * p.stats_slab;
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm) {
+                int m = mw0 + sm * 16 + frow;
+                m = m < p.M ? m : p.M - 1;
+                const float2 v = *reinterpret_cast<const float2*>(sq + 2 * (long)m);
+                float sx = hv ? v.x : 0.f, sy = hv ? v.y : 0.f;
+                sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
+                sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
+                st[sm].x += sx; st[sm].y += sy;
+            }
         }
     }
     // residual row of output row m: ((m / T) / share) * T + (m % T); walked incrementally (m advances by 16)
@@ -226,13 +258,11 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 }
             }
         }
-        if (STATS) {  // lanes frow + 16*fq hold parts of row m: combine the 4 column groups, one atomic pair per wave and row
+        if (STATS) {  // lanes frow + 16*fq hold parts of row m: combine the 4 column groups; this wave's 64-column partial of
+            // the row goes to LDS (combined with the other three column waves after the loop)
             row_s += __shfl_xor(row_s, 16, 64); row_q += __shfl_xor(row_q, 16, 64);
             row_s += __shfl_xor(row_s, 32, 64); row_q += __shfl_xor(row_q, 32, 64);
-            if (fq == 0 && m < p.M) {
-                atomicAdd(p.stats_out + 2 * (long)m, row_s);
-                atomicAdd(p.stats_out + 2 * (long)m + 1, row_q);
-            }
+            if (fq == 0) *reinterpret_cast<float2*>(stg + STAT_OFF + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
         }
         if (!OUT_F32 && (sm & 1)) {
             // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B)
@@ -249,6 +279,24 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                     } else *dstp = val;
                 }
             }
+        }
+    }
+    if (STATS) {
+        // the four column waves (wn = 0..3) of this row half have each left 128 row partials in their LDS pieces: add them
+        // in wave order and store ONE (sum, sumsq) per row and column tile.  Wave wn finishes rows [32 wn, 32 wn + 32).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int wave = (int)((stg - smem_base) >> 14), wn = wave & 3;
+        if (lane < 32) {
+            const int row = wn * 32 + lane;
+            const char* half = smem_base + (wave & 4) * 16384 + STAT_OFF + row * 8;
+            float2 t = *reinterpret_cast<const float2*>(half);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float2 u = *reinterpret_cast<const float2*>(half + w * 16384);
+                t.x += u.x; t.y += u.y;
+            }
+            const int m = mw0 + row;
+            if (m < p.M) *reinterpret_cast<float2*>(p.stats_out + (long)tile_n * p.stats_slab + 2 * (long)m) = t;
         }
     }
 }
@@ -415,7 +463,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     AG_MARK(123)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (already true: the last half-step waited for 0)
     if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
-    wave_epilogue<EPI, VAR == 1, VAR == 2>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane);
+    wave_epilogue<EPI, VAR == 1, VAR == 2>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
     AG_MARK(124)
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     AG_MARK(125)
@@ -479,6 +527,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
     a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K; a.stats_out = d_stats_out;
+    a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, BT);
     a.dbg = nullptr;
     if (getenv("AG_GEMM_DBG")) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
         static unsigned long long* dbuf = nullptr;
@@ -490,7 +539,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     // group width: one group (the plain N-fastest order) unless the weight matrix overflows an XCD's 4 MiB L2 while the
     // A panels are cheap to fetch again (short K): then groups of <= 2.5 MiB of weight rows (fc1 768->3072: 2 groups of 6
     // tiles, measured -1.7 %; splitting fc2's 3 tiles (K = 3072) costs +16 %: its A panels are 1.5 MB each)
-    static const int ngrp_env = getenv("AG_GEMM_NGRP") ? atoi(getenv("AG_GEMM_NGRP")) : 0;
+    const int ngrp_env = getenv("AG_GEMM_NGRP") ? atoi(getenv("AG_GEMM_NGRP")) : 0;   // read per call: the parity tests toggle it
     {
         const int tiles_n = ceil_div(N, BT);
         const double wbytes = (double)N * K * 2.0;
@@ -504,7 +553,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
         if (g > tiles_n) g = tiles_n;
         a.ngrp = g;
     }
-    static const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
+    const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
     a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
     switch (epilogue) {
         case AG_EPI_BIAS: return launch_ring<AG_EPI_BIAS>(a, s);

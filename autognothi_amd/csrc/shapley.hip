@@ -54,6 +54,25 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restr
     }
 }
 
+// the reference function as it stands (models/shapley.py:82-93): out[b,t,c] = pred[b,t,c] + ((grand[b,c] - null[c]) - sum_t pred[b,t,c]) / T
+// over ALL T rows (no CLS drop, no permute); bwd != 0 computes its adjoint: dpred = dout - sum_t dout / T.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ pred, const float* __restrict__ grand,
+                                                             const float* __restrict__ null, int T, int C, int bwd,
+                                                             float* __restrict__ out) {
+    extern __shared__ float sc[];  // [C]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const float* pb = pred + (int64_t)b * T * C;
+    for (int c = wave; c < C; c += nw) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += pb[t * C + c];
+        s = wave_sum(s);
+        if (lane == 0) sc[c] = bwd ? -s / (float)T : ((grand[(int64_t)b * C + c] - null[c]) - s) / (float)T;
+    }
+    __syncthreads();
+    float* ob = out + (int64_t)b * T * C;
+    for (int i = tid; i < T * C; i += blockDim.x) ob[i] = pb[i] + sc[i % C];
+}
+
 // diff[b,k,c] = v0[c] + sum_p bit(b,k,p+1) * phi[b,c,p] - v_s[b*K+k, c]; one wave per (b,k,c)
 __global__ __launch_bounds__(256) void loss_diff_kernel(const uint32_t* __restrict__ bits, const float* __restrict__ v0,
                                                         const float* __restrict__ vs, const float* __restrict__ phi,
@@ -192,6 +211,24 @@ extern "C" int ag_shapley_normalize_bwd(const float* d_dphi, int B, int T, int C
     AG_REQUIRE(d_dphi && d_dpred && T >= 2 && C >= 1 && C <= 4096, "ag_shapley_normalize_bwd: bad arguments");
     if (B == 0) return AG_OK;
     hipLaunchKernelGGL(normalize_bwd_kernel, dim3(B), dim3(256), (size_t)C * 4, (hipStream_t)stream, d_dphi, T, C, normalize, d_dpred);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_shapley_normalize_rows(const float* d_pred, const float* d_grand, const float* d_null, int B, int T, int C,
+                                         float* d_out, void* stream) {
+    AG_REQUIRE(d_pred && d_out && d_grand && d_null && T >= 1 && C >= 1 && C <= 4096, "ag_shapley_normalize_rows: bad arguments");
+    if (B == 0) return AG_OK;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(B), dim3(256), (size_t)C * 4, (hipStream_t)stream, d_pred, d_grand, d_null, T, C, 0, d_out);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_shapley_normalize_rows_bwd(const float* d_dout, int B, int T, int C, float* d_dpred, void* stream) {
+    AG_REQUIRE(d_dout && d_dpred && T >= 1 && C >= 1 && C <= 4096, "ag_shapley_normalize_rows_bwd: bad arguments");
+    if (B == 0) return AG_OK;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(B), dim3(256), (size_t)C * 4, (hipStream_t)stream, d_dout, (const float*)nullptr,
+                       (const float*)nullptr, T, C, 1, d_dpred);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -12,6 +12,7 @@ from .. import engine
 from ..utils.nnmodel import ObservableModuleMixin
 from .vanilla_bert import (VanillaBertClassifier, VanillaBertConfig, VanillaBertModel, VanillaBertPooler,
                            VanillaBertSurrogate, _BertExplainerHead, _BertHead)
+from .. import autograd as _ag
 from .vanilla_vit import _no_autograd
 
 _FIELDS = list(VanillaBertConfig.model_fields.keys())
@@ -45,7 +46,9 @@ class DuoVanillaBertExplainer(_BertExplainerHead, ObservableModuleMixin, _BertHe
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor],
                 surrogate_grand: Tensor, surrogate_null: Tensor) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):   # scripts/train_duo_explainer.py:180-198: both outputs carry gradients
+            phi, logits = _ag.explainer_forward(self, input_ids, attention_mask, surrogate_grand, surrogate_null)
+            return logits, phi
         dtype = engine.get_precision()
         hidden, rows, bits = self.bert.run(input_ids, attention_mask, token_type_ids, cls_only=False)
         self.om_record_features(repr_cls=hidden, repr_exp=hidden)

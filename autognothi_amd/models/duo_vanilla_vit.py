@@ -9,6 +9,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import _lib as L
+from .. import autograd as _ag
 from .. import engine, ops
 from ..utils.nnmodel import ObservableModuleMixin
 from .vanilla_vit import (VanillaViTClassifier, VanillaViTConfig, VanillaViTModel, VanillaViTSurrogate, _ExplainerHead,
@@ -51,7 +52,8 @@ class DuoVanillaViTExplainer(_ExplainerHead, ObservableModuleMixin):
 
     def forward(self, pixel_values: Tensor, attention_mask: Tensor, surrogate_grand: Tensor,
                 surrogate_null: Tensor) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):   # scripts/train_duo_explainer.py:180-198: both outputs carry gradients
+            return _ag.explainer_forward(self, pixel_values, attention_mask, surrogate_grand, surrogate_null)
         dtype = engine.get_precision()
         bits = engine.to_mask_bits(attention_mask, self.vit.n_players)
         hidden, rows = self.vit.run(pixel_values, bits, cls_only=False)

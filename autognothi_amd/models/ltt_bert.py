@@ -16,6 +16,7 @@ from typing_extensions import Self
 from .. import _lib as L
 from .. import engine, ops
 from ..utils.nnmodel import ObservableModuleMixin, freeze_model_parameters
+from .. import autograd as _ag
 from .vanilla_bert import (VanillaBertConfig, VanillaBertEmbeddings, VanillaBertLayer, VanillaBertModel, VanillaBertPooler,
                            _BertHead, _no_autograd)
 
@@ -244,7 +245,8 @@ class LttBertSurrogate(nn.Module, ObservableModuleMixin, _BertHead):
         self.bert.encoder.ltt_freeze_layers_until(layer_id)
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):   # side probabilities carry the gradient; the frozen backbone's do not
+            return _ag.surrogate_forward(self, input_ids, attention_mask)
         dtype = engine.get_precision()
         if self.om_is_observing():
             output, (srg_output,), _, rows = self.bert.run(input_ids, attention_mask, token_type_ids, [0])
@@ -319,7 +321,8 @@ class LttBertExplainer(_LttBertExplainerHead, ObservableModuleMixin, _BertHead):
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor],
                 surrogate_grand: Tensor, surrogate_null: Tensor) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):
+            return _ag.explainer_forward(self, input_ids, attention_mask, surrogate_grand, surrogate_null)
         dtype = engine.get_precision()
         output, (exp_output,), bits, rows = self.bert.run(input_ids, attention_mask, token_type_ids, [0])
         self.om_record_features(repr_cls=output, repr_exp=exp_output)

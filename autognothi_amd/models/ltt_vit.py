@@ -26,6 +26,7 @@ from typing_extensions import Self
 from .. import _lib as L
 from .. import engine, ops
 from ..utils.nnmodel import ObservableModuleMixin, freeze_model_parameters
+from .. import autograd as _ag
 from .vanilla_vit import VanillaViTConfig, VanillaViTEmbeddings, VanillaViTLayer, VanillaViTModel, _no_autograd
 
 
@@ -165,7 +166,7 @@ class LttViTModel(nn.Module):
         side: Dict[int, Optional[Tensor]] = {i_b: None for i_b in branches}
         enc = self.encoder
         # LayerNorm-fold row statistics of the stream, produced by layer i's fc2 epilogue for layer i+1's QKV (one call per layer)
-        chain = [torch.empty(rows * t * 2, dtype=torch.float32, device=hidden.device), False, True]
+        chain = [ops.new_row_stats(rows * t, self.config.hidden_size, hidden.device), False, True]
         for i_ly in range(enc.num_layers):
             share = rows // b if i_ly == 0 else 1
             chain[2] = i_ly + 1 < enc.num_layers
@@ -229,7 +230,8 @@ class LttViTSurrogate(nn.Module, ObservableModuleMixin):
         self.vit.encoder.ltt_freeze_layers_until(layer_id)
 
     def forward(self, pixel_values: Tensor, attention_mask: Tensor) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):   # side probabilities carry the gradient; the frozen backbone's do not
+            return _ag.surrogate_forward(self, pixel_values, attention_mask)
         dtype = engine.get_precision()
         output, (srg_output,), _, _ = self.vit.run(pixel_values, attention_mask, [0])
         self.om_record_features(repr_cls=output, repr_srg=srg_output)
@@ -300,7 +302,8 @@ class LttViTExplainer(_LttExplainerHead, ObservableModuleMixin):
 
     def forward(self, pixel_values: Tensor, attention_mask: Tensor, surrogate_grand: Tensor,
                 surrogate_null: Tensor) -> Tuple[Tensor, Tensor]:
-        _no_autograd(self)
+        if _ag.grad_mode(self):
+            return _ag.explainer_forward(self, pixel_values, attention_mask, surrogate_grand, surrogate_null)
         dtype = engine.get_precision()
         output, (exp_output,), bits, _ = self.vit.run(pixel_values, attention_mask, [0])
         self.om_record_features(repr_cls=output, repr_exp=exp_output)

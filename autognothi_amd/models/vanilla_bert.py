@@ -17,6 +17,7 @@ from typing_extensions import Self
 from .. import _lib as L
 from .. import engine, ops
 from ..utils.nnmodel import ObservableModuleMixin, freeze_model_parameters
+from .. import autograd as _ag
 from .vanilla_vit import _no_autograd
 
 
@@ -227,8 +228,9 @@ class VanillaBertClassifier(nn.Module, ObservableModuleMixin, _BertHead):
         return self
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor] = None) -> Tensor:
-        """reference :61-77 -> probabilities [R,C]."""
-        _no_autograd(self)
+        """reference :61-77 -> probabilities [R,C]; differentiable under grad mode (scripts/train_surrogate.py:143-147)."""
+        if _ag.grad_mode(self):
+            return _ag.surrogate_forward(self, input_ids, attention_mask)[0]
         dtype = engine.get_precision()
         observing = self.om_is_observing()
         hidden, rows, _ = self.bert.run(input_ids, attention_mask, token_type_ids, cls_only=not observing)
@@ -285,8 +287,9 @@ class VanillaBertExplainer(_BertExplainerHead, ObservableModuleMixin):
 
     def forward(self, input_ids: Tensor, attention_mask: Tensor, token_type_ids: Optional[Tensor],
                 surrogate_grand: Tensor, surrogate_null: Tensor) -> Tensor:
-        """reference :123-162 -> phi [B,C,P]."""
-        _no_autograd(self)
+        """reference :123-162 -> phi [B,C,P]; differentiable under grad mode (scripts/train_explainer.py:183-197)."""
+        if _ag.grad_mode(self):
+            return _ag.explainer_forward(self, input_ids, attention_mask, surrogate_grand, surrogate_null)[0]
         dtype = engine.get_precision()
         hidden, rows, bits = self.bert.run(input_ids, attention_mask, token_type_ids, cls_only=False)
         self.om_record_features(repr_exp=hidden)

@@ -22,6 +22,7 @@ from torch import Tensor, nn
 from typing_extensions import Self
 
 from .. import _lib as L
+from .. import autograd as _ag
 from .. import engine, ops
 from ..utils.nnmodel import ObservableModuleMixin, freeze_model_parameters
 
@@ -203,10 +204,12 @@ class VanillaViTModel(nn.Module):
 
 
 def _no_autograd(module: nn.Module) -> None:
+    """The Final modules (and the plain classifier) are never trained by the reference's pipelines: inference only.
+    Surrogates and explainers route to autognothi_amd.autograd under grad mode instead of calling this."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise RuntimeError(
-            f"{type(module).__name__}.forward: the HIP path is inference-only here; call it under torch.no_grad() "
-            "(training goes through autognothi_amd.scripts.train_* which own the backward).")
+            f"{type(module).__name__}.forward: this module has no training path on the HIP kernels; call it under "
+            "torch.no_grad() (surrogate / explainer modules are differentiable: autognothi_amd/autograd.py).")
 
 
 class VanillaViTClassifier(nn.Module, ObservableModuleMixin):
@@ -227,8 +230,10 @@ class VanillaViTClassifier(nn.Module, ObservableModuleMixin):
 
     def forward(self, x: Tensor, attention_mask: Tensor) -> Tensor:
         """reference :51-56: softmax(Linear(LN_f(h)[:,0])) -> probabilities [R, C].  Only the CLS row
-        of the last layer is consumed, so that layer's out-proj/MLP run on the CLS token only."""
-        _no_autograd(self)
+        of the last layer is consumed, so that layer's out-proj/MLP run on the CLS token only.
+        Under grad mode (reference scripts/train_surrogate.py:143-147) the result carries a grad_fn (autograd.py)."""
+        if _ag.grad_mode(self):
+            return _ag.surrogate_forward(self, x, attention_mask)[0]
         dtype = engine.get_precision()
         observing = self.om_is_observing()
         hidden, rows = self.vit.run(x, attention_mask, cls_only=not observing)
@@ -296,8 +301,9 @@ class VanillaViTExplainer(_ExplainerHead, ObservableModuleMixin):
 
     def forward(self, pixel_values: Tensor, attention_mask: Tensor, surrogate_grand: Tensor,
                 surrogate_null: Tensor) -> Tensor:
-        """reference :102-130 -> phi [B, C, P]."""
-        _no_autograd(self)
+        """reference :102-130 -> phi [B, C, P]; differentiable under grad mode (scripts/train_explainer.py:183-197)."""
+        if _ag.grad_mode(self):
+            return _ag.explainer_forward(self, pixel_values, attention_mask, surrogate_grand, surrogate_null)[0]
         dtype = engine.get_precision()
         bits = engine.to_mask_bits(attention_mask, self.vit.n_players)
         z = self.vit(pixel_values, bits)

@@ -25,6 +25,29 @@ def mask_words(n_players: int) -> int:
 
 
 # ----------------------------------------------------------------------------- RNG / samplers
+def parse_torch_cpu_state(state: Tensor):
+    """torch.get_rng_state() of the CPU generator -> (mt[624] uint32, pos).  Layout (at::mt19937_data_pod): u64 seed,
+    i32 left, i32 seeded, u64 next, u64 state[624], ...; at::mt19937 keeps ``left == 625 - next`` between twists and
+    ``left == 1`` when the next draw twists first (fresh seed: next == 0; exhausted block: next == 624).
+    pos: index of the next word to hand out, 624 = twist on the next draw."""
+    st = state.numpy()
+    left = int(st[8:12].view(np.int32)[0])
+    nxt = int(st[16:24].view(np.uint64)[0])
+    mt = np.ascontiguousarray(st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32))
+    return mt, (624 if left == 1 else nxt)
+
+
+def fill_torch_cpu_state(state: Tensor, mt: np.ndarray, pos: int) -> Tensor:
+    """Inverse of parse_torch_cpu_state on a copy of `state` (Box-Muller cache fields are left as they are)."""
+    st = state.clone()
+    a = st.numpy()
+    a[8:12].view(np.int32)[0] = 1 if pos >= 624 else 625 - pos
+    a[12:16].view(np.int32)[0] = 1
+    a[16:24].view(np.uint64)[0] = 624 if pos >= 624 else pos
+    a[24:24 + 624 * 8].view(np.uint64)[:] = np.asarray(mt, dtype=np.uint32).astype(np.uint64)
+    return st
+
+
 class DeviceMT19937:
     """MT19937 state resident in HBM; bit-compatible with torch's CPU generator
     (reference consumers: models/shapley.py:69,114,133)."""
@@ -41,13 +64,8 @@ class DeviceMT19937:
         return self
 
     def import_torch_cpu_state(self, gen: Optional[torch.Generator] = None) -> "DeviceMT19937":
-        """Continue torch's *CPU* generator stream on the device (layout of
-        torch.get_rng_state(): u64 seed, i32 left, i32 seeded, u64 next, u64 state[624], ...)."""
-        st = (gen.get_state() if gen is not None else torch.get_rng_state()).numpy()
-        left = int(st[8:12].view(np.int32)[0])
-        nxt = int(st[16:24].view(np.uint64)[0])
-        mt = np.ascontiguousarray(st[24:24 + 624 * 8].view(np.uint64).astype(np.uint32))
-        pos = 624 if left == 1 else nxt  # left==1: the next draw twists first
+        """Continue torch's *CPU* generator stream on the device."""
+        mt, pos = parse_torch_cpu_state(gen.get_state() if gen is not None else torch.get_rng_state())
         with L.on(self.device):
             L.check(L.lib().ag_mt19937_import(L.ptr(self.state), mt.ctypes.data, pos, L.stream()))
         return self
@@ -59,13 +77,7 @@ class DeviceMT19937:
         pos = C.c_int(0)
         with L.on(self.device):
             L.check(L.lib().ag_mt19937_export(L.ptr(self.state), mt.ctypes.data, C.byref(pos), L.stream()))
-        st = (gen.get_state() if gen is not None else torch.get_rng_state()).clone()
-        a = st.numpy()
-        p = pos.value
-        a[8:12].view(np.int32)[0] = 1 if p >= 624 else 624 - p
-        a[12:16].view(np.int32)[0] = 1
-        a[16:24].view(np.uint64)[0] = 0 if p >= 624 else p
-        a[24:24 + 624 * 8].view(np.uint64)[:] = mt.astype(np.uint64)
+        st = fill_torch_cpu_state(gen.get_state() if gen is not None else torch.get_rng_state(), mt, pos.value)
         (gen.set_state(st) if gen is not None else torch.set_rng_state(st))
 
     def raw(self, n: int) -> Tensor:
@@ -203,12 +215,27 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     return out
 
 
+def stat_slabs(h: int) -> int:
+    return (h + 255) // 256
+
+
+def new_row_stats(rows: int, h: int, device) -> Tensor:
+    """uninitialised row-statistics buffer [ceil(h/256), rows, 2] (include/autognothi_hip.h: AG_ROW_STATS_FLOATS)."""
+    return torch.empty((stat_slabs(h), rows, 2), dtype=torch.float32, device=device)
+
+
+def reduce_row_stats(st: Tensor, rows: int, h: int) -> Tensor:
+    """[S, rows, 2] slab partials -> [rows, 2] totals (a view helper for tests / diagnostics; the kernels add the slabs
+    themselves)."""
+    return st.view(stat_slabs(h), rows, 2).sum(dim=0)
+
+
 def row_stats(x: Tensor) -> Tensor:
-    """(sum, sum of squares) per row of a bf16 [rows, H] tensor -> fp32 [rows, 2]."""
+    """per-256-column partial (sum, sum of squares) of each row of a bf16 [rows, H] tensor -> fp32 [ceil(H/256), rows, 2]."""
     L.require_gpu(x)
     x = x.contiguous()
     rows, h = x.shape
-    st = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    st = new_row_stats(rows, h, x.device)
     with L.on(x.device):
         L.check(L.lib().ag_row_stats_bf16(L.ptr(x), h, rows, h, L.ptr(st), L.stream()))
     return st

@@ -57,9 +57,38 @@ def infer_perturbed(recipe: ModelRecipe, m_surrogate, xs: Tensor, explanation: T
     return out[0], out[1]
 
 
-def measure_faithfulness(env: Any, device: torch.device, recipe: ModelRecipe, m_surrogate, m_final,
-                         samples: Iterable[Tuple[Any, Any]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
-                         resolution: int) -> Dict[str, Any]:
+def measure_faithfulness(env: Any, device: torch.device, d_loader: Optional[Any], resolution: Optional[int]) -> Dict[str, Any]:
+    """reference measure_faithfulness(env, device, d_loader, resolution) (:41-140): load the surrogate + final checkpoints
+    of ``env.model_path``, walk ``d_loader.test(1)`` and return the report fields (as a dict: the reference's
+    MeasureFaithfulnessReport / FaithfulnessCurve are pydantic containers of the same keys).  ``env`` is duck-typed:
+    ``.config`` (``net``, ``train_*.epochs``, ``eval_faithfulness.resolution``), ``.model_path``, ``.log``; ``d_loader`` None
+    falls back to ``env.d_loader`` (scripts/resources.load_cfg_dataset)."""
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env
+    env.log("loading final model...")
+    config = env.config
+    m_recipe, m_config = get_recipe(config)
+    if not m_recipe.measurements.allow_faithfulness:
+        raise ValueError("unsupported recipe action")
+    _, m_surrogate = load_epoch_model_env(env, m_recipe, "surrogate", device=device)
+    _, m_final = load_epoch_model_env(env, m_recipe, "final", device=device)
+    m_misc = m_recipe.load_misc(env.model_path, m_config)
+    gen_input = m_recipe.gen_input(m_config, m_misc, device)
+    if d_loader is None:
+        env.log("loading dataset...")
+        d_loader = load_cfg_dataset(env, getattr(getattr(config, "eval_faithfulness", None), "dataset", None))
+    if resolution is None:
+        resolution = config.eval_faithfulness.resolution
+    env.log("[[[ running measurement... ]]]")
+    report = measure_faithfulness_loaded(env, device, m_recipe, m_surrogate, m_final, d_loader.test(1), gen_input, resolution)
+    env.log("FINAL RESULTS:\n"
+            f"  > insertion: target {report['insertion']['auc']:.6f}, non-target {report['insertion_non_ok']['auc']:.6f}\n"
+            f"  > deletion: target {report['deletion']['auc']:.6f}, non-target {report['deletion_non_ok']['auc']:.6f}")
+    return report
+
+
+def measure_faithfulness_loaded(env: Any, device: torch.device, recipe: ModelRecipe, m_surrogate, m_final,
+                                samples: Iterable[Tuple[Any, Any]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
+                                resolution: int) -> Dict[str, Any]:
     """reference measure_faithfulness (:41-140) given loaded models and a test iterator of single samples.
     Returns the report fields (insertion / deletion AUC for target and non-target classes + raw curves)."""
     env = env or Log()

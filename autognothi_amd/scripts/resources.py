@@ -85,6 +85,43 @@ def save_epoch_ckpt(path: pathlib.Path, section: str, ckpt_when: str, epochs: in
     return True
 
 
+def get_recipe(config) -> Tuple[object, object]:
+    """reference get_recipe (:55-83): experiment config -> (recipe, model config).  ``config.net.kind`` picks the recipe;
+    ``config.net.params`` may be this package's config object, the reference's pydantic model or a plain dict."""
+    from ..recipes import get_recipe as by_kind
+    recipe = by_kind(config.net.kind)
+    params = config.net.params
+    if isinstance(params, recipe.t_config):
+        return recipe, params
+    if hasattr(params, "model_dump"):
+        params = params.model_dump()
+    return recipe, recipe.t_config(**dict(params))
+
+
+def load_cfg_dataset(env, d_config=None):
+    """reference load_cfg_dataset (:86-147) builds a DatasetLoader from ``config.dataset``; dataset loading is outside this
+    build's scope (datasets/params loaders), so the loader is taken from the environment: any object with
+    ``.train(batch_size)`` / ``.test(batch_size)`` iterables of ``(_inputs, _targets)`` that ``recipe.gen_input`` accepts
+    (the reference's own ``datasets.loader.DatasetLoader`` qualifies)."""
+    loader = getattr(env, "d_loader", None)
+    if loader is None:
+        raise NotImplementedError("attach a dataset loader as env.d_loader (.train(bs) / .test(bs)); the reference's "
+                                  "datasets/loader.py is out of this build's scope")
+    return loader
+
+
+def load_epoch_model_env(env, m_recipe, section: str, device: torch.device = torch.device("cpu")) -> Tuple[int, nn.Module]:
+    """reference load_epoch_model(env, m_recipe, section, device) (:225-271)."""
+    _, m_config = get_recipe(env.config)
+    max_epochs = 0 if section == "final" else getattr(env.config, "train_" + section).epochs
+    return load_epoch_model(env.model_path, m_recipe, m_config, section, max_epochs, device)
+
+
+def save_epoch_ckpt_cfg(path: pathlib.Path, section: str, cfg, epoch: int, state_dict) -> bool:
+    """reference save_epoch_ckpt(path, id, cfg: Config_Train, epoch, state_dict) (:182-222)."""
+    return save_epoch_ckpt(path, section, cfg.ckpt_when, cfg.epochs, epoch, state_dict)
+
+
 def load_epoch_model(model_path: pathlib.Path, m_recipe, m_config, section: str, max_epochs: int,
                      device: torch.device = torch.device("cpu")) -> Tuple[int, nn.Module]:
     """reference load_epoch_model (:225-271): build ``t_{section}(config)``, load the newest checkpoint, ``.eval()``."""

@@ -100,3 +100,57 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         total += xs.shape[0]
         env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
     return reg_loss / max(total, 1)
+
+
+def train_explainer(env: Any, device: torch.device) -> None:
+    """reference train_explainer(env, device) (scripts/train_explainer.py:19-125; duo recipes: train_duo_explainer.py:20-118):
+    resume from the newest explainer checkpoint, per epoch reseed (set_iterative_seed) -> train epoch -> eval epoch ->
+    scheduler step -> metrics -> checkpoint.  ``env`` is duck-typed: ``.config`` (``net``, ``seed``, ``train_explainer``
+    with epochs / lr / batch_size / n_mask_samples / ckpt_when), ``.model_path``, ``.log``, and optionally ``.metrics``,
+    ``.flush_cfg``, ``.d_loader`` (scripts/resources.load_cfg_dataset).  The kernel_shap variant is out of scope."""
+    import math
+    import time
+
+    from ..utils.tools import set_iterative_seed
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_cfg
+    env.log("[[[ train explainer ]]]")
+    config = env.config
+    m_recipe, m_config = get_recipe(config)
+    if not m_recipe.training.support_explainer:
+        env.log("[[[ skip: explainer cannot be trained ]]]")
+        return
+    if m_recipe.training.exp_variant_kernel_shap:
+        raise NotImplementedError("the kernel_shap explainer baseline is outside this build's scope")
+    tcfg = config.train_explainer
+    d_loader = load_cfg_dataset(env, getattr(config, "dataset", None))
+    m_misc = m_recipe.load_misc(env.model_path, m_config)
+    n_players = m_recipe.n_players(m_config)
+    gen_input = m_recipe.gen_input(m_config, m_misc, device)
+    _, m_surrogate = load_epoch_model_env(env, m_recipe, "surrogate", device=device)
+    epoch_explainer, m_explainer = load_epoch_model_env(env, m_recipe, "explainer", device=device)
+    if epoch_explainer >= tcfg.epochs:
+        env.log("[[[ explainer already trained ]]]")
+        return
+    optimizer = torch.optim.AdamW(m_explainer.parameters(), lr=tcfg.lr)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, tcfg.epochs)
+    v_0 = surrogate_null(m_recipe, m_config, m_misc, m_surrogate, device)
+    for epoch in range(epoch_explainer + 1, tcfg.epochs + 1):
+        seed = set_iterative_seed(config.seed, f"train_explainer[epoch={epoch}]")
+        env.log(f"### epoch {epoch}")
+        if getattr(tcfg, "EXPERIMENTAL_progressive_training", None):      # trick for ltt (reference :69-74)
+            freeze_lys = min(math.ceil(epoch / 2), m_config.num_hidden_layers)
+            env.log(f"  > freeze side branches exc. first {freeze_lys} layers")
+            m_explainer.ltt_freeze_layers_until(freeze_lys)
+        ts_begin = time.time()
+        train_reg_loss = explainer_epoch_train(env, device, tcfg.n_mask_samples, n_players, v_0, d_loader.train(tcfg.batch_size),
+                                               m_recipe, m_surrogate, m_explainer, optimizer, epoch, gen_input, seed=seed)
+        test_reg_loss = explainer_epoch_eval(env, device, tcfg.n_mask_samples, n_players, v_0, d_loader.test(tcfg.batch_size),
+                                             m_recipe, m_surrogate, m_explainer, epoch, gen_input)
+        scheduler.step()
+        ts_delta = time.time() - ts_begin
+        if hasattr(env, "metrics"):
+            env.metrics({"epoch": epoch, "train_reg_loss": train_reg_loss, "test_reg_loss": test_reg_loss, "test_plots": []})
+        env.log(f"  > epoch {epoch} done in {ts_delta:.2f}s // train_loss: shap {train_reg_loss:.6f} // "
+                f"test_loss: shap {test_reg_loss:.6f}")
+        if save_epoch_ckpt_cfg(env.model_path, "explainer", tcfg, epoch, m_explainer) and hasattr(env, "flush_cfg"):
+            env.flush_cfg()

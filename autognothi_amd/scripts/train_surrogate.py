@@ -73,3 +73,50 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
         n += b
         env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: kl {tot / n:.6f}")
     return tot / max(n, 1)
+
+
+def train_surrogate(env: Any, device: torch.device) -> None:
+    """reference train_surrogate(env, device) (scripts/train_surrogate.py:16-109): resume, per epoch reseed -> train epoch ->
+    eval epoch -> scheduler step -> metrics -> checkpoint.  ``env`` duck-typed as in scripts/train_explainer.train_explainer."""
+    import math
+    import time
+
+    from ..utils.tools import set_iterative_seed
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_cfg
+    env.log("[[[ train surrogate ]]]")
+    config = env.config
+    m_recipe, m_config = get_recipe(config)
+    if not m_recipe.training.support_surrogate:
+        env.log("[[[ skip: surrogate cannot be trained ]]]")
+        return
+    tcfg = config.train_surrogate
+    d_loader = load_cfg_dataset(env, getattr(config, "dataset", None))
+    m_misc = m_recipe.load_misc(env.model_path, m_config)
+    n_players = m_recipe.n_players(m_config)
+    gen_input = m_recipe.gen_input(m_config, m_misc, device)
+    _, m_classifier = load_epoch_model_env(env, m_recipe, "classifier", device=device)
+    epoch_surrogate, m_surrogate = load_epoch_model_env(env, m_recipe, "surrogate", device=device)
+    if epoch_surrogate >= tcfg.epochs:
+        env.log("[[[ surrogate already trained ]]]")
+        return
+    optimizer = torch.optim.AdamW(m_surrogate.parameters(), lr=tcfg.lr)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, tcfg.epochs)
+    for epoch in range(epoch_surrogate + 1, tcfg.epochs + 1):
+        seed = set_iterative_seed(config.seed, f"train_surrogate[epoch={epoch}]")
+        env.log(f"### epoch {epoch}")
+        if getattr(tcfg, "EXPERIMENTAL_progressive_training", None):      # trick for ltt (reference :57-62)
+            freeze_lys = min(math.ceil(epoch / 3), m_config.num_hidden_layers)
+            env.log(f"  > freeze side branches exc. first {freeze_lys} layers")
+            m_surrogate.ltt_freeze_layers_until(freeze_lys)
+        ts_begin = time.time()
+        train_kld = surrogate_epoch_train(env, device, n_players, d_loader.train(tcfg.batch_size), m_recipe, m_classifier,
+                                          m_surrogate, optimizer, epoch, gen_input, seed=seed)
+        test_kld = surrogate_epoch_eval(env, device, n_players, d_loader.test(tcfg.batch_size), m_recipe, m_classifier,
+                                        m_surrogate, epoch, gen_input)
+        scheduler.step()
+        ts_delta = time.time() - ts_begin
+        if hasattr(env, "metrics"):
+            env.metrics({"epoch": epoch, "train_kld_loss": train_kld, "test_kld_loss": test_kld})
+        env.log(f"  > epoch {epoch} done in {ts_delta:.2f}s // train_loss: kld {train_kld:.6f} // test_loss: kld {test_kld:.6f}")
+        if save_epoch_ckpt_cfg(env.model_path, "surrogate", tcfg, epoch, m_surrogate) and hasattr(env, "flush_cfg"):
+            env.flush_cfg()

@@ -265,6 +265,22 @@ def _any_trainable(mod: nn.Module) -> bool:
     return any(p.requires_grad for p in mod.parameters())
 
 
+def _module_n_players(m: nn.Module) -> int:
+    """recipe.n_players(cfg) read off the module: ViT = patches (recipes/vanilla_vit.py n_players), BERT =
+    max_position_embeddings - 1 (recipes/vanilla_bert.py)."""
+    cfg = m.config
+    if hasattr(cfg, "img_px_size"):
+        return (cfg.img_px_size // cfg.img_patch_size) ** 2
+    return cfg.max_position_embeddings - 1
+
+
+def _drop_block_saved(blk: "Block") -> None:
+    blk.saved = None
+    for lin in (blk.qkv, blk.o, blk.fc1, blk.fc2):
+        lin.x = None
+    blk.n1.x = blk.n2.x = None
+
+
 class ViTBackboneTrainer:
     """VanillaViTModel (embeddings + encoder + final LN), reference models/vanilla_vit.py:207-214."""
 
@@ -304,6 +320,13 @@ class ViTBackboneTrainer:
                 tap(i, hid)
         self.saved = (b, p, h, ph, s_emb)
         return self.ln_f.forward(hid)
+
+    def drop_saved(self) -> None:
+        """forget the activations of a forward whose backward will not run (frozen backbone)."""
+        for blk in self.blocks:
+            _drop_block_saved(blk)
+        self.ln_f.x = self.proj.x = None
+        self.saved = None
 
     def backward(self, dz: Tensor) -> None:
         b, p, h, ph, s_emb = self.saved
@@ -352,6 +375,12 @@ class BertBackboneTrainer:
         self.saved = (ids, b, t, h, ph, s_emb)
         return hid
 
+    def drop_saved(self) -> None:
+        for blk in self.blocks:
+            _drop_block_saved(blk)
+        self.ln_e.x = None
+        self.saved = None
+
     def backward(self, dh: Tensor) -> None:
         ids, b, t, h, ph, s_emb = self.saved
         d = dh
@@ -366,8 +395,14 @@ class BertBackboneTrainer:
             g = _grad(e.token_type_embeddings.weight)
             _acc(g[0], ops.colsum(d))
         if e.word_embeddings.weight.requires_grad:
-            # scatter-add of B*T rows into the vocabulary table: index plumbing (torch), no arithmetic beyond the adds
-            _grad(e.word_embeddings.weight).index_add_(0, ids.view(-1), d)
+            # scatter-add of B*T rows into the vocabulary table: index plumbing (torch), no arithmetic beyond the adds.
+            # nn.Embedding(padding_idx=pad_token_id) (reference models/vanilla_bert.py:288-290): autograd never gives the
+            # [PAD] row a gradient, although [PAD] positions are ordinary players in the forward.
+            pad = e.word_embeddings.padding_idx
+            flat = ids.view(-1)
+            if pad is not None:
+                d = d.masked_fill((flat == pad).unsqueeze(1), 0.0)
+            _grad(e.word_embeddings.weight).index_add_(0, flat, d)
         self.saved = None
 
 
@@ -418,10 +453,13 @@ class ExplainerTrainer:
     """fw_explainer + loss_shapley_new with gradients (vanilla / froyo / duo; ViT or BERT)."""
 
     def __init__(self, recipe, m_explainer: nn.Module):
+        """``recipe`` may be None (the autograd bridge builds trainers from the module alone)."""
         self.recipe, self.m = recipe, m_explainer
         cfg = m_explainer.config
         self.is_vit = hasattr(m_explainer, "vit")
-        self.duo = bool(recipe.training.exp_variant_duo)
+        self.duo = bool(recipe.training.exp_variant_duo) if recipe is not None else hasattr(m_explainer, "classifier")
+        self.n_players = _module_n_players(m_explainer)
+        self.saved = None
         self.kind = L.AG_MASK_VIT_MUL if self.is_vit else L.AG_MASK_BERT_ADD
         self.backbone = ViTBackboneTrainer(m_explainer.vit) if self.is_vit else BertBackboneTrainer(m_explainer.bert)
         self.backbone_frozen = not _any_trainable(m_explainer.vit if self.is_vit else m_explainer.bert)
@@ -432,49 +470,63 @@ class ExplainerTrainer:
         self.pool = Lin([m_explainer.bert_pooler.dense]) if (self.duo and not self.is_vit) else None
         self.step = 0
 
-    @_fp32_step
-    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
-                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
-        """One reference training-step body (scripts/train_explainer.py:182-196 / train_duo_explainer.py:180-196):
-        explainer forward (all-ones mask), loss, backward into param.grad.  -> (loss tensor [1], phi)."""
+    def forward_phi(self, xs: Tensor, v_0: Optional[Tensor], v_1: Optional[Tensor], train: bool = True, seed: int = 0,
+                    bits: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        """fw_explainer with activations saved for ``backward_phi`` -> (phi [B,C,P], base_Ys or None).  ``base_Ys`` is what the
+        duo recipes return second: soft-maxed head output for ViT (models/duo_vanilla_vit.py:121-122), raw logits for BERT
+        (models/duo_vanilla_bert.py:142-144).  ``bits``: key bits of the attention mask (all ones in every reference caller)."""
         cfg = self.m.config
         self.step += 1
         seeds = Seeds(seed * 7919 + self.step)
         b = xs.shape[0]
-        p = self.recipe.n_players(cfg)
+        p = self.n_players
         t, h, c = p + 1, cfg.hidden_size, cfg.num_labels
-        ones_bits = engine.ones_mask_bits(b, p, xs.device)
-        z = self.backbone.forward(xs, ones_bits, seeds, train)          # [B*T, H] (ViT: after the final LN)
+        if bits is None:
+            bits = engine.ones_mask_bits(b, p, xs.device)
+        z = self.backbone.forward(xs, bits, seeds, train)          # [B*T, H] (ViT: after the final LN)
         o = z
         for blk in self.attn:
-            o = blk.forward(o, ones_bits, b, t, seeds, train)
+            o = blk.forward(o, bits, b, t, seeds, train)
         s_exp = seeds.next()
         ph = cfg.hidden_dropout_prob if (train and not self.is_vit) else 0.0   # BERT explainer_dropout (:152)
         o = ops.dropout(o, ph, s_exp)
         pred = self.mlp.forward(o).view(b, t, c)
         phi = ops.shapley_normalize(pred, v_1, v_0, normalize=bool(cfg.explainer_normalize))
-        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
-        total = loss
-        dz_extra = None
+        base, duo_saved = None, None
         if self.duo:
             zc = z.view(b, t, h)[:, 0, :].contiguous()
             if self.is_vit:
-                logits = self.cls.forward(zc, L.AG_EPI_BIAS_F32)
-                probs = ops.softmax_rows(logits)                          # duo-ViT: CE on probabilities (:121-122, A.5)
-                ce, dprobs = _cross_entropy(probs, labels)
-                dz_cls = self.cls.backward(ops.softmax_rows_bwd(probs, dprobs))
+                base = ops.softmax_rows(self.cls.forward(zc, L.AG_EPI_BIAS_F32))
+                duo_saved = (base,)
             else:
                 pooled = self.pool.forward(zc, L.AG_EPI_BIAS_TANH)
                 s_pool = seeds.next()
-                pooled_d = ops.dropout(pooled, cfg.hidden_dropout_prob if train else 0.0, s_pool)
-                logits = self.cls.forward(pooled_d, L.AG_EPI_BIAS_F32)   # duo-BERT: raw logits (:142-144)
-                ce, dlogits = _cross_entropy(logits, labels)
-                dp = ops.dropout(self.cls.backward(dlogits), cfg.hidden_dropout_prob if train else 0.0, s_pool)
+                pd = cfg.hidden_dropout_prob if train else 0.0
+                base = self.cls.forward(ops.dropout(pooled, pd, s_pool), L.AG_EPI_BIAS_F32)
+                duo_saved = (pooled, pd, s_pool)
+        self.saved = (b, t, h, c, ph, s_exp, duo_saved)
+        return phi, base
+
+    def backward_phi(self, dphi: Tensor, dbase: Optional[Tensor] = None) -> None:
+        """Backward of ``forward_phi`` into param.grad: dphi = d loss / d phi [B,C,P]; dbase = d loss / d base_Ys (duo)."""
+        cfg = self.m.config
+        b, t, h, c, ph, s_exp, duo_saved = self.saved
+        self.saved = None
+        dz_extra = None
+        if self.duo and dbase is not None:
+            if self.is_vit:
+                (probs,) = duo_saved
+                dz_cls = self.cls.backward(ops.softmax_rows_bwd(probs, dbase.contiguous().float()))
+            else:
+                pooled, pd, s_pool = duo_saved
+                dp = ops.dropout(self.cls.backward(dbase.contiguous().float()), pd, s_pool)
                 dz_cls = self.pool.backward(ops.tanh_bwd(pooled, dp))
-            total = loss + ce
-            dz_extra = torch.zeros((b, t, h), dtype=torch.float32, device=xs.device)
+            dz_extra = torch.zeros((b, t, h), dtype=torch.float32, device=dphi.device)
             dz_extra[:, 0, :].copy_(dz_cls)
-        # ---- backward ----
+        elif self.duo:
+            self.cls.x = None
+            if self.pool is not None:
+                self.pool.x = None
         dpred = ops.shapley_normalize_bwd(dphi, t, normalize=bool(cfg.explainer_normalize)).view(b * t, c)
         d = ops.dropout(self.mlp.backward(dpred), ph, s_exp)
         for blk in reversed(self.attn):
@@ -483,6 +535,22 @@ class ExplainerTrainer:
             d = ops.add(d, dz_extra.view(b * t, h))
         if not self.backbone_frozen:
             self.backbone.backward(d)
+        else:
+            self.backbone.drop_saved()
+
+    @_fp32_step
+    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
+                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+        """One reference training-step body (scripts/train_explainer.py:182-196 / train_duo_explainer.py:180-196):
+        explainer forward (all-ones mask), loss, backward into param.grad.  -> (loss tensor [1], phi)."""
+        b = xs.shape[0]
+        phi, base = self.forward_phi(xs, v_0, v_1, train, seed)
+        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
+        total, dbase = loss, None
+        if self.duo:
+            ce, dbase = _cross_entropy(base, labels)     # duo-ViT: CE on probabilities, duo-BERT: on raw logits (A.5)
+            total = loss + ce
+        self.backward_phi(dphi, dbase)
         return total, phi
 
 
@@ -492,21 +560,23 @@ class SurrogateTrainer:
     def __init__(self, recipe, m_surrogate: nn.Module):
         self.recipe, self.m = recipe, m_surrogate
         self.is_vit = hasattr(m_surrogate, "vit")
+        self.n_players = _module_n_players(m_surrogate)
+        self.saved = None
         self.backbone = ViTBackboneTrainer(m_surrogate.vit) if self.is_vit else BertBackboneTrainer(m_surrogate.bert)
         self.cls = Lin([m_surrogate.classifier])
         self.pool = None if self.is_vit else Lin([m_surrogate.bert_pooler.dense])
         self.step = 0
 
-    @_fp32_step
-    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+    def forward_probs(self, xs: Tensor, bits: Tensor, train: bool = True, seed: int = 0) -> Tensor:
+        """fw_surrogate (probabilities [B,C]) with activations saved for ``backward_probs``."""
         cfg = self.m.config
         self.step += 1
         seeds = Seeds(seed * 104729 + self.step)
         b = xs.shape[0]
-        p = self.recipe.n_players(cfg)
-        t, h = p + 1, cfg.hidden_size
+        t, h = self.n_players + 1, cfg.hidden_size
         z = self.backbone.forward(xs, bits, seeds, train)
         zc = z.view(b, t, h)[:, 0, :].contiguous()
+        pooled, ph, s_pool = None, 0.0, 0
         if self.is_vit:
             logits = self.cls.forward(zc, L.AG_EPI_BIAS_F32)
         else:
@@ -515,16 +585,27 @@ class SurrogateTrainer:
             ph = cfg.hidden_dropout_prob if train else 0.0
             logits = self.cls.forward(ops.dropout(pooled, ph, s_pool), L.AG_EPI_BIAS_F32)
         probs = ops.softmax_rows(logits)
-        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
-        dlogits = ops.softmax_rows_bwd(probs, dprobs)
+        self.saved = (b, t, h, probs, pooled, ph, s_pool)
+        return probs
+
+    def backward_probs(self, dprobs: Tensor) -> None:
+        b, t, h, probs, pooled, ph, s_pool = self.saved
+        self.saved = None
+        dlogits = ops.softmax_rows_bwd(probs, dprobs.contiguous().float())
         if self.is_vit:
             dzc = self.cls.backward(dlogits)
         else:
             dp = ops.dropout(self.cls.backward(dlogits), ph, s_pool)
             dzc = self.pool.backward(ops.tanh_bwd(pooled, dp))
-        dz = torch.zeros((b, t, h), dtype=torch.float32, device=xs.device)
+        dz = torch.zeros((b, t, h), dtype=torch.float32, device=dprobs.device)
         dz[:, 0, :].copy_(dzc)
         self.backbone.backward(dz.view(b * t, h))
+
+    @_fp32_step
+    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+        probs = self.forward_probs(xs, bits, train, seed)
+        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
+        self.backward_probs(dprobs)
         return loss, probs
 
 
@@ -568,6 +649,7 @@ class LadderTrainer:
             self.pre.append(pre)
 
         z = self.backbone.forward(x, bits, seeds, train, tap=tap)
+        self.z_last = z                  # the frozen backbone's output (the recipes' second, non-differentiable result)
         side = state["side"]
         if self.ln_s is not None:
             side = self.ln_s.forward(side)
@@ -579,13 +661,7 @@ class LadderTrainer:
             d = self.side[i].backward(d)                       # grad of (side_{i-1} + gelu(pre_i))
             self.maps[i].backward(ops.gelu_bwd(self.pre[i], d), need_dx=False)   # the backbone is frozen: no dX
         self.pre = []
-        # drop what the frozen backbone saved
-        for blk in self.backbone.blocks:
-            blk.saved = None
-            for lin in (blk.qkv, blk.o, blk.fc1, blk.fc2):
-                lin.x = None
-            blk.n1.x = blk.n2.x = None
-        self.backbone.saved = None
+        self.backbone.drop_saved()       # what the frozen backbone saved
 
 
 class LttSurrogateTrainer:
@@ -595,21 +671,22 @@ class LttSurrogateTrainer:
     def __init__(self, recipe, m_surrogate: nn.Module):
         self.recipe, self.m = recipe, m_surrogate
         self.is_vit = hasattr(m_surrogate, "vit")
+        self.n_players = _module_n_players(m_surrogate)
+        self.saved = None
         self.ladder = LadderTrainer(m_surrogate.vit if self.is_vit else m_surrogate.bert, self.is_vit, 0)
         self.cls = Lin([m_surrogate.s_attn_classifier])
         self.pool = None if self.is_vit else Lin([m_surrogate.bert_s_attn_pooler.dense])
         self.step = 0
 
-    @_fp32_step
-    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+    def forward_probs(self, xs: Tensor, bits: Tensor, train: bool = True, seed: int = 0) -> Tensor:
         cfg = self.m.config
         self.step += 1
         seeds = Seeds(seed * 104729 + self.step)
         b = xs.shape[0]
-        t, hs = self.recipe.n_players(cfg) + 1, cfg.s_attn_hidden_size
+        t, hs = self.n_players + 1, cfg.s_attn_hidden_size
         _, side = self.ladder.forward(xs, bits, seeds, train)
         sc = side.view(b, t, hs)[:, 0, :].contiguous()
-        ph = 0.0
+        pooled, ph, s_pool = None, 0.0, 0
         if self.is_vit:
             logits = self.cls.forward(sc, L.AG_EPI_BIAS_F32)
         else:
@@ -618,16 +695,27 @@ class LttSurrogateTrainer:
             ph = cfg.hidden_dropout_prob if train else 0.0
             logits = self.cls.forward(ops.dropout(pooled, ph, s_pool), L.AG_EPI_BIAS_F32)
         probs = ops.softmax_rows(logits)
-        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
-        dlogits = ops.softmax_rows_bwd(probs, dprobs)
+        self.saved = (b, t, hs, probs, pooled, ph, s_pool)
+        return probs
+
+    def backward_probs(self, dprobs: Tensor) -> None:
+        b, t, hs, probs, pooled, ph, s_pool = self.saved
+        self.saved = None
+        dlogits = ops.softmax_rows_bwd(probs, dprobs.contiguous().float())
         if self.is_vit:
             dsc = self.cls.backward(dlogits)
         else:
             dp = ops.dropout(self.cls.backward(dlogits), ph, s_pool)
             dsc = self.pool.backward(ops.tanh_bwd(pooled, dp))
-        dside = torch.zeros((b, t, hs), dtype=torch.float32, device=xs.device)
+        dside = torch.zeros((b, t, hs), dtype=torch.float32, device=dprobs.device)
         dside[:, 0, :].copy_(dsc)
         self.ladder.backward(dside.view(b * t, hs))
+
+    @_fp32_step
+    def loss_and_grads(self, xs: Tensor, bits: Tensor, orig_probs: Tensor, train: bool = True, seed: int = 0):
+        probs = self.forward_probs(xs, bits, train, seed)
+        loss, dprobs = ops.kl_loss(orig_probs, probs, want_grad=True)
+        self.backward_probs(dprobs)
         return loss, probs
 
 
@@ -639,6 +727,8 @@ class LttExplainerTrainer:
         self.recipe, self.m = recipe, m_explainer
         cfg = m_explainer.config
         self.is_vit = hasattr(m_explainer, "vit")
+        self.n_players = _module_n_players(m_explainer)
+        self.saved = None
         self.kind = L.AG_MASK_VIT_MUL if self.is_vit else L.AG_MASK_BERT_ADD
         self.ladder = LadderTrainer(m_explainer.vit if self.is_vit else m_explainer.bert, self.is_vit, 0)
         layers = m_explainer.s_explainer_attn if self.is_vit else m_explainer.s_attn_attention_layers
@@ -647,36 +737,53 @@ class LttExplainerTrainer:
         self.mlp = MLPHead(m_explainer.s_explainer_mlp if self.is_vit else m_explainer.s_attn_explainer)
         self.step = 0
 
-    @_fp32_step
-    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
-                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+    def forward_phi(self, xs: Tensor, v_0: Optional[Tensor], v_1: Optional[Tensor], train: bool = True, seed: int = 0,
+                    bits: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         cfg = self.m.config
         self.step += 1
         seeds = Seeds(seed * 7919 + self.step)
         b = xs.shape[0]
-        p = self.recipe.n_players(cfg)
+        p = self.n_players
         t, c = p + 1, cfg.num_labels
-        ones_bits = engine.ones_mask_bits(b, p, xs.device)
-        _, o = self.ladder.forward(xs, ones_bits, seeds, train)
+        if bits is None:
+            bits = engine.ones_mask_bits(b, p, xs.device)
+        _, o = self.ladder.forward(xs, bits, seeds, train)
         for blk in self.attn:
-            o = blk.forward(o, ones_bits, b, t, seeds, train)
+            o = blk.forward(o, bits, b, t, seeds, train)
         s_exp = seeds.next()
         ph = cfg.hidden_dropout_prob if (train and not self.is_vit) else 0.0   # BERT s_attn_exp_dropout (ltt_bert.py:205)
         o = ops.dropout(o, ph, s_exp)
         pred = self.mlp.forward(o).view(b, t, c)
         phi = ops.shapley_normalize(pred, v_1, v_0, normalize=bool(cfg.explainer_normalize))
-        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
+        self.saved = (b, t, c, ph, s_exp)
+        return phi, None
+
+    def backward_phi(self, dphi: Tensor, dbase: Optional[Tensor] = None) -> None:
+        cfg = self.m.config
+        b, t, c, ph, s_exp = self.saved
+        self.saved = None
         dpred = ops.shapley_normalize_bwd(dphi, t, normalize=bool(cfg.explainer_normalize)).view(b * t, c)
         d = ops.dropout(self.mlp.backward(dpred), ph, s_exp)
         for blk in reversed(self.attn):
             d = blk.backward(d)
         self.ladder.backward(d)
+
+    @_fp32_step
+    def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
+                       labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+        phi, _ = self.forward_phi(xs, v_0, v_1, train, seed)
+        loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, xs.shape[0], n_mask_samples, want_grad=True)
+        self.backward_phi(dphi)
         return loss, phi
 
 
+def _is_ltt(recipe, module: nn.Module) -> bool:
+    return recipe.id.startswith("ltt_") if recipe is not None else type(module).__name__.startswith("Ltt")
+
+
 def make_explainer_trainer(recipe, m_explainer: nn.Module):
-    return LttExplainerTrainer(recipe, m_explainer) if recipe.id.startswith("ltt_") else ExplainerTrainer(recipe, m_explainer)
+    return LttExplainerTrainer(recipe, m_explainer) if _is_ltt(recipe, m_explainer) else ExplainerTrainer(recipe, m_explainer)
 
 
 def make_surrogate_trainer(recipe, m_surrogate: nn.Module):
-    return LttSurrogateTrainer(recipe, m_surrogate) if recipe.id.startswith("ltt_") else SurrogateTrainer(recipe, m_surrogate)
+    return LttSurrogateTrainer(recipe, m_surrogate) if _is_ltt(recipe, m_surrogate) else SurrogateTrainer(recipe, m_surrogate)

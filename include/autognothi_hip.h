@@ -79,8 +79,10 @@ int ag_mask_purely_uniform(void* d_state, int batch, int n_players, int64_t* d_m
 int ag_pack_mask(const int64_t* d_mask_i64, int rows, int n_players, uint32_t* d_mask_bits, void* stream);
 /* scripts/measure_faithfulness.py:225-251 _get_perturbed_samples for `n_attr` attribution vectors
  * at once: d_attr [n_attr, P] fp32; stops = linspace(0,P,steps) as int64; mask i flips the `stops[i]`
- * highest-attribution players of an all-`mask_base` row.  Ties rank the higher index first (stable
- * ascending argsort reversed).  d_stops [steps] int64, d_mask_i64 [n_attr, steps, P]. */
+ * highest-attribution players of an all-`mask_base` row.  Ties: the reference ranks with np.argsort's default kind, which
+ * is not stable — its order inside a group of equal attributions depends on the host's numpy build (fixture
+ * tests/golden/perturbed_ties.npz) — so the result is only defined up to the choice inside a tie group; here the higher
+ * index ranks first (= stable ascending argsort, reversed).  d_stops [steps] int64, d_mask_i64 [n_attr, steps, P]. */
 int ag_perturbed_masks(const float* d_attr, int n_attr, int n_players, int steps, int mask_base,
                        int64_t* d_stops, int64_t* d_mask_i64, void* stream);
 
@@ -104,17 +106,21 @@ int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, con
  * the K masked copies of one input share the layer-0 residual).  K % 64 == 0 (bf16) / K % 32 == 0
  * (fp32) required; N, M arbitrary.
  * LayerNorm folding (optional; only where ag_gemm_supports_ln_fold() says so — the large-M bf16 kernel):
- *   d_ln_stats [M,2] = (sum, sum of squares) over the K features of each A row, d_ln_colsum [N] =
- *   sum_k W[n,k]: the result becomes rstd[m]*(A·Wᵀ - mean[m]*colsum[n]) + bias[n], i.e. Linear(LayerNorm(A))
- *   when W is pre-scaled by gamma and bias carries beta·Wᵀ (reference models/vanilla_vit.py:369,373 feed
- *   LayerNorm outputs straight into Linear layers).  d_stats_out [M,2] (pre-zeroed) receives the same
- *   statistics of the rows this call writes (float atomics), for the next folded consumer. */
+ *   row statistics are slab-major partial sums: stats[s][m] = (sum, sum of squares) of features [256 s, 256 s + 256)
+ *   of row m, S = ceil(H / 256) slabs of 2·M floats (AG_ROW_STATS_FLOATS).  d_ln_stats [ceil(K/256), M, 2] describe
+ *   the A rows, d_ln_colsum [N] = sum_k W[n,k]: the result becomes rstd[m]*(A·Wᵀ - mean[m]*colsum[n]) + bias[n],
+ *   i.e. Linear(LayerNorm(A)) when W is pre-scaled by gamma and bias carries beta·Wᵀ (reference
+ *   models/vanilla_vit.py:369,373 feed LayerNorm outputs straight into Linear layers).  d_stats_out
+ *   [ceil(N/256), M, 2] receives the statistics of the (bf16-rounded) rows this call writes, for the next folded
+ *   consumer: each element is written once by the tile that owns it (no zero fill needed, no atomics) and the consumer
+ *   adds the slabs in a fixed order, so results are bit-reproducible from run to run. */
+#define AG_ROW_STATS_FLOATS(M, H) ((size_t)(((H) + 255) / 256) * (size_t)(M) * 2)
 int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
             const void* d_R, int64_t ldr, int rows_per_seq, int resid_share,
             int M, int N, int K, int epilogue, int dtype,
             const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, void* stream);
 int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype);
-/* (sum, sum of squares) of each row of a bf16 [rows,H] tensor -> d_stats [rows,2]. */
+/* row statistics (layout above) of a bf16 [rows,H] tensor -> d_stats [ceil(H/256), rows, 2]. */
 int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream);
 
 /* Fused masked multi-head attention (reference models/vanilla_vit.py:436-465,
@@ -154,6 +160,12 @@ int ag_shapley_normalize(const float* d_pred, const float* d_grand, const float*
                          int normalize, float* d_phi, void* stream);
 /* its backward: dpred[b,t,c] = (t>0 ? dphi[b,c,t-1] : 0) - (normalize ? sum_p dphi[b,c,p] / T : 0). */
 int ag_shapley_normalize_bwd(const float* d_dphi, int B, int T, int C, int normalize, float* d_dpred, void* stream);
+/* reference models/shapley.py:82-93 normalize_shapley_explanation exactly as declared there (the drop-in for direct callers
+ * of that function): pred [B,T,C] -> out [B,T,C] = pred + ((grand - null) - sum_t pred) / T over all T rows; and its adjoint
+ * dpred = dout - sum_t dout / T. */
+int ag_shapley_normalize_rows(const float* d_pred, const float* d_grand, const float* d_null, int B, int T, int C,
+                              float* d_out, void* stream);
+int ag_shapley_normalize_rows_bwd(const float* d_dout, int B, int T, int C, float* d_dpred, void* stream);
 /* reference models/shapley.py:9-53 loss_shapley_new: mask bits [B*K, ceil((P+1)/32)] (CLS bit
  * ignored), v0 [1,C], v_s [B*K,C], phi [B,C,P] -> loss (1 float, device) and optional dphi [B,C,P]
  * (d loss / d phi).  d_scratch: >= B*K*C floats. */
@@ -214,7 +226,7 @@ int ag_encoder_forward(const ag_encoder_desc* desc, const void* d_h0, int R, int
                        const uint32_t* d_mask_bits, void* d_h, int cls_only_last,
                        void* d_workspace, size_t workspace_bytes, void* stream);
 /* The same forward for callers that run the layers one call at a time (the LTT ladder taps the stream after every backbone
- * layer, reference models/ltt_vit.py:423-436): d_row_stats [R*T, 2] floats, caller-owned, carries the LayerNorm-fold row
+ * layer, reference models/ltt_vit.py:423-436): d_row_stats [AG_ROW_STATS_FLOATS(R*T, H)] floats, caller-owned, carries the LayerNorm-fold row
  * statistics from one call to the next.  stats_in_ready: they describe d_h0 (written by the previous call with
  * want_stats_out that reported *stats_written = 1, same R, share == 1); want_stats_out: the last layer's fc2 accumulates the
  * statistics of d_h into them when the shapes fold (ViT, bf16, large GEMMs) and *stats_written (host int) says whether it

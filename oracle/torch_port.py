@@ -70,7 +70,9 @@ def vit_backbone(x, mask_t, sd: SD, cfg: dict):
 def bert_backbone(ids, mask_t, sd: SD, cfg: dict):
     t = ids.shape[1]
     pr = "bert.embeddings"
-    e = sd[pr + ".word_embeddings.weight"][ids] + sd[pr + ".token_type_embeddings.weight"][0]
+    # padding_idx: the reference's nn.Embedding(vocab, H, padding_idx=pad_token_id) (models/vanilla_bert.py:288-290) — same
+    # forward, but the [PAD] row never receives a gradient
+    e = F.embedding(ids, sd[pr + ".word_embeddings.weight"], padding_idx=cfg.get("pad_token_id")) + sd[pr + ".token_type_embeddings.weight"][0]
     e = e + sd[pr + ".position_embeddings.weight"][:t][None]
     h = _ln(e, sd, pr + ".LayerNorm", cfg["layer_norm_eps"])
     for i in range(cfg["num_hidden_layers"]):
@@ -133,7 +135,9 @@ def bert_surrogate(ids, mask_p, sd: SD, cfg: dict):
     mask_t = _prepend_cls(mask_p)
     t = ids.shape[1]
     pr = "bert.embeddings"
-    e = sd[pr + ".word_embeddings.weight"][ids] + sd[pr + ".token_type_embeddings.weight"][0]
+    # padding_idx: the reference's nn.Embedding(vocab, H, padding_idx=pad_token_id) (models/vanilla_bert.py:288-290) — same
+    # forward, but the [PAD] row never receives a gradient
+    e = F.embedding(ids, sd[pr + ".word_embeddings.weight"], padding_idx=cfg.get("pad_token_id")) + sd[pr + ".token_type_embeddings.weight"][0]
     e = e + sd[pr + ".position_embeddings.weight"][:t][None]
     nh, eps = cfg["num_attention_heads"], cfg["layer_norm_eps"]
     h = _ln(e, sd, pr + ".LayerNorm", eps)

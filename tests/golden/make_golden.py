@@ -348,6 +348,130 @@ def gen_ltt_state_keys():
     print("wrote state_keys_ltt.json")
 
 
+def gen_full_depth():
+    """Full-depth fixtures: the shipped configs at their real depth and K, one input each, so the
+    benchmarked kernels (ring GEMM at M >= 1024, LayerNorm fold, full 12/24-layer drift) meet the reference's numbers:
+    ViT-base 12 layers K=32 (BASELINE config 2), BERT-base 12 layers L=128 K=32 (config 3), ViT-large 24 layers K=64
+    (config 4), and config 5's two recipes (duo BERT-base, froyo ViT-base) at K=32."""
+    base = hparams("vit_base_imagenette_vanilla")
+    gen_model_fixture("vit_base_l12", r_vvit.vanilla_vit_recipe, base, "vit", B=1, K=32, mask_seed=3407)
+    bert = dict(hparams("bert_base_tayp_vanilla"), max_position_embeddings=128)
+    gen_model_fixture("bert_base_l12", r_vbert.vanilla_bert_recipe, bert, "bert", B=1, K=32, mask_seed=3407)
+    large = hparams("vit_large_imagenette_vanilla")
+    gen_model_fixture("vit_large_l24", r_vvit.vanilla_vit_recipe, large, "vit", B=1, K=64, mask_seed=3407)
+    dbert = dict(hparams("bert_base_tayp_duo_vanilla"), max_position_embeddings=128)
+    gen_model_fixture("duo_bert_base_l12", r_dbert.duo_vanilla_bert_recipe, dbert, "bert", B=1, K=32, mask_seed=3407, duo=True)
+    fvit = hparams("vit_base_imagenette_vanilla")   # FroyoViTConfig has the vanilla fields (no shipped froyo ViT experiment)
+    gen_model_fixture("froyo_vit_base_l12", r_fvit.froyo_vit_recipe, fvit, "vit", B=1, K=32, mask_seed=3407, froyo=True)
+
+
+def gen_perturbed_ties():
+    """_get_perturbed_samples on attributions WITH ties (SURVEY §8c fixture 4).  The reference ranks with np.argsort's
+    default kind, which is not stable: the order inside a tie group is whatever this host's numpy build does (AVX-512
+    sorting networks here), so the recorded masks pin the reference's behaviour on THIS machine only; the fixture also
+    records the stable order so that a test can show the two differ."""
+    _stub_modules()
+    from reference.scripts.measure_faithfulness import _get_perturbed_samples
+    g = np.random.default_rng(78)
+    arrs = {}
+    cases = []
+    for i, (P, steps) in enumerate([(196, 16), (196, 196), (127, 32)]):
+        attr = (np.round(g.standard_normal(P) * 2) / 2).astype(np.float32)      # ~12 distinct values: large tie groups
+        if i == 1:
+            attr[:] = 0.25                                                        # one tie group of everything
+        for base in (0, 1):
+            stops, masks = _get_perturbed_samples(torch.from_numpy(attr), P, steps, base)
+            arrs[f"c{i}_b{base}_stops"] = stops.numpy()
+            arrs[f"c{i}_b{base}_masks"] = np.packbits(masks.numpy().astype(np.uint8), axis=1)
+        arrs[f"c{i}_attr"] = attr
+        arrs[f"c{i}_ranking_reference_host"] = np.argsort(attr)[::-1].astype(np.int64)
+        arrs[f"c{i}_ranking_stable"] = np.argsort(attr, kind="stable")[::-1].astype(np.int64)
+        cases.append([P, steps])
+    arrs["cases"] = np.asarray(cases, dtype=np.int64)
+    import platform
+    with open(os.path.join(HERE, "perturbed_ties.json"), "w") as f:
+        json.dump({"numpy": np.__version__, "machine": platform.machine(),
+                   "note": "np.argsort default kind; tie order is host/numpy-build specific"}, f, indent=1)
+    save("perturbed_ties.npz", **arrs)
+
+
+def sample_idx(n):
+    return np.linspace(0, n - 1, min(n, 16)).astype(np.int64)
+
+
+def gen_train_step():
+    """One reference _explainer_epoch_train step (SURVEY §8c fixture 5): scripts/train_explainer.py:128-207 run unmodified
+    on the CPU with dropout probabilities 0, one batch, AdamW lr 1e-3; per trainable parameter the gradient the step saw
+    (captured by wrapping optimizer.step) and the post-step value, as checksums + 16 samples; plus the loss and the masks."""
+    _stub_modules()
+    import reference.scripts.train_explainer as rte
+
+    class Env:
+        def log(self, msg):
+            pass
+
+    def one(tag, recipe_fn, params, kind, B, K, froyo=False):
+        params = dict(params, attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0)
+        recipe = recipe_fn()
+        cfg = recipe.t_config(**params)
+        P = recipe.n_players(cfg)
+        m_srg, m_exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
+        synth.load_synth_weights(m_srg, seed=0)
+        synth.load_synth_weights(m_exp, seed=1)
+        if kind == "vit":
+            Xs = torch.from_numpy(synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=0))
+            null = torch.zeros((1, params["img_channels"], params["img_px_size"], params["img_px_size"]))
+        else:
+            L = params["max_position_embeddings"]
+            Xs = torch.from_numpy(synth.synth_token_ids(B, L, params["vocab_size"], seed=0))
+            Xs[:, -9:] = params["pad_token_id"]          # [PAD] positions: ordinary players whose embedding row gets no gradient
+            null = torch.from_numpy(synth.synth_null_ids(L, params["vocab_size"]))
+        m_srg.eval()
+        with torch.no_grad():
+            v_0, _ = recipe.fw_surrogate(m_srg, null, torch.ones((1, P), dtype=torch.long))
+        lr = 1e-3
+        opt = torch.optim.AdamW(m_exp.parameters(), lr=lr)
+        seen = {}
+        real_step = opt.step
+
+        def step(*a, **k):
+            for n, p in m_exp.named_parameters():
+                seen[n] = None if p.grad is None else p.grad.detach().clone()
+            return real_step(*a, **k)
+        opt.step = step
+        torch.manual_seed(3407)
+        loss = rte._explainer_epoch_train(env=Env(), device=torch.device("cpu"), n_mask_samples=K, n_players=P,
+                                          surrogate_null=v_0, d_items=[(None, None)], m_recipe=recipe, m_surrogate=m_srg,
+                                          m_explainer=m_exp, optimizer=opt, epoch=1,
+                                          gen_input=lambda a, b: (Xs, torch.zeros(B, dtype=torch.long)))
+        torch.manual_seed(3407)
+        masks = rshap.mask_shapley_new(B * K, P)
+        arrs = dict(dims=np.asarray([B, K, P], dtype=np.int64), loss_mean=np.asarray([loss], dtype=np.float64),
+                    masks=np.packbits(masks.numpy().astype(np.uint8), axis=1), v_0=v_0.numpy(), lr=np.asarray([lr]))
+        if kind == "bert":
+            arrs["ids"] = Xs.numpy()
+        names = []
+        for n, p in m_exp.named_parameters():
+            if not p.requires_grad or seen.get(n) is None:
+                continue
+            gflat, pflat = seen[n].reshape(-1).double(), p.detach().reshape(-1).double()
+            idx = sample_idx(gflat.numel())
+            names.append(n)
+            arrs["g/" + n] = np.concatenate([[gflat.sum().item(), gflat.abs().sum().item(), gflat.abs().max().item()], gflat[idx].numpy()])
+            arrs["p/" + n] = np.concatenate([[pflat.sum().item(), pflat.abs().sum().item()], pflat[idx].numpy()])
+        frozen = [n for n, p in m_exp.named_parameters() if not p.requires_grad]
+        with open(os.path.join(HERE, f"train_step_{tag}.json"), "w") as f:
+            json.dump({"kind": kind, "froyo": froyo, "params": params, "B": B, "K": K, "trained": names, "frozen": frozen,
+                       "weights": {"surrogate_seed": 0, "explainer_seed": 1}, "input_seed": 0, "torch_seed": 3407}, f, indent=1)
+        save(f"train_step_{tag}.npz", **arrs)
+
+    tiny = dict(hparams("vit_tiny_imagenette_vanilla"), num_hidden_layers=2)
+    one("vit_tiny_l2", r_vvit.vanilla_vit_recipe, tiny, "vit", B=2, K=4)
+    one("froyo_vit_tiny_l2", r_fvit.froyo_vit_recipe, tiny, "vit", B=2, K=4, froyo=True)
+    bert = dict(hparams("bert_base_tayp_vanilla"), num_hidden_layers=2, max_position_embeddings=128)
+    one("bert_base_l2", r_vbert.vanilla_bert_recipe, bert, "bert", B=2, K=4)
+
+
 def gen_state_keys():
     """state-dict key -> shape of every reference class on the path (names + shapes only)."""
     import reference.recipes.duo_vanilla_vit, reference.recipes.froyo_vit  # noqa: F401
@@ -375,6 +499,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
         gen_mc_shapley()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "perturbed_ties", "train_step"):   # round-2 additions
+        {"full_depth": gen_full_depth, "perturbed_ties": gen_perturbed_ties, "train_step": gen_train_step}[sys.argv[1]]()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
         gen_ltt_models()
         gen_ltt_state_keys()
@@ -388,3 +515,6 @@ if __name__ == "__main__":
     gen_ltt_models()
     gen_ltt_state_keys()
     gen_mc_shapley()
+    gen_full_depth()
+    gen_perturbed_ties()
+    gen_train_step()

@@ -1,0 +1,229 @@
+"""GPU parity of the 256x256 ring GEMM (csrc/gemm_big.hip: the benchmarked kernel) against the float64 numpy oracle, one
+test per template instantiation, at shapes that SELECT it (M >= 1024, N >= 256) with ragged M and N edges, K in
+{128, 768, 1024, 3072} (general loop and the unrolled steady state), several tile-order groups (ngrp > 1) and the
+non-temporal store path.  Reference call sites: every nn.Linear of models/vanilla_vit.py:422-424,:477,:491-492,:510-512."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer as otr
+
+pytestmark = pytest.mark.gpu
+
+BF16 = 1
+TOL = dict(rtol=1e-2, atol=2e-2)      # bf16 storage of the result: half an ulp at |x| <= 4 is 1.6e-2
+
+
+def _r(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+def _dev(a, dev):
+    return torch.from_numpy(a).to(dev).to(torch.bfloat16)
+
+
+def _case(m, n, k, seed):
+    g = np.random.default_rng(seed)
+    a = _r((g.standard_normal((m, k)) * 1.2 + 0.2).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = g.standard_normal(n).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+    return g, a, w, b, ref
+
+
+def _assert_ring(m, n, k, epi=0):
+    from autognothi_amd import _lib as L
+    assert L.lib().ag_gemm_supports_ln_fold(m, n, k, k, n, n, epi, BF16) == 1, "shape does not select the ring kernel"
+
+
+SHAPES = [
+    (1061, 2312, 768),     # ragged M (4 full tiles + 37 rows) and ragged N (9 tiles + 8 columns), unrolled steady state
+    (1300, 3072, 768),     # W = 4.7 MB > an XCD's L2: two tile-order groups of 6 columns (ngrp > 1)
+    (1157, 768, 3072),     # K = 3072 (fc2)
+    (1024, 264, 128),      # K = 128: 4 half-steps, the general (non-unrolled) loop; one ragged column tile
+    (2100, 1024, 1024),    # ViT-large width
+    (1030, 776, 160),      # nh = 5: general loop with refills, ragged both ways
+]
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_ring_plain_epilogues(cuda_device, m, n, k):
+    """<BIAS>, <BIAS_GELU> (fast_gelu2 vs erf GELU), <BIAS_TANH>, <BIAS_F32>."""
+    from autognothi_amd import _lib as L, ops
+    _assert_ring(m, n, k)
+    _, a, w, b, ref = _case(m, n, k, m + n + k)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_F32, BF16).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=3e-5)            # fp32 accumulate of exact bf16 inputs
+    np.testing.assert_allclose(ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy(), ref, **TOL)
+    np.testing.assert_allclose(ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16).float().cpu().numpy(), otr.gelu(ref.astype(np.float32)), **TOL)
+    np.testing.assert_allclose(ops.gemm(A, W, B, L.AG_EPI_BIAS_TANH, BF16).float().cpu().numpy(), np.tanh(ref), **TOL)
+    np.testing.assert_allclose(ops.gemm(A, W, None, L.AG_EPI_BIAS, BF16).float().cpu().numpy(), ref - b, **TOL)   # bias = NULL
+
+
+def test_ring_gelu_is_the_erf_gelu_to_1e4(cuda_device):
+    """the one-transcendental GELU of the bf16 epilogue against nn.GELU() (erf), before bf16 rounding hides it: feed
+    pre-activations through an identity-like GEMM into the fp32-free path and compare the bf16 results bit-wise with the
+    bf16-rounded exact GELU except where the two fp32 values straddle a rounding boundary (|err| <= 1.7e-5 claimed)."""
+    from autognothi_amd import _lib as L, ops
+    m = n = k = 1024
+    g = np.random.default_rng(5)
+    x = _r((g.standard_normal((m, k)) * 2.5).astype(np.float32))
+    eye = np.eye(n, k, dtype=np.float32)
+    out = ops.gemm(_dev(x, cuda_device), _dev(eye, cuda_device), None, L.AG_EPI_BIAS_GELU, BF16).float().cpu().numpy()
+    want = otr.gelu(x)
+    # a bf16 result may differ from round(want) by one ulp where want sits within 1.7e-5 of a rounding boundary
+    ulp = np.maximum(np.abs(want), 2.0 ** -126) * 2.0 ** -7
+    assert np.all(np.abs(out - want) <= 0.5 * ulp + 2e-5)
+    assert (out != _r(want)).mean() < 0.06
+
+
+@pytest.mark.parametrize("m,n,k", [(1061, 776, 768), (1157, 768, 3072), (2100, 1024, 1024)])
+def test_ring_residual(cuda_device, m, n, k):
+    """<BIAS_RESID>: dense residual, a strided residual (ldr > N), and the layer-0 residual shared by `share` masked rows
+    (row index ((m / T) / share) * T + m % T) with T not a multiple of the 16-row epilogue blocks."""
+    from autognothi_amd import _lib as L, ops
+    _assert_ring(m, n, k, L.AG_EPI_BIAS_RESID)
+    g, a, w, b, ref = _case(m, n, k, 7 * m + k)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    r = _r(g.standard_normal((m, n)).astype(np.float32))
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev)).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref + r, **TOL)
+    # strided residual rows
+    rs = np.full((m, n + 24), np.nan, dtype=np.float32)
+    rs[:, :n] = r
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(rs, dev), ldr=n + 24).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref + r, **TOL)
+    # shared residual: m = rows * T output rows, `share` consecutive sequences read the same T residual rows
+    for t, share in ((197, 4), (13, 3), (128, 8)):
+        rows = m // t
+        if rows < share:
+            continue
+        rows -= rows % share
+        mm = rows * t
+        if mm < 1024:
+            continue
+        res = _r(g.standard_normal((rows // share, t, n)).astype(np.float32))
+        out = ops.gemm(A[:mm], W, B, L.AG_EPI_BIAS_RESID, BF16, m=mm, resid=_dev(res, dev), rows_per_seq=t,
+                       resid_share=share).float().cpu().numpy()
+        want = ref[:mm] + np.repeat(res, share, axis=0).reshape(mm, n)
+        np.testing.assert_allclose(out, want, **TOL)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(1061, 2312, 768, "bias"), (1300, 3072, 768, "gelu"), (2100, 4096, 1024, "gelu"), (1024, 264, 128, "bias")])
+def test_ring_layernorm_fold_consumer(cuda_device, m, n, k, epi):
+    """VAR = 1: Linear(LayerNorm(x)) with the LayerNorm folded into the epilogue (row statistics + gamma-scaled weights),
+    bias and bias+GELU epilogues, ragged edges, eps 1e-12 (models/vanilla_vit.py:369,:373)."""
+    from autognothi_amd import _lib as L, ops
+    g = np.random.default_rng(n + k)
+    x = _r((g.standard_normal((m, k)) * 1.5 + 0.3).astype(np.float32))
+    w = (g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = g.standard_normal(n).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(k)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(k)).astype(np.float32)
+    eps = 1e-12
+    ref = otr.layer_norm(x, {"ln.weight": gamma, "ln.bias": beta}, "ln", eps).astype(np.float64) @ w.astype(np.float64).T + b
+    if epi == "gelu":
+        ref = otr.gelu(ref.astype(np.float32))
+    dev = cuda_device
+    X = _dev(x, dev)
+    wf = torch.from_numpy(w * gamma[None, :]).to(dev).to(torch.bfloat16)
+    bias_f = torch.from_numpy((b + w @ beta).astype(np.float32)).to(dev)
+    colsum = wf.float().sum(dim=1).contiguous()
+    stats = ops.row_stats(X)
+    code = L.AG_EPI_BIAS if epi == "bias" else L.AG_EPI_BIAS_GELU
+    out = ops.gemm(X, wf, bias_f, code, BF16, ln_stats=stats, ln_colsum=colsum, ln_eps=eps).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=2e-2, atol=3e-2)    # + the bf16 rounding of gamma * W
+
+
+@pytest.mark.parametrize("m,n,k", [(1061, 768, 768), (1157, 1024, 4096), (1030, 264, 160)])
+def test_ring_row_statistics_producer(cuda_device, m, n, k):
+    """VAR = 2: the residual epilogue also emits (sum, sum of squares) of the bf16-rounded rows it writes, over ALL column
+    tiles, for the next folded consumer; rows beyond M and columns beyond N contribute nothing."""
+    from autognothi_amd import _lib as L, ops
+    g, a, w, b, ref = _case(m, n, k, 3 * m + n)
+    dev = cuda_device
+    r = _r(g.standard_normal((m, n)).astype(np.float32))
+    st = ops.new_row_stats(m, n, dev)
+    out = ops.gemm(_dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev), stats_out=st)
+    o = out.float().cpu().numpy()
+    np.testing.assert_allclose(o, ref + r, **TOL)
+    got = ops.reduce_row_stats(st, m, n).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], o.astype(np.float64).sum(1), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(got[:, 1], (o.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    # ... and is bit-reproducible from launch to launch (no float atomics)
+    st2 = ops.new_row_stats(m, n, dev)
+    ops.gemm(_dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev), stats_out=st2)
+    assert torch.equal(ops.reduce_row_stats(st2, m, n), ops.reduce_row_stats(st, m, n))
+
+
+def test_ring_producer_feeds_consumer(cuda_device):
+    """out-proj(+residual, statistics) -> fc1 (folded LN2 + GELU): the two kernels exactly as encoder.cpp chains them."""
+    from autognothi_amd import _lib as L, ops
+    m, h, i = 1379, 768, 3072
+    g = np.random.default_rng(99)
+    dev = cuda_device
+    ctx = _r(g.standard_normal((m, h)).astype(np.float32))
+    wo = _r((g.standard_normal((h, h)) / np.sqrt(h)).astype(np.float32))
+    bo = g.standard_normal(h).astype(np.float32)
+    hin = _r((g.standard_normal((m, h)) * 2).astype(np.float32))
+    w1 = (g.standard_normal((i, h)) / np.sqrt(h)).astype(np.float32)
+    b1 = g.standard_normal(i).astype(np.float32)
+    gamma = (1 + 0.1 * g.standard_normal(h)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(h)).astype(np.float32)
+    st = ops.new_row_stats(m, h, dev)
+    hx = ops.gemm(_dev(ctx, dev), _dev(wo, dev), torch.from_numpy(bo).to(dev), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(hin, dev), stats_out=st)
+    hx_ref = _r((ctx.astype(np.float64) @ wo.astype(np.float64).T + bo + hin).astype(np.float32))
+    np.testing.assert_allclose(hx.float().cpu().numpy(), hx_ref, **TOL)
+    wf = torch.from_numpy(w1 * gamma[None, :]).to(dev).to(torch.bfloat16)
+    bias_f = torch.from_numpy((b1 + w1 @ beta).astype(np.float32)).to(dev)
+    out = ops.gemm(hx, wf, bias_f, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st, ln_colsum=wf.float().sum(1).contiguous(), ln_eps=1e-12)
+    hx_gpu = hx.float().cpu().numpy()
+    ref = otr.gelu((otr.layer_norm(hx_gpu, {"ln.weight": gamma, "ln.bias": beta}, "ln", 1e-12).astype(np.float64) @ w1.astype(np.float64).T + b1).astype(np.float32))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("env", [{"AG_GEMM_NT": "1"}, {"AG_GEMM_NGRP": "2"}, {"AG_GEMM_NGRP": "5"}, {"AG_GEMM_NT": "1", "AG_GEMM_NGRP": "3"}])
+def test_ring_store_and_tile_order_variants(cuda_device, env):
+    """the non-temporal store path (taken by itself when the output exceeds 192 MiB) and tile-order groups that do not divide
+    the column tiles (ragged last group): same results as the default order."""
+    from autognothi_amd import _lib as L, ops
+    m, n, k = 1300, 2056, 768     # 6 x 9 tiles, the last column tile 8 wide
+    g, a, w, b, ref = _case(m, n, k, 41)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    r = _r(g.standard_normal((m, n)).astype(np.float32))
+    old = {kk: os.environ.get(kk) for kk in env}
+    os.environ.update(env)
+    try:
+        out = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
+        out_r = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev)).float().cpu().numpy()
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = v
+    np.testing.assert_allclose(out, ref, **TOL)
+    np.testing.assert_allclose(out_r, ref + r, **TOL)
+    base = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
+    np.testing.assert_array_equal(out, base)        # same arithmetic per element whatever the tile order
+
+
+def test_ring_auto_nontemporal_output(cuda_device):
+    """an output above 192 MiB switches to non-temporal stores by itself (the fc1 / QKV outputs of the benchmarked step):
+    checked on sampled rows incl. the first and last tiles."""
+    from autognothi_amd import _lib as L, ops
+    m, n, k = 33000, 3072, 768     # 203 MB of bf16 output
+    g = np.random.default_rng(3)
+    a = _r(g.standard_normal((m, k)).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = g.standard_normal(n).astype(np.float32)
+    out = ops.gemm(_dev(a, cuda_device), _dev(w, cuda_device), torch.from_numpy(b).to(cuda_device), L.AG_EPI_BIAS, BF16)
+    rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(m - 300, m), g.integers(0, m, 600)]))
+    ref = a[rows].astype(np.float64) @ w.astype(np.float64).T + b
+    np.testing.assert_allclose(out[torch.from_numpy(rows).to(cuda_device)].float().cpu().numpy(), ref, **TOL)

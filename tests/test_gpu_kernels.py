@@ -243,21 +243,22 @@ def test_gemm_layernorm_fold(cuda_device):
     bias_f = torch.from_numpy((b + w @ beta).astype(np.float32)).to(dev)
     colsum = wf.float().sum(dim=1).contiguous()
     stats = ops.row_stats(X)
-    np.testing.assert_allclose(stats.cpu().numpy()[:, 0], x.sum(1), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(ops.reduce_row_stats(stats, m, h).cpu().numpy()[:, 0], x.sum(1), rtol=1e-5, atol=1e-3)
     out = ops.gemm(X, wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=stats, ln_colsum=colsum, ln_eps=eps).float().cpu().numpy()
     np.testing.assert_allclose(out, ref, rtol=2e-2, atol=3e-2)
     # producer: a residual GEMM that writes rows and accumulates their (sum, sumsq)
     a = _bf16_round(g.standard_normal((m, h)).astype(np.float32))
     w2 = _bf16_round((g.standard_normal((h, h)) / np.sqrt(h)).astype(np.float32))
-    st_out = torch.zeros((m, 2), dtype=torch.float32, device=dev)
+    st_out = ops.new_row_stats(m, h, dev)
     hx = ops.gemm(torch.from_numpy(a).to(dev).to(torch.bfloat16), torch.from_numpy(w2).to(dev).to(torch.bfloat16), None,
                   L.AG_EPI_BIAS_RESID, BF16, resid=X, stats_out=st_out)
     hxf = hx.float().cpu().numpy()
-    np.testing.assert_allclose(st_out.cpu().numpy()[:, 0], hxf.sum(1), rtol=1e-4, atol=2e-3)
-    np.testing.assert_allclose(st_out.cpu().numpy()[:, 1], (hxf.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    tot = ops.reduce_row_stats(st_out, m, h).cpu().numpy()
+    np.testing.assert_allclose(tot[:, 0], hxf.sum(1), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(tot[:, 1], (hxf.astype(np.float64) ** 2).sum(1), rtol=1e-4)
     # the folded path is refused where it is not implemented (small / fp32 GEMMs) instead of silently ignored
     with pytest.raises(RuntimeError, match="folding"):
-        ops.gemm(X[:64], wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=stats[:64], ln_colsum=colsum)
+        ops.gemm(X[:64], wf, bias_f, L.AG_EPI_BIAS, BF16, ln_stats=ops.row_stats(X[:64]), ln_colsum=colsum)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

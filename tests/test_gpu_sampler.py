@@ -96,10 +96,19 @@ def test_torch_cpu_generator_roundtrip(cuda_device):
     rng = ops.DeviceMT19937(cuda_device).import_torch_cpu_state()
     rng.raw(1000)
     rng.export_to_torch_cpu()
-    after_device = torch.rand(5)
+    after_device = torch.rand(1500)      # crosses two 624-word block boundaries of the handed-back generator
     torch.manual_seed(3407)
     _ = torch.rand(10 + 1000)
-    assert torch.equal(after_device, torch.rand(5))
+    assert torch.equal(after_device, torch.rand(1500))
+    # hand-back exactly at a block boundary (pos == 624: the host twists on its next draw)
+    torch.manual_seed(7)
+    rng = ops.DeviceMT19937(cuda_device).import_torch_cpu_state()
+    rng.raw(624)
+    rng.export_to_torch_cpu()
+    after_device = torch.rand(700)
+    torch.manual_seed(7)
+    _ = torch.rand(624)
+    assert torch.equal(after_device, torch.rand(700))
 
 
 def test_pack_mask(cuda_device):
@@ -131,3 +140,30 @@ def test_perturbed_masks(cuda_device):
             assert on.sum() == st
             if 0 < st < 196:
                 assert attr[a][on].min() >= attr[a][~on].max()
+
+
+def test_perturbed_masks_with_ties(cuda_device):
+    """attributions WITH ties through the reference's _get_perturbed_samples (fixture made by the reference
+    on the build host).  np.argsort's default kind is not stable and its tie order depends on the host's numpy build (the
+    fixture records that it differs from the stable order), so bit-exactness is only defined where the top-k set is unique:
+    there the device masks equal the reference's; inside a tie group the device takes the higher index first and the
+    test checks that both choices are valid top-k sets."""
+    from autognothi_amd import ops
+    from util import check_perturbed_against_reference
+    g = golden("perturbed_ties.npz")
+    split = 0
+    for i, (p, steps) in enumerate(g["cases"]):
+        attr = g[f"c{i}_attr"]
+        for base in (0, 1):
+            stops, masks = ops.perturbed_masks(torch.from_numpy(attr).to(cuda_device)[None], int(steps), base)
+            split += check_perturbed_against_reference(attr, base, stops.cpu().numpy(), masks[0].cpu().numpy(),
+                                                       g[f"c{i}_b{base}_stops"], unpack(g[f"c{i}_b{base}_masks"], int(p)))
+    assert split > 20          # the fixture does exercise tie-splitting cuts
+    # the documented device rule: inside a tie group the higher index ranks first (stable ascending argsort, reversed)
+    attr = g["c0_attr"]
+    stops, masks = ops.perturbed_masks(torch.from_numpy(attr).to(cuda_device)[None], 196, 0)
+    rank_dev = np.argsort(attr, kind="stable")[::-1]
+    for s, st in enumerate(stops.cpu().numpy()):
+        want = np.zeros(196, dtype=np.int64)
+        want[rank_dev[:st]] = 1
+        assert np.array_equal(masks[0, s].cpu().numpy(), want)

@@ -174,3 +174,21 @@ def test_set_iterative_seed_reference_property():
         return random.randint(0, 1000)
     a, b, c = get("stage-a"), get("stage-b"), get("stage-c")
     assert (get("stage-c"), get("stage-a"), get("stage-b")) == (c, a, b)
+
+
+def test_torch_cpu_generator_state_fields_round_trip():
+    """(mt, pos) <-> torch's CPU generator state (at::mt19937: left == 625 - next inside a block, left == 1 when the next
+    draw twists): the state handed back by DeviceMT19937.export_to_torch_cpu must continue the host stream across block
+    boundaries.  Host-only: the field arithmetic, no device."""
+    from autognothi_amd import ops
+    for n in (0, 1, 10, 386, 623, 624, 625, 1000, 1248):
+        g = torch.Generator()
+        g.manual_seed(3407)
+        if n:
+            torch.rand(n, generator=g)
+        mt, pos = ops.parse_torch_cpu_state(g.get_state())
+        assert pos == (624 if n % 624 == 0 else n % 624)
+        h = torch.Generator()
+        h.manual_seed(1)
+        h.set_state(ops.fill_torch_cpu_state(h.get_state(), mt, pos))
+        assert torch.equal(torch.rand(1500, generator=h), torch.rand(1500, generator=g)), n

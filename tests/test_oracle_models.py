@@ -90,3 +90,20 @@ def test_oracle_ltt_matches_reference(tag):
     f_logits, f_phi = fin(c["xs"], sd_f, prm)
     np.testing.assert_allclose(f_logits, g["fin_logits"], rtol=0, atol=ATOL)
     np.testing.assert_allclose(f_phi, g["fin_phi"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["vit_base_l12", "bert_base_l12", "vit_large_l24"])
+def test_oracle_full_depth_matches_reference(tag):
+    """The shipped depth and K (BASELINE configs 2-4; fixtures: make_golden.py full_depth): the torch-CPU port — bench.py's
+    cpu_baseline and the GPU tests' gradient reference — reproduces the reference's K-mask surrogate values at 12 / 24
+    layers (the numpy oracle is pinned on the truncated fixtures above; at full depth it takes minutes on 8 cores)."""
+    import torch
+    c = build_case(tag)
+    g, prm, kind = c["g"], c["meta"]["params"], c["meta"]["kind"]
+    sd_t = {k: v.detach() for k, v in c["surrogate"].state_dict().items()}
+    srg_t = otp.vit_surrogate if kind == "vit" else otp.bert_surrogate
+    xs_ext = torch.from_numpy(np.repeat(c["xs"], c["K"], axis=0))
+    v_s = srg_t(xs_ext, torch.from_numpy(c["masks"]), sd_t, prm).numpy()
+    np.testing.assert_allclose(v_s, g["v_s"], rtol=0, atol=ATOL)
+    v_1 = srg_t(torch.from_numpy(c["xs"]), torch.ones((c["B"], c["P"]), dtype=torch.long), sd_t, prm).numpy()
+    np.testing.assert_allclose(v_1, g["v_1"], rtol=0, atol=ATOL)

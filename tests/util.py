@@ -40,6 +40,9 @@ MODEL_TAGS = ["vit_tiny_c1", "vit_base_l2", "vit_large_l2", "bert_base_l2", "duo
 
 LTT_TAGS = ["ltt_vit_tiny_l3", "ltt_bert_base_l2"]
 
+# the shipped configs at their real depth and K, one input each (BASELINE configs 2-5)
+FULL_TAGS = ["vit_base_l12", "bert_base_l12", "vit_large_l24", "duo_bert_base_l12", "froyo_vit_base_l12"]
+
 
 def recipe_kind(meta):
     if meta.get("ltt"):
@@ -76,3 +79,30 @@ def build_case(tag):
         synth.load_synth_weights(fin, seed=meta["weights"]["final_seed"])
         out["final"] = fin.eval()
     return out
+
+
+def tie_split(attr, stop):
+    """does a cut after the `stop` highest attributions fall INSIDE a group of equal values (top-`stop` set not unique)?"""
+    v = np.sort(np.asarray(attr))[::-1]
+    return 0 < stop < len(v) and v[stop - 1] == v[stop]
+
+
+def check_perturbed_against_reference(attr, base, stops, masks, ref_stops, ref_masks):
+    """masks [S,P] vs the reference's on an attribution with ties: identical wherever the top-k set is unique; where a cut
+    splits a tie group any k-subset that contains everything strictly larger and nothing strictly smaller is a correct
+    answer (the reference's own choice there is np.argsort's unstable, host-specific order: tests/golden/perturbed_ties.json)."""
+    attr = np.asarray(attr)
+    assert np.array_equal(stops, ref_stops)
+    n_split = 0
+    for s, st in enumerate(stops):
+        flipped = masks[s] != base
+        assert flipped.sum() == st
+        if not tie_split(attr, st):
+            assert np.array_equal(masks[s], ref_masks[s]), (s, st)
+            continue
+        n_split += 1
+        thr = np.sort(attr)[::-1][st - 1]
+        assert flipped[attr > thr].all() and not flipped[attr < thr].any(), (s, st)
+        ref_flipped = ref_masks[s] != base
+        assert ref_flipped[attr > thr].all() and not ref_flipped[attr < thr].any()
+    return n_split
