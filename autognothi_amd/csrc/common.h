@@ -113,6 +113,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// x[l] + x[l^16] + x[l^32] + x[l^48] on every lane (the four lanes that hold one accumulator row in the 16x16 MFMA layout),
+// by the gfx950 row / half swaps: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows
+// of the second, v_permlane32_swap the upper half of the first with the lower half of the second — with both operands the
+// same value the two results are x and its partner, so one swap + one add per level (a __shfl_xor is a ds_bpermute with
+// address arithmetic and an LDS round trip).  All four lanes end with the same bits: (x0 + x1) + (x2 + x3).
+__device__ __forceinline__ float quad_rows_sum(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t dtype_size(int dtype) { return dtype == AG_BF16 ? 2 : 4; }
 

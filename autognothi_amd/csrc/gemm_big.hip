@@ -25,6 +25,7 @@ constexpr int HALF_OP_BYTES = BT * HROWB;       // 16 KiB per operand per half-s
 constexpr int SLOT_BYTES = 2 * HALF_OP_BYTES;   // 32 KiB
 constexpr int NSLOT = 4;
 constexpr int NT = 512;
+constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + BT * 8;   // ring + one (mean, rstd) pair per tile row (LayerNorm-fold consumer)
 
 struct BigArgs {
     const char* A; long lda_b;
@@ -123,6 +124,33 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     constexpr int STAT_OFF = 8192;  // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its 16 KB
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
 
+    // ---- row constants (LayerNorm fold) ----
+    // Each of the tile's 256 rows is finished ONCE per workgroup: wave (wm, wn) takes rows [32 wn, 32 wn + 32) of its half,
+    // lanes 0..31 add the row's S slab partials in slab order, turn them into (mean, rstd) and park the pair in the LDS
+    // tail behind the ring; the barrier below (which the epilogue needs anyway: the staging buffers live in the ring)
+    // publishes them, and the row loop reads its pair back with one ds_read_b64.  The loads are requested before the
+    // column constants so that both batches are in flight together.
+    float2* const stat_lds = reinterpret_cast<float2*>(const_cast<char*>(smem_base) + NSLOT * SLOT_BYTES);
+    const int wave_id = (int)((stg - smem_base) >> 14);
+    float2 racc = make_float2(0.f, 0.f);
+    if (LNF && lane < 32) {
+        int m = mw0 + (wave_id & 3) * 32 + lane;
+        m = m < p.M ? m : p.M - 1;
+        const float* sp = p.ln_stats + 2 * (long)m;
+        // up to four slabs (H <= 1024: every shipped width) requested together, added in slab order
+        float2 v[4];
+#pragma unroll
+        for (int s_i = 0; s_i < 4; ++s_i) v[s_i] = *reinterpret_cast<const float2*>(sp + (s_i < p.ln_nslab ? s_i : 0) * p.stats_slab);
+        racc = v[0];
+#pragma unroll
+        for (int s_i = 1; s_i < 4; ++s_i) {
+            racc.x += s_i < p.ln_nslab ? v[s_i].x : 0.f; racc.y += s_i < p.ln_nslab ? v[s_i].y : 0.f;
+        }
+        for (int s_i = 4; s_i < p.ln_nslab; ++s_i) {      // wider rows: one more round trip per slab
+            const float2 w = *reinterpret_cast<const float2*>(sp + s_i * p.stats_slab);
+            racc.x += w.x; racc.y += w.y;
+        }
+    }
     // ---- column constants ----
     float4 bv[4], sv[4];
     int ncl[4];
@@ -141,41 +169,15 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn) sv[sn] = *reinterpret_cast<const float4*>(p.ln_s + ncl[sn]);
     }
-    // ---- row constants ----
-    // The four lanes that share a row (fq = 0..3) each fetch ONE slab's partial of it; two xor-shuffles add the four
-    // partials in the same order on every lane: (p0 + p1) + (p2 + p3).  More than four slabs (H > 1024): further rounds.
-    float2 st[8];
     if (LNF) {
-        const bool have = fq < p.ln_nslab;
-        const float* sp = p.ln_stats + (have ? fq : 0) * p.stats_slab;
-#pragma unroll
-        for (int sm = 0; sm < 8; ++sm) {
-            int m = mw0 + sm * 16 + frow;
-            m = m < p.M ? m : p.M - 1;
-            st[sm] = *reinterpret_cast<const float2*>(sp + 2 * (long)m);
+        if (lane < 32) {
+            const float mean = racc.x * p.ln_inv_h;
+            const float rstd = rsqrtf(fmaxf(racc.y * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
+            stat_lds[(wave_id >> 2) * 128 + (wave_id & 3) * 32 + lane] = make_float2(mean, rstd);
         }
-#pragma unroll
-        for (int sm = 0; sm < 8; ++sm) {
-            float sx = have ? st[sm].x : 0.f, sy = have ? st[sm].y : 0.f;
-            sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
-            sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
-            st[sm] = make_float2(sx, sy);
-        }
-        for (int s0 = 4; s0 < p.ln_nslab; s0 += 4) {      // (not reached by the shipped widths)
-            const bool hv = s0 + fq < p.ln_nslab;
-            const float* sq = p.ln_stats + (hv ? s0 + fq : 0) * p.stats_slab;
-#pragma unroll
-            for (int sm = 0; sm < 8; ++sm) {
-                int m = mw0 + sm * 16 + frow;
-                m = m < p.M ? m : p.M - 1;
-                const float2 v = *reinterpret_cast<const float2*>(sq + 2 * (long)m);
-                float sx = hv ? v.x : 0.f, sy = hv ? v.y : 0.f;
-                sx += __shfl_xor(sx, 16, 64); sy += __shfl_xor(sy, 16, 64);
-                sx += __shfl_xor(sx, 32, 64); sy += __shfl_xor(sy, 32, 64);
-                st[sm].x += sx; st[sm].y += sy;
-            }
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (!OUT_F32) asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring (the staging buffers reuse it)
     // residual row of output row m: ((m / T) / share) * T + (m % T); walked incrementally (m advances by 16)
     int r_t = 0, r_seq_rem = 0;
     long r_base = 0;  // (seq / share) * T
@@ -217,8 +219,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         }
         float ln_mean = 0.f, ln_rstd = 1.f;
         if (LNF) {
-            ln_mean = st[sm].x * p.ln_inv_h;
-            ln_rstd = rsqrtf(fmaxf(st[sm].y * p.ln_inv_h - ln_mean * ln_mean, 0.f) + p.ln_eps);
+            const float2 mr = stat_lds[(wave_id >> 2) * 128 + sm * 16 + frow];
+            ln_mean = mr.x; ln_rstd = mr.y;
         }
         float row_s = 0.f, row_q = 0.f;  // producer side: stats of the bf16-rounded values this lane writes
 #pragma unroll
@@ -260,8 +262,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         }
         if (STATS) {  // lanes frow + 16*fq hold parts of row m: combine the 4 column groups; this wave's 64-column partial of
             // the row goes to LDS (combined with the other three column waves after the loop)
-            row_s += __shfl_xor(row_s, 16, 64); row_q += __shfl_xor(row_q, 16, 64);
-            row_s += __shfl_xor(row_s, 32, 64); row_q += __shfl_xor(row_q, 32, 64);
+            row_s = quad_rows_sum(row_s); row_q = quad_rows_sum(row_q);
             if (fq == 0) *reinterpret_cast<float2*>(stg + STAT_OFF + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
         }
         if (!OUT_F32 && (sm & 1)) {
@@ -285,7 +286,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         // the four column waves (wn = 0..3) of this row half have each left 128 row partials in their LDS pieces: add them
         // in wave order and store ONE (sum, sumsq) per row and column tile.  Wave wn finishes rows [32 wn, 32 wn + 32).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int wave = (int)((stg - smem_base) >> 14), wn = wave & 3;
+        const int wave = wave_id, wn = wave & 3;
         if (lane < 32) {
             const int row = wn * 32 + lane;
             const char* half = smem_base + (wave & 4) * 16384 + STAT_OFF + row * 8;
@@ -462,7 +463,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
     // ---- epilogue ----
     AG_MARK(123)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (already true: the last half-step waited for 0)
-    if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");  // every wave is done reading the ring
     wave_epilogue<EPI, VAR == 1, VAR == 2>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
     AG_MARK(124)
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -475,12 +475,12 @@ int launch_ring_var(const BigArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_ring): %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
-    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
@@ -499,9 +499,9 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
     }
     if (a.dbg && EPI == AG_EPI_BIAS) {  // diagnostic (stamped) build, tools/gemm_stamps.py
         static bool dset = false;
-        if (!dset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES); dset = true; }
+        if (!dset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); dset = true; }
         const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
-        hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 0, true>), dim3(tiles), dim3(NT), NSLOT * SLOT_BYTES, s, a);
+        hipLaunchKernelGGL((gemm_ring_kernel<AG_EPI_BIAS, 0, true>), dim3(tiles), dim3(NT), LDS_BYTES, s, a);
         AG_LAUNCH_CHECK();
         return AG_OK;
     }

@@ -365,6 +365,54 @@ def gen_full_depth():
     gen_model_fixture("froyo_vit_base_l12", r_fvit.froyo_vit_recipe, fvit, "vit", B=1, K=32, mask_seed=3407, froyo=True)
 
 
+def gen_full_depth_aux():
+    """What the full-depth tolerances are derived from: the reference run in float64 (same synthetic weights and inputs cast
+    up) next to its fp32 self — |ref32 - ref64| is the reference's OWN rounding noise at 12 / 24 layers, the yardstick for
+    an fp32 comparison — and the magnitude of the explainer MLP's raw output, of which phi is a small difference
+    (phi = pred + ((grand - null) - sum pred) / T): a storage rounding of pred moves phi by |pred| u, not |phi| u."""
+    table = {
+        "vit_base_l12": (r_vvit.vanilla_vit_recipe, hparams("vit_base_imagenette_vanilla"), "vit", 32),
+        "bert_base_l12": (r_vbert.vanilla_bert_recipe, dict(hparams("bert_base_tayp_vanilla"), max_position_embeddings=128), "bert", 32),
+        "vit_large_l24": (r_vvit.vanilla_vit_recipe, hparams("vit_large_imagenette_vanilla"), "vit", 64),
+        "duo_bert_base_l12": (r_dbert.duo_vanilla_bert_recipe, dict(hparams("bert_base_tayp_duo_vanilla"), max_position_embeddings=128), "bert", 32),
+        "froyo_vit_base_l12": (r_fvit.froyo_vit_recipe, hparams("vit_base_imagenette_vanilla"), "vit", 32),
+    }
+    for tag, (recipe_fn, params, kind, K) in table.items():
+        g = np.load(os.path.join(HERE, f"model_{tag}.npz"))
+        recipe = recipe_fn()
+        cfg = recipe.t_config(**params)
+        P = recipe.n_players(cfg)
+        m_srg, m_exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
+        synth.load_synth_weights(m_srg, seed=0)
+        synth.load_synth_weights(m_exp, seed=1)
+        m_srg.eval(); m_exp.eval()
+        if kind == "vit":
+            Xs = torch.from_numpy(synth.synth_images(1, params["img_px_size"], params["img_channels"], seed=0))
+        else:
+            Xs = torch.from_numpy(synth.synth_token_ids(1, params["max_position_embeddings"], params["vocab_size"], seed=0))
+        masks = torch.from_numpy(np.unpackbits(g["masks"], axis=-1)[:, :P].astype(np.int64))
+        ones = torch.ones((1, P), dtype=torch.long)
+        v_1, v_0 = torch.from_numpy(g["v_1"]), torch.from_numpy(g["v_0"])
+        raw = []
+        head = m_exp.explainer_mlp
+        hook = head.register_forward_hook(lambda m, i, o: raw.append(o.detach()))
+        with torch.no_grad():
+            recipe.fw_explainer(m_exp, Xs, ones, v_1, v_0)
+        hook.remove()
+        pred = raw[0]
+        m_srg.double(); m_exp.double()
+        X64 = Xs.double() if kind == "vit" else Xs
+        with torch.no_grad():
+            v_s64, _ = recipe.fw_surrogate(m_srg, torch.repeat_interleave(X64, K, dim=0), masks)
+            out = recipe.fw_explainer(m_exp, X64, ones, v_1.double(), v_0.double())
+        phi64 = out[0]
+        save(f"model_{tag}_aux.npz", v_s64=v_s64.numpy(), phi64=phi64.numpy(),
+             pred_absmax=np.asarray([pred.abs().max().item()]), pred_meanabs=np.asarray([pred.abs().mean().item()]),
+             noise_v_s=np.asarray([np.abs(v_s64.numpy() - g["v_s"]).max()]), noise_phi=np.asarray([np.abs(phi64.numpy() - g["phi"]).max()]))
+        print(tag, "reference fp32 vs fp64: v_s", np.abs(v_s64.numpy() - g["v_s"]).max(), "phi", np.abs(phi64.numpy() - g["phi"]).max(),
+              "| pred absmax", pred.abs().max().item(), "phi absmax", np.abs(g["phi"]).max())
+
+
 def gen_perturbed_ties():
     """_get_perturbed_samples on attributions WITH ties (SURVEY §8c fixture 4).  The reference ranks with np.argsort's
     default kind, which is not stable: the order inside a tie group is whatever this host's numpy build does (AVX-512
@@ -499,8 +547,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
         gen_mc_shapley()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "perturbed_ties", "train_step"):   # round-2 additions
-        {"full_depth": gen_full_depth, "perturbed_ties": gen_perturbed_ties, "train_step": gen_train_step}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "full_depth_aux", "perturbed_ties", "train_step"):   # round-2 additions
+        {"full_depth": gen_full_depth, "full_depth_aux": gen_full_depth_aux, "perturbed_ties": gen_perturbed_ties,
+         "train_step": gen_train_step}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
         gen_ltt_models()
@@ -516,5 +565,6 @@ if __name__ == "__main__":
     gen_ltt_state_keys()
     gen_mc_shapley()
     gen_full_depth()
+    gen_full_depth_aux()
     gen_perturbed_ties()
     gen_train_step()

@@ -177,6 +177,7 @@ def test_reference_explainer_step_fixture(cuda_device, tag):
     np.testing.assert_allclose(loss, float(g["loss_mean"][0]), rtol=2e-4)
     assert len(env.lines) == 1 and ":0:train" in env.lines[0]
     trained = set(meta["trained"])
+    gscale = max(float(g["g/" + n][2]) for n in trained)        # largest gradient element of the step
     for n, q in exp.named_parameters():
         if n in meta["frozen"]:
             assert not q.requires_grad and seen[n] is None and torch.equal(q, before[n]), n
@@ -186,8 +187,8 @@ def test_reference_explainer_step_fixture(cuda_device, tag):
         gsum, gabs, gmax, gsamp = gw[0], gw[1], gw[2], gw[3:]
         got = seen[n].reshape(-1).double().cpu()
         idx = _sample_idx(got.numel())
-        if gmax < 1e-9:        # structurally zero in the reference (key biases: soft-max shift invariance)
-            assert float(got.abs().max()) < 1e-6, n
+        if gmax < 1e-5 * gscale:   # structurally zero in the reference (key biases: soft-max shift invariance): rounding noise
+            assert float(got.abs().max()) < 1e-4 * gscale, n
             continue
         np.testing.assert_allclose(got[idx].numpy(), gsamp, rtol=2e-3, atol=2e-3 * gmax, err_msg=n)
         np.testing.assert_allclose(float(got.abs().sum()), gabs, rtol=5e-3, err_msg=n)
