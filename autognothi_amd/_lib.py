@@ -41,8 +41,10 @@ SIGNATURES = {
     "ag_mt19937_seed": (i32, [vp, u32, vp]),
     "ag_mt19937_import": (i32, [vp, vp, i32, vp]),
     "ag_mt19937_export": (i32, [vp, vp, C.POINTER(i32), vp]),
+    "ag_mt19937_skip": (i32, [vp, i64, vp]),
     "ag_mt19937_raw": (i32, [vp, vp, i64, vp]),
     "ag_mask_shapley_new": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
+    "ag_mask_shapley_new_rows": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "ag_mask_purely_uniform": (i32, [vp, i32, i32, vp, vp, vp, vp]),
     "ag_pack_mask": (i32, [vp, i32, i32, vp, vp]),
     "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
@@ -83,8 +85,9 @@ SIGNATURES = {
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),
     "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
     "ag_encoder_forward_chained": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp, i32, i32, C.POINTER(i32), vp]),
-    "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, C.POINTER(i32), vp]),
+    "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, vp, vp]),
     "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp]),
+    "ag_dynamic_rows": (i32, [vp]),
     "ag_seq_compact_plan": (i32, [vp, i32, i32, vp, vp, vp]),
     "ag_gather_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "ag_masked_attention_varlen": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

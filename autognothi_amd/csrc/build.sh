@@ -7,14 +7,17 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 OBJS=()
+PIDS=()
 for src in gemm.hip gemm_big.hip probe.hip attention.hip sampler.hip elementwise.hip shapley.hip train.hip encoder.cpp capi.cpp; do
   obj="$OUT/${src%.*}.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ ../../include/autognothi_hip.h -nt "$obj" ]; then
     echo "hipcc $src"
+    rm -f "$obj"          # a failed compile must not leave a stale object behind
     $HIPCC $FLAGS -x hip -c "$src" -o "$obj" &
+    PIDS+=($!)
   fi
   OBJS+=("$obj")
 done
-wait
+for pid in "${PIDS[@]}"; do wait "$pid"; done   # (set -e: the first failed compile aborts the build)
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libautognothi_hip.so" "${OBJS[@]}"
 echo "built $OUT/libautognothi_hip.so"

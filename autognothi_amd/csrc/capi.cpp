@@ -36,7 +36,7 @@ extern "C" int ag_device_info(int device, int* cu_count, char* arch, size_t arch
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; const int* dyn; double rows_upper; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -49,10 +49,17 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-AgProfScope::AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
+thread_local const int* g_ag_dyn_rows = nullptr;
+
+extern "C" int ag_dynamic_rows(const int* d_rows) {
+    g_ag_dyn_rows = d_rows;
+    return AG_OK;
+}
+
+AgProfScope::AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, double rows_upper) : idx(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{kernel_class, flops, bytes, take_event(), take_event()};
+    ProfRec r{kernel_class, flops, bytes, take_event(), take_event(), rows_upper > 0.0 ? g_ag_dyn_rows : nullptr, rows_upper};
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
     idx = (int)g_recs.size() - 1;
@@ -79,7 +86,13 @@ extern "C" int ag_profile_collect(int kernel_class, double* total_ms, double* to
         AG_HIP_CHECK(hipEventSynchronize(r.e1));
         float t = 0.f;
         AG_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
-        ms += t; fl += r.flops; by += r.bytes; ++n;
+        double scale = 1.0;
+        if (r.dyn) {   // the launch ran on *dyn rows of the rows_upper it was sized (and priced) for
+            int actual = 0;
+            AG_HIP_CHECK(hipMemcpy(&actual, r.dyn, sizeof(int), hipMemcpyDeviceToHost));
+            if ((double)actual < r.rows_upper) scale = (double)actual / r.rows_upper;
+        }
+        ms += t; fl += r.flops * scale; by += r.bytes * scale; ++n;
         g_pool.push_back(r.e0); g_pool.push_back(r.e1);
     }
     g_recs.swap(keep);

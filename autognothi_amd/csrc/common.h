@@ -132,9 +132,19 @@ static inline size_t dtype_size(int dtype) { return dtype == AG_BF16 ? 2 : 4; }
 struct AgProfScope {
     int idx;
     hipStream_t stream;
-    AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s);
+    // rows_upper > 0: flops / bytes were computed for rows_upper rows while the launch runs under ag_dynamic_rows(): the
+    // totals are scaled by (actual rows / rows_upper) when collected
+    AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, double rows_upper = 0.0);
     ~AgProfScope();
 };
+
+// ag_dynamic_rows(): device pointer to the actual row count of the following launches of this host thread (NULL = the
+// host-side count is exact).  Read by the launchers of ag_gemm / ag_layernorm / ag_gather_rows and handed to their kernels.
+extern thread_local const int* g_ag_dyn_rows;
+__device__ __forceinline__ int ag_dyn_clamp(int rows, const int* dyn) {
+    if (dyn) { const int d = *dyn; rows = d < rows ? d : rows; }
+    return rows;
+}
 
 // gemm_big.hip
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);

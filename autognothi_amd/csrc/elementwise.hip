@@ -22,7 +22,9 @@ constexpr int LN_MAXV = 8;  // supports H up to 2048
 template <typename XT, typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x, int64_t ldx, int rows, int H,
                                                         const float* __restrict__ g, const float* __restrict__ b,
-                                                        float eps, T* __restrict__ ys, float* __restrict__ yf) {
+                                                        float eps, T* __restrict__ ys, float* __restrict__ yf,
+                                                        const int* __restrict__ dyn) {
+    rows = ag_dyn_clamp(rows, dyn);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -75,7 +77,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
 // kernel leave the memory pipeline with twice the instructions per byte)
 __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __restrict__ x, int64_t ldx, int rows, int H,
                                                                const float* __restrict__ g, const float* __restrict__ b,
-                                                               float eps, bf16_t* __restrict__ ys, float* __restrict__ yf) {
+                                                               float eps, bf16_t* __restrict__ ys, float* __restrict__ yf,
+                                                               const int* __restrict__ dyn) {
+    rows = ag_dyn_clamp(rows, dyn);
     const int lane = threadIdx.x & 63, sub = lane & 31;
     const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     const bool live = row < rows;
@@ -143,7 +147,9 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __r
 template <typename XT, typename T>
 __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const XT* __restrict__ x, int64_t ldx, int rows, int H,
                                                                const float* __restrict__ g, const float* __restrict__ b,
-                                                               float eps, T* __restrict__ ys, float* __restrict__ yf) {
+                                                               float eps, T* __restrict__ ys, float* __restrict__ yf,
+                                                               const int* __restrict__ dyn) {
+    rows = ag_dyn_clamp(rows, dyn);
     const int lane = threadIdx.x & 63, sub = lane & 7;
     const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
     const bool live = row < rows;
@@ -367,7 +373,9 @@ __global__ __launch_bounds__(256) void seq_index_kernel(const uint32_t* __restri
 }
 // dst[i, :] = src[idx[i], :]  (rows of H elements of `es` bytes, 16-byte vectors)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, long ld_src_b, const int* __restrict__ idx,
-                                                          char* __restrict__ dst, long ld_dst_b, int n, int row_bytes) {
+                                                          char* __restrict__ dst, long ld_dst_b, int n, int row_bytes,
+                                                          const int* __restrict__ dyn) {
+    n = ag_dyn_clamp(n, dyn);
     const int vec = row_bytes >> 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * vec; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / vec), v = (int)(i % vec);
@@ -398,14 +406,16 @@ extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows,
     const int blocks = ceil_div(rows, 4);
     hipStream_t s = (hipStream_t)stream;
     AG_REQUIRE(x_dtype == AG_F32 || x_dtype == AG_BF16, "ag_layernorm: bad x_dtype %d", x_dtype);
-    AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * ((double)dtype_size(x_dtype) + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s);
+    const int* dyn = g_ag_dyn_rows;
+    AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * ((double)dtype_size(x_dtype) + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s,
+                     dyn ? (double)rows : 0.0);
     if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
     const bool narrow = H <= 128;                      // 8 lanes per row, 32 rows per block
     const int nblk = narrow ? ceil_div(rows, 32) : blocks;
 #define AG_LN_LAUNCH(XT_, T_, X_, Y_)                                                                                              \
     do {                                                                                                                           \
-        if (narrow) hipLaunchKernelGGL((layernorm_narrow_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32); \
-        else hipLaunchKernelGGL((layernorm_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32);               \
+        if (narrow) hipLaunchKernelGGL((layernorm_narrow_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32, dyn); \
+        else hipLaunchKernelGGL((layernorm_kernel<XT_, T_>), dim3(nblk), dim3(256), 0, s, X_, ldx, rows, H, d_gamma, d_beta, eps, Y_, d_y_f32, dyn);          \
     } while (0)
     if (x_dtype == AG_F32) {
         const float* x = (const float*)d_x;
@@ -415,7 +425,7 @@ extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows,
         const bf16_t* x = (const bf16_t*)d_x;
         static const bool wide_off = getenv("AG_LN_WIDE") && atoi(getenv("AG_LN_WIDE")) == 0;
         if (dtype == AG_BF16 && !narrow && !wide_off && H % 8 == 0 && H <= 1024 && ldx % 8 == 0)
-            hipLaunchKernelGGL(layernorm_bf16x8_kernel, dim3(ceil_div(rows, 8)), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32);
+            hipLaunchKernelGGL(layernorm_bf16x8_kernel, dim3(ceil_div(rows, 8)), dim3(256), 0, s, x, ldx, rows, H, d_gamma, d_beta, eps, (bf16_t*)d_y_store, d_y_f32, dyn);
         else if (dtype == AG_BF16) AG_LN_LAUNCH(bf16_t, bf16_t, x, (bf16_t*)d_y_store);
         else AG_LN_LAUNCH(bf16_t, float, x, (float*)d_y_store);
     }
@@ -501,7 +511,7 @@ extern "C" int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_in
     const long total = (long)n * ((H * es) >> 4);
     const int grid = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)d_src, (long)(ld_src * es), d_index,
-                       (char*)d_dst, (long)(ld_dst * es), n, (int)(H * es));
+                       (char*)d_dst, (long)(ld_dst * es), n, (int)(H * es), g_ag_dyn_rows);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -194,15 +194,20 @@ extern "C" int ag_encoder_forward_chained(const ag_encoder_desc* d, const void* 
 // attention; the last layer's out-projection / MLP run on the CLS rows only.  On Shapley-kernel masks half the
 // players are off on average: half the GEMM rows, a quarter of the attention.
 // Output contract = ag_encoder_forward(cls_only_last = 1): d_h [R,T,H] with token 0 of every row defined.
-// One 4-byte device->host read (the packed row count) sizes the launches: this entry synchronises the stream once.
+// The packed row count never leaves the device: launches are sized for the upper bound R*T and clamp to it at run time
+// (ag_dynamic_rows), so this entry neither synchronises nor allocates and can be captured into a hipGraph.
 extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const void* d_h0, int R, int share,
                                               const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
-                                              int* packed_rows_out, void* stream) {
+                                              int* d_packed_rows_out, void* stream) {
     AG_REQUIRE(d && d_h0 && d_mask_bits && d_h && d_workspace, "ag_bert_encoder_forward_pruned: null pointer");
     AG_REQUIRE(d->kind == AG_MASK_BERT_ADD, "ag_bert_encoder_forward_pruned: only the additive (BERT) mask prunes exactly");
     AG_REQUIRE(d->n_layers >= 1 && d->layers, "ag_bert_encoder_forward_pruned: no layers");
     if (d->n_layers == 1) {
-        if (packed_rows_out) *packed_rows_out = R * d->T;
+        if (d_packed_rows_out) {
+            const int all = R * d->T;
+            AG_HIP_CHECK(hipMemcpyAsync(d_packed_rows_out, &all, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+            AG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        }
         return ag_encoder_forward(d, d_h0, R, share, d_mask_bits, d_h, 1, d_workspace, workspace_bytes, stream);
     }
     AG_REQUIRE(workspace_bytes >= ag_encoder_workspace_bytes(d, R), "ag_bert_encoder_forward_pruned: workspace too small");
@@ -215,15 +220,21 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     ag_encoder_desc d0 = *d;
     d0.n_layers = 1;
     TRY(ag_encoder_forward(&d0, d_h0, R, share, d_mask_bits, d_h, 0, d_workspace, workspace_bytes, stream));
-    // plan + pack
+    // plan + pack.  The packed row count N lives on the device (cu[R]); nothing is read back: the launches of the packed
+    // section are sized for the upper bound R*T and run under ag_dynamic_rows(cu + R), their kernels clamp to N.
     int* cu = ws.idx;
     int* tok_src = ws.idx + R + 1;
     TRY(ag_seq_compact_plan(d_mask_bits, R, T, cu, tok_src, stream));
-    int N = 0;
-    AG_HIP_CHECK(hipMemcpyAsync(&N, cu + R, sizeof(int), hipMemcpyDeviceToHost, hs));
-    AG_HIP_CHECK(hipStreamSynchronize(hs));
-    AG_REQUIRE(N >= R && N <= R * T, "ag_bert_encoder_forward_pruned: packed row count %d out of range (CLS bit missing from a mask row?)", N);
-    if (packed_rows_out) *packed_rows_out = N;
+    const int N = R * T;                   // upper bound of the packed rows
+    const int* dN = cu + R;
+    if (d_packed_rows_out) AG_HIP_CHECK(hipMemcpyAsync(d_packed_rows_out, dN, sizeof(int), hipMemcpyDeviceToDevice, hs));
+    struct DynScope {                      // launches inside run on *dN rows; restored on every exit path
+        const int* prev;
+        explicit DynScope(const int* p) : prev(g_ag_dyn_rows) { g_ag_dyn_rows = p; }
+        ~DynScope() { g_ag_dyn_rows = prev; }
+        void off() { g_ag_dyn_rows = prev; }
+        void on(const int* p) { g_ag_dyn_rows = p; }
+    } dyn(dN);
     char* x = ws.xs;                       // packed stream entering the layer
     TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, stream));
     char* xn = (char*)d_h;                 // d_h is free again (only token 0 of each row is defined at exit): ping-pong
@@ -236,7 +247,8 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         const char* ctx = ws.ctx;
         const char* res = x;
         int Mo = N;
-        if (last) {   // CLS rows only: compact [R,H] copies of the attention output and of the residual
+        if (last) {   // CLS rows only: compact [R,H] copies of the attention output and of the residual; exact row count from here on
+            dyn.off();
             TRY(ag_gather_rows(ws.ctx, H, cu, ws.inter, H, R, H, dt, stream));
             TRY(ag_gather_rows(x, H, cu, ws.inter + (size_t)R * H * es, H, R, H, dt, stream));
             ctx = ws.inter; res = ws.inter + (size_t)R * H * es; Mo = R;

@@ -37,6 +37,7 @@ struct GemmArgs {
     int M, N, K;
     long kbytes;          // K * sizeof(T): 16-B chunks at or beyond it are read from `zeros` instead
     const char* zeros;    // >= 16 B of zeros in HBM
+    const int* dyn;       // ag_dynamic_rows(): M is an upper bound, the actual row count is read here (NULL: M is exact)
 };
 
 template <typename T> struct Mma;
@@ -82,7 +83,9 @@ __device__ __forceinline__ uint4 lds_frag(const char* lds_tile, int row, int chu
 }
 
 template <typename T, int EPI, int BT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs pin) {
+    GemmArgs p = pin;
+    p.M = ag_dyn_clamp(p.M, p.dyn);    // the grid was sized for the upper bound: surplus workgroups leave at once
     constexpr int BM = BT, BN = BT, TILE_BYTES = BT * ROWB, NS = BT / 32, WT = BT / 2;   // NS sub-tiles per wave and dim
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs p) {
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
     // bijective XCD remap (blocks b and b+8 share an XCD under round-robin dispatch)
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
@@ -274,11 +278,13 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
         AG_HIP_CHECK(hipMemset(zero_chunk, 0, 256));
     }
     a.zeros = zero_chunk;
+    a.dyn = g_ag_dyn_rows;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic work of this launch: 2*M*N*K flops; bytes = A + W + C (+R) each touched once
     const double out_es = (epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
-                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (has_r ? (double)M * N * es : 0.0), s);
+                     (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (has_r ? (double)M * N * es : 0.0), s,
+                     g_ag_dyn_rows ? (double)M : 0.0);
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
     const bool big = dtype == AG_BF16 && !force_small && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
     AG_REQUIRE(big || (!d_ln_stats && !d_stats_out), "ag_gemm: LayerNorm folding is only available on the large-M bf16 path "

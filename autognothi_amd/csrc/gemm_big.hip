@@ -46,6 +46,7 @@ struct BigArgs {
     long stats_slab;   // floats between slabs (= 2 M)
     int ln_nslab;      // slabs of ln_stats (= ceil(K / 256))
     unsigned long long* dbg;  // diagnostic build only
+    const int* dyn;  // ag_dynamic_rows(): actual row count (NULL: M is exact)
     int ngrp;      // N-tiles per tile-order group (>= 1)
     int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
 };
@@ -304,7 +305,9 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
 
 // VAR: 0 plain, 1 LayerNorm-folded consumer (ln_stats / ln_s), 2 row-statistics producer (stats_out)
 template <int EPI, int VAR = 0, bool DBG = false>
-__global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
+__global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
+    BigArgs p = pin;
+    p.M = ag_dyn_clamp(p.M, p.dyn);    // grid sized for the upper bound: workgroups beyond the actual tiles leave at once
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,6 +315,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs p) {
 
     const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
     const int nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     // Tile order: N-tiles are walked in groups of `ngrp` columns, a whole group for every M-panel before the next
@@ -529,6 +533,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K; a.stats_out = d_stats_out;
     a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, BT);
     a.dbg = nullptr;
+    a.dyn = g_ag_dyn_rows;
     if (getenv("AG_GEMM_DBG")) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) { (void)hipMalloc((void**)&dbuf, 2 * 8 * 128 * 8 * sizeof(unsigned long long)); }

@@ -65,6 +65,16 @@ __device__ void mt_stream(uint32_t* mt, int& pos, int64_t count, Sink sink) {
     }
 }
 
+// step over n draws: twists only
+__device__ void mt_skip(uint32_t* mt, int& pos, int64_t n) {
+    while (n > 0) {
+        if (pos >= MT_N) { mt_twist(mt); pos = 0; }
+        const int64_t take = min((int64_t)(MT_N - pos), n);
+        pos += (int)take;
+        n -= take;
+    }
+}
+
 __global__ void mt_seed_kernel(MtState* st, uint32_t seed) {
     if (threadIdx.x == 0) {
         uint32_t x = seed;
@@ -93,6 +103,16 @@ __global__ __launch_bounds__(256) void mt_raw_kernel(MtState* st, uint32_t* out,
     store_state(st, mt, pos);
 }
 
+// fast-forward by n draws: only the twists, nothing tempered or stored (row-sharded ranks step over the draws that belong to
+// other ranks so that every rank stays on the ONE stream an unsharded run would consume)
+__global__ __launch_bounds__(256) void mt_skip_kernel(MtState* st, int64_t n) {
+    __shared__ uint32_t mt[MT_N];
+    int pos;
+    load_state(st, mt, pos);
+    mt_skip(mt, pos, n);
+    store_state(st, mt, pos);
+}
+
 __device__ __forceinline__ float u24(uint32_t w) { return (float)(w & 0xFFFFFFu) * 5.9604644775390625e-08f; }
 
 // Phase 1 of both samplers: one workgroup streams the h*P + h tempered words into the caller's
@@ -106,15 +126,23 @@ struct SamplerArgs {
     uint32_t* mask_bits;   // [n, Tw] or nullptr
     uint32_t* scratch;     // [h*P + h] u32
     int Tw;
+    // row-sharded call (ag_mask_shapley_new_rows): this rank's h rows are rows [h_lo, h_lo + h) of a call with h_total sampled
+    // rows; the draws of the other rows are stepped over so that the state advances by the FULL call (0 / h: unsharded)
+    int h_lo, h_total;
 };
 
 __global__ __launch_bounds__(256) void sampler_draw_kernel(SamplerArgs a) {
     __shared__ uint32_t mt[MT_N];
     int pos;
     load_state(a.st, mt, pos);
-    const int64_t total = (int64_t)a.h * a.P + a.h;
     uint32_t* sc = a.scratch;
-    mt_stream(mt, pos, total, [&](int64_t j, uint32_t w) { sc[j] = w; });
+    const int64_t own_u1 = (int64_t)a.h * a.P, after = a.h_total - a.h_lo - a.h;
+    // the reference draws U1[h_total, P] row-major first, then u2[h_total] (models/shapley.py:69,:133)
+    mt_skip(mt, pos, (int64_t)a.h_lo * a.P);
+    mt_stream(mt, pos, own_u1, [&](int64_t j, uint32_t w) { sc[j] = w; });
+    mt_skip(mt, pos, after * a.P + a.h_lo);
+    mt_stream(mt, pos, (int64_t)a.h, [&](int64_t j, uint32_t w) { sc[own_u1 + j] = w; });
+    mt_skip(mt, pos, after);
     store_state(a.st, mt, pos);
 }
 
@@ -236,10 +264,13 @@ extern "C" int ag_mt19937_raw(void* d_state, uint32_t* d_out, int64_t n, void* s
     return AG_OK;
 }
 
+extern "C" int ag_mt19937_skip(void* d_state, int64_t n, void* stream);
 static int run_sampler(void* d_state, int h, int P, int paired, const float* prefix, int64_t* mi, uint32_t* mb,
-                       uint32_t* scratch, void* stream) {
-    if (h == 0) return AG_OK;
+                       uint32_t* scratch, void* stream, int h_lo = 0, int h_total = -1) {
+    if (h_total < 0) h_total = h;
+    if (h == 0) return h_total > 0 ? ag_mt19937_skip(d_state, (int64_t)h_total * P + h_total, stream) : AG_OK;
     SamplerArgs a;
+    a.h_lo = h_lo; a.h_total = h_total;
     a.st = (MtState*)d_state; a.h = h; a.P = P; a.inv_p = (float)(1.0 / (double)P); a.paired = paired; a.prefix = prefix;
     a.mask_i64 = mi; a.mask_bits = mb; a.scratch = scratch; a.Tw = (P + 1 + 31) / 32;
     hipStream_t s = (hipStream_t)stream;
@@ -250,12 +281,33 @@ static int run_sampler(void* d_state, int h, int P, int paired, const float* pre
     return AG_OK;
 }
 
+extern "C" int ag_mt19937_skip(void* d_state, int64_t n, void* stream) {
+    AG_REQUIRE(d_state && n >= 0, "ag_mt19937_skip: bad arguments");
+    if (n == 0) return AG_OK;
+    hipLaunchKernelGGL(mt_skip_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (MtState*)d_state, n);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 extern "C" int ag_mask_shapley_new(void* d_state, int n_mask_samples, int n_players, const float* d_prefix,
                                    int64_t* d_mask_i64, uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream) {
     AG_REQUIRE(d_state && d_prefix && d_scratch, "ag_mask_shapley_new: null pointer");
     AG_REQUIRE(n_mask_samples >= 0 && n_mask_samples % 2 == 0, "ag_mask_shapley_new: n_mask_samples=%d must be even (reference models/shapley.py:62)", n_mask_samples);
     AG_REQUIRE(n_players >= 2, "ag_mask_shapley_new: n_players=%d", n_players);
     return run_sampler(d_state, n_mask_samples / 2, n_players, 1, d_prefix, d_mask_i64, d_mask_bits, d_scratch, stream);
+}
+
+extern "C" int ag_mask_shapley_new_rows(void* d_state, int n_mask_samples_total, int row_lo, int row_hi, int n_players,
+                                        const float* d_prefix, int64_t* d_mask_i64, uint32_t* d_mask_bits, uint32_t* d_scratch,
+                                        void* stream) {
+    AG_REQUIRE(d_state && d_prefix && d_scratch, "ag_mask_shapley_new_rows: null pointer");
+    AG_REQUIRE(n_mask_samples_total >= 0 && n_mask_samples_total % 2 == 0 && row_lo % 2 == 0 && row_hi % 2 == 0 &&
+               0 <= row_lo && row_lo <= row_hi && row_hi <= n_mask_samples_total,
+               "ag_mask_shapley_new_rows: rows [%d, %d) of %d must be even-aligned (paired rows 2i / 2i+1 stay together)",
+               row_lo, row_hi, n_mask_samples_total);
+    AG_REQUIRE(n_players >= 2, "ag_mask_shapley_new_rows: n_players=%d", n_players);
+    return run_sampler(d_state, (row_hi - row_lo) / 2, n_players, 1, d_prefix, d_mask_i64, d_mask_bits, d_scratch, stream,
+                       row_lo / 2, n_mask_samples_total / 2);
 }
 
 extern "C" int ag_mask_purely_uniform(void* d_state, int batch, int n_players, int64_t* d_mask_i64,

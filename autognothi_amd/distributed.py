@@ -133,6 +133,98 @@ def allreduce_grads(params: Iterable[Tensor], average: bool = True, bucket_bytes
     return calls
 
 
+class GradBucketReducer:
+    """Gradient exchange of explainer / surrogate training, overlapped with the backward pass.
+
+    The manual backward of ``autognothi_amd/training.py`` walks the graph from the head down and reports every parameter
+    whose gradient is final (``ready(p)``: the trainers call it through ``training.GRAD_SINK``).  Ready gradients are packed
+    into a flat bucket; as soon as a bucket holds ``bucket_bytes`` it is summed over the ranks with an ASYNCHRONOUS
+    all-reduce — RCCL runs it on its own stream, over all seven xGMI links of the GPU, while the backward kernels of the
+    layers below keep the compute stream busy — and ``finish()`` (before ``optimizer.step()``) flushes the tail bucket,
+    waits for the collectives in issue order, averages and scatters the results back into ``.grad``.
+    Bucket size: xGMI is point-to-point, a ring step is per-link bound, so buckets are large (default 64 MiB: the vanilla
+    ViT-base explainer's 419 MB of fp32 gradients are 7 collectives, the first one in flight after the head + 2 layers).
+    Every parameter must be reported at most once per step; ``finish()`` also reduces trainable parameters that were never
+    reported but hold a gradient (callers that do not instrument their backward lose the overlap, not the result)."""
+
+    def __init__(self, params: Iterable[Tensor], bucket_bytes: int = 64 << 20, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket_bytes, self.average = int(bucket_bytes), average
+        self._pending: List[Tensor] = []
+        self._pending_bytes = 0
+        self._inflight: List[Tuple[object, Tensor, List[Tensor]]] = []
+        self._seen = set()
+        self.collectives = 0
+
+    def ready(self, p: Tensor) -> None:
+        _, w = world()
+        if w == 1 or p.grad is None:
+            return
+        if id(p) in self._seen:
+            raise RuntimeError("GradBucketReducer.ready: a parameter was reported twice in one step")
+        self._seen.add(id(p))
+        if self._pending and self._pending[0].grad.dtype != p.grad.dtype:
+            self._flush()
+        self._pending.append(p)
+        self._pending_bytes += p.grad.numel() * p.grad.element_size()
+        if self._pending_bytes >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self) -> None:
+        if not self._pending:
+            return
+        ps = self._pending
+        flat = torch.cat([q.grad.reshape(-1) for q in ps])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._inflight.append((work, flat, ps))
+        self._pending, self._pending_bytes = [], 0
+        self.collectives += 1
+
+    def finish(self) -> int:
+        """-> number of collectives of this step."""
+        _, w = world()
+        if w > 1:
+            for p in self.params:                 # gradients nobody reported (un-instrumented backward)
+                if p.grad is not None and id(p) not in self._seen:
+                    self.ready(p)
+            self._flush()
+            for work, flat, ps in self._inflight:
+                work.wait()
+                if self.average:
+                    flat /= w
+                off = 0
+                for q in ps:
+                    n = q.grad.numel()
+                    q.grad.copy_(flat[off:off + n].view_as(q.grad))
+                    off += n
+        n_coll = self.collectives
+        self._inflight, self._seen, self.collectives = [], set(), 0
+        return n_coll
+
+
+class ShardedMaskStream:
+    """The ONE mask stream of the unsharded loop, consumed by row-sharded ranks without any traffic: every rank seeds the same
+    device generator; per step each rank asks for ITS rows of the global call ``mask_shapley_new(n_inputs_total * k, P)``
+    (ag_mask_shapley_new_rows: the other ranks' draws are stepped over, twists only, and the state advances by the whole
+    call).  The union of the ranks' masks — and everything derived from them — is bit-identical to a single-process run on
+    the concatenated batch (row order ``[b0 s0, b0 s1, b1 s0, ...]``, models/shapley.py:24; k is even, so a complementary
+    row pair never straddles two inputs)."""
+
+    def __init__(self, device: torch.device, seed: int):
+        from . import ops
+        self.ops = ops
+        self.rng = ops.DeviceMT19937(device, seed)
+
+    def seed(self, seed: int) -> "ShardedMaskStream":
+        self.rng.seed(seed)
+        return self
+
+    def sample(self, n_inputs_total: int, lo: int, hi: int, k: int, n_players: int, want_i64: bool = False):
+        """-> (int64 masks or None, key bits) of inputs [lo, hi) out of the n_inputs_total inputs of this step."""
+        return self.ops.mask_shapley_new_rows(self.rng, n_inputs_total * k, lo * k, hi * k, n_players, want_i64=want_i64,
+                                              want_bits=True)
+
+
 def reduce_scalars(values: Sequence[float], device: torch.device) -> List[float]:
     r, w = world()
     if w == 1:

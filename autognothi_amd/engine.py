@@ -17,7 +17,24 @@ from . import ops
 
 _PRECISION = {"dtype": L.AG_BF16}
 PRUNE_BERT_TOKENS = os.environ.get("AG_BERT_PRUNE", "1") != "0"  # BERT cls-only forwards skip additively masked tokens after layer 0
-LAST_PACKED_ROWS = 0   # visible tokens of the last pruned forward (bench.py: executed-work accounting)
+_PACKED_ROWS = {}      # device -> int32 [1]: visible tokens of the last pruned forward (stays on the device: no host read per step)
+
+
+def last_packed_rows(device=None) -> int:
+    """visible tokens of the last token-pruned BERT forward on `device` (bench.py: executed-work accounting).  Synchronises:
+    call it outside timed regions."""
+    if not _PACKED_ROWS:
+        return 0
+    key = str(device) if device is not None else next(iter(_PACKED_ROWS))
+    t = _PACKED_ROWS.get(key)
+    if t is None:
+        return 0
+    return int(t) if isinstance(t, int) else int(t.item())
+
+
+def note_packed_rows(device, n: int) -> None:
+    """(paths that already hold the packed row count on the host: the LTT-BERT ladder driver)"""
+    _PACKED_ROWS[str(device)] = int(n)
 FOLD_LAYERNORM = os.environ.get("AG_LN_FOLD", "1") != "0"  # bf16 ViT: fold LayerNorm into the consuming GEMM epilogue
 
 
@@ -179,11 +196,11 @@ class PackedEncoder:
             need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
             ws = WORKSPACE.get(h0.device, need)
             if self.kind == L.AG_MASK_BERT_ADD and cls_only_last and len(self.layers) >= 2 and PRUNE_BERT_TOKENS:
-                global LAST_PACKED_ROWS
-                n_packed = C.c_int32(0)
+                key = str(h0.device)
+                if not isinstance(_PACKED_ROWS.get(key), torch.Tensor):
+                    _PACKED_ROWS[key] = torch.zeros(1, dtype=torch.int32, device=h0.device)
                 L.check(L.lib().ag_bert_encoder_forward_pruned(C.byref(d), L.ptr(h0), rows, share, L.ptr(mask_bits), L.ptr(out),
-                                                               L.ptr(ws), ws.numel(), C.byref(n_packed), L.stream()))
-                LAST_PACKED_ROWS = int(n_packed.value)
+                                                               L.ptr(ws), ws.numel(), L.ptr(_PACKED_ROWS[key]), L.stream()))
                 return out
             if chain is not None:
                 st, st_in, st_out = chain
@@ -256,3 +273,34 @@ def to_mask_bits(attention_mask: Tensor, n_players: int) -> Tensor:
 def linear_head(x_rows: Tensor, lda: int, m: int, lin: PackedLinear, epilogue: int, dtype: int) -> Tensor:
     w, b = lin.get(dtype)
     return ops.gemm(x_rows, w, b, epilogue, dtype, m=m, lda=lda)
+
+
+class GraphedStep:
+    """One step of the hot path as a hipGraph: ``fn`` (no arguments; reads static device tensors, e.g. the resident inputs,
+    and returns device tensors) is captured once and replayed with a single ``hipGraphLaunch``.
+
+    At the reference's operating point (2-4 inputs x K=32 masks per GPU, experiments/*/.hparams.json) a forward is ~170 kernel
+    launches of a few microseconds each: host launch overhead, not the GPU, sets the pace.  Everything in the step is
+    capture-safe by construction: the mask sampler's generator state lives in HBM (each replay advances it exactly as an eager
+    call would), the encoder is one C call with no allocation or synchronisation, LayerNorm-fold statistics need no zero fill.
+    Capture goes through torch.cuda.CUDAGraph (= hipStreamBeginCapture / hipGraphInstantiate on the launch stream) so that
+    the tensors ``fn`` allocates come from a pool owned by the graph and stay valid across replays.
+    The token-pruned BERT forward is capturable too: its data-dependent packed row count stays on the device
+    (ag_dynamic_rows).  Not capturable: host reads (``.item()``), in-library event timing (ag_profile_enable)."""
+
+    def __init__(self, fn, warmup: int = 2):
+        self.fn = fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # weight packing, workspace growth, lazy kernel attributes: all before capture
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out

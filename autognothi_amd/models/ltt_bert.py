@@ -205,7 +205,7 @@ class LttBertModel(nn.Module):
                 w, bias = self._maps[key].get(dtype)
                 s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1)
                 side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype)
-        engine.LAST_PACKED_ROWS = n
+        engine.note_packed_rows(hidden.device, n)
         h_cls = ops.gather_rows(hidden, cu, rows, dtype).view(rows, 1, c.hidden_size)
         s_cls = [ops.gather_rows(side[i_b], cu, rows, dtype).view(rows, 1, c.s_attn_hidden_size) for i_b in branches]
         return h_cls, s_cls, rows

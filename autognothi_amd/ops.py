@@ -80,6 +80,13 @@ class DeviceMT19937:
         st = fill_torch_cpu_state(gen.get_state() if gen is not None else torch.get_rng_state(), mt, pos.value)
         (gen.set_state(st) if gen is not None else torch.set_rng_state(st))
 
+    def skip(self, n: int) -> "DeviceMT19937":
+        """advance by n draws without producing them."""
+        if n > 0:
+            with L.on(self.device):
+                L.check(L.lib().ag_mt19937_skip(L.ptr(self.state), int(n), L.stream()))
+        return self
+
     def raw(self, n: int) -> Tensor:
         out = torch.empty(n, dtype=torch.int32, device=self.device)
         with L.on(self.device):
@@ -118,6 +125,22 @@ def mask_shapley_new(rng: DeviceMT19937, n_mask_samples: int, n_players: int, wa
     with L.on(dev):
         L.check(L.lib().ag_mask_shapley_new(L.ptr(rng.state), n_mask_samples, n_players, L.ptr(prefix),
                                             L.ptr(mi), L.ptr(mb), L.ptr(scratch), L.stream()))
+    return mi, mb
+
+
+def mask_shapley_new_rows(rng: DeviceMT19937, n_mask_samples_total: int, row_lo: int, row_hi: int, n_players: int,
+                          want_i64: bool = True, want_bits: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """rows [row_lo, row_hi) of ``mask_shapley_new(n_mask_samples_total, n_players)``; the generator advances by the whole
+    call (row-sharded ranks: autognothi_amd.distributed.ShardedMaskStream)."""
+    dev = rng.device
+    prefix = shapley_prefix_table(n_players, dev)
+    n = row_hi - row_lo
+    mi = torch.empty((n, n_players), dtype=torch.int64, device=dev) if want_i64 else None
+    mb = torch.empty((n, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
+    scratch = torch.empty(max(1, n // 2 * (n_players + 1)), dtype=torch.int32, device=dev)
+    with L.on(dev):
+        L.check(L.lib().ag_mask_shapley_new_rows(L.ptr(rng.state), n_mask_samples_total, row_lo, row_hi, n_players, L.ptr(prefix),
+                                                 L.ptr(mi), L.ptr(mb), L.ptr(scratch), L.stream()))
     return mi, mb
 
 

@@ -82,23 +82,35 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
     from ..training import make_explainer_trainer
     env = env or Log()
     rng = device_rng(m_surrogate, device, seed)
+    from .. import training as _training
     trainer = m_explainer.__dict__.get("_ag_trainer") or make_explainer_trainer(m_recipe, m_explainer)
     m_explainer.__dict__["_ag_trainer"] = trainer
-    reg_loss, total = 0.0, 0
+    total = 0
+    losses = []                                   # device scalars: read back ONCE per epoch (no per-step host sync)
     m_explainer.train()
+    # N > 1 ranks (rows sharded by input): gradients are averaged over RCCL in 64 MiB buckets whose all-reduce starts as soon
+    # as the backward has finished them (distributed.GradBucketReducer); a no-op at N = 1
+    _, n_ranks = distributed.world()
+    reducer = distributed.GradBucketReducer(m_explainer.parameters()) if n_ranks > 1 else None
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, zs = gen_input(_inputs, _targets)
         optimizer.zero_grad()
         bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
-        loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
-                                            seed=(seed or 0) + epoch)
-        # N>1 ranks (rows sharded by input): average gradients over RCCL in a few large buckets (no-op at N=1)
-        distributed.allreduce_grads([p for p in m_explainer.parameters() if p.requires_grad], average=True)
+        _training.GRAD_SINK = reducer.ready if reducer is not None else None
+        try:
+            loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
+                                                seed=(seed or 0) + epoch)
+        finally:
+            _training.GRAD_SINK = None
+        if reducer is not None:
+            reducer.finish()
         optimizer.step()
-        lv = float(loss.item())
-        reg_loss += lv
+        losses.append(loss.reshape(()))
         total += xs.shape[0]
-        env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
+        if getattr(env, "log_every_step", False):  # the reference logs the loss of every batch (a host read per step)
+            env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {float(loss.item()) / xs.shape[0]:.6f}, fin {total}")
+    reg_loss = float(torch.stack(losses).sum().item()) if losses else 0.0
+    env.log(f"  > epoch {epoch} :train // loss: shap {reg_loss / max(total, 1):.6f}, fin {total}")
     return reg_loss / max(total, 1)
 
 

@@ -53,11 +53,14 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
     from ..training import make_surrogate_trainer
     env = env or Log()
     rng = device_rng(m_surrogate, device, seed)
+    from .. import training as _training
     trainer = m_surrogate.__dict__.get("_ag_trainer") or make_surrogate_trainer(m_recipe, m_surrogate)
     m_surrogate.__dict__["_ag_trainer"] = trainer
     m_classifier.eval()
     m_surrogate.train()
     tot, n = 0.0, 0
+    _, n_ranks = distributed.world()
+    reducer = distributed.GradBucketReducer(m_surrogate.parameters()) if n_ranks > 1 else None
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, _ = gen_input(_inputs, _targets)
         b = xs.shape[0]
@@ -66,8 +69,13 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
         ones = torch.ones((b, n_players), dtype=torch.long, device=xs.device)
         with torch.no_grad():
             _, orig = m_recipe.fw_classifier(m_classifier, xs, ones)   # second output (reference :141)
-        loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
-        distributed.allreduce_grads([p for p in m_surrogate.parameters() if p.requires_grad], average=True)
+        _training.GRAD_SINK = reducer.ready if reducer is not None else None
+        try:
+            loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
+        finally:
+            _training.GRAD_SINK = None
+        if reducer is not None:
+            reducer.finish()     # bucketed all-reduces overlapped with the backward (distributed.GradBucketReducer)
         optimizer.step()
         tot += float(loss.item()) * b
         n += b

@@ -42,6 +42,19 @@ def _mm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: int, w_b
     return ops.gemm(a, w, bias, epilogue, F32, m=m)
 
 
+# Called with every parameter whose gradient of the current step is final (each parameter receives exactly one contribution
+# per step): distributed.GradBucketReducer.ready during N-rank training, so that a bucket's all-reduce starts while the
+# backward of the layers below is still running.  None: nothing to tell.
+GRAD_SINK: Optional[Callable[[Tensor], None]] = None
+
+
+def _final(*params: Tensor) -> None:
+    if GRAD_SINK is not None:
+        for p in params:
+            if p.requires_grad:
+                GRAD_SINK(p)
+
+
 def _grad(p: Tensor) -> Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p, dtype=torch.float32)
@@ -57,6 +70,7 @@ def _acc_grad(p: Tensor, src: Tensor, fresh: bool = False) -> None:
         p.grad = src if (fresh and src.is_contiguous()) else src.clone(memory_format=torch.contiguous_format)
     else:
         _acc(p.grad, src)
+    _final(p)
 
 
 def _acc(dst: Tensor, src: Tensor) -> None:
@@ -199,6 +213,8 @@ class Norm:
         dx = ops.layernorm_bwd(self.x, self.mod.weight.detach().float(), dy, self.eps,
                                _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=not fresh)
         self.x = None
+        if train:
+            _final(self.mod.weight, self.mod.bias)
         return dx
 
 
@@ -391,9 +407,11 @@ class BertBackboneTrainer:
         if e.position_embeddings.weight.requires_grad:
             g = _grad(e.position_embeddings.weight)
             _acc(g[:t], ops.colsum(d.view(b, t * h)).view(t, h))
+            _final(e.position_embeddings.weight)
         if e.token_type_embeddings.weight.requires_grad:
             g = _grad(e.token_type_embeddings.weight)
             _acc(g[0], ops.colsum(d))
+            _final(e.token_type_embeddings.weight)
         if e.word_embeddings.weight.requires_grad:
             # scatter-add of B*T rows into the vocabulary table: index plumbing (torch), no arithmetic beyond the adds.
             # nn.Embedding(padding_idx=pad_token_id) (reference models/vanilla_bert.py:288-290): autograd never gives the
@@ -403,6 +421,7 @@ class BertBackboneTrainer:
             if pad is not None:
                 d = d.masked_fill((flat == pad).unsqueeze(1), 0.0)
             _grad(e.word_embeddings.weight).index_add_(0, flat, d)
+            _final(e.word_embeddings.weight)
         self.saved = None
 
 

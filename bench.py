@@ -6,19 +6,24 @@ A "step" = one pass of the hot path over one batch of synthetic inputs resident 
   B*K rows (K masks share each input's embeddings / layer-0 LN+QKV) -> v_s [B*K, C] on device.
 Workload (config.workload) = BASELINE.json configs[1]: vit_base_imagenette_vanilla, K=32, bf16.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload vit_base|bert_base|vit_large|vit_tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload vit_base|bert_base|vit_large|vit_tiny|...]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  (a bare `python bench.py --gpus N` with N > 1 starts that launcher itself, as a child, before anything touches a GPU)
 
-Multi-GPU: rows shard by image (each rank owns B images x all K masks; weights replicated; masks
-come from per-rank device generators) — no data-path collective, weak scaling.  Rank 0 prints ONE
-JSON line.  `roofline` is measured live with hipEvents around every launch of the dominant kernel
-inside the timed region; `cpu_baseline` times the torch-CPU port of the reference path (oracle/torch_port.py)
-on a bounded sample on the host cores (rank 0, N=1).
+Multi-GPU: rows shard by input (each rank owns B inputs x all K masks; weights replicated; every rank runs the SAME device
+mask generator and takes its rows of the global call, distributed.ShardedMaskStream) — no data-path collective, weak
+scaling.  Rank 0 prints ONE JSON line.  `roofline` is measured live with hipEvents around every launch of the dominant
+kernel inside the timed region; `cpu_baseline` times the torch-CPU port of the reference path (oracle/torch_port.py) on a
+bounded sample on the host cores (rank 0, N=1).  `secondary` carries the other modes the criteria live in: the small-batch
+sweep (eager and hipGraph replay), fp32 parity mode, Shapley attributions/s, the explainer training step with its own
+roofline block, BASELINE config 5's recipes, and BERT with token pruning off next to on.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -62,6 +67,14 @@ WORKLOADS["ltt_vit_base"] = ("ltt_vit", dict({k: v for k, v in WORKLOADS["vit_ba
                                               explainer_normalize=True, **_LTT), 32)
 WORKLOADS["ltt_bert_base"] = ("ltt_bert", dict({k: v for k, v in WORKLOADS["bert_base"][1].items() if not k.startswith("explainer_")},
                                                 explainer_normalize=True, **_LTT), 32)
+# BASELINE config 5's recipes (same backbones; what differs is the training step: duo = one backbone for both objectives
+# + a cross-entropy term, froyo = frozen shared backbone, explainer head only)
+WORKLOADS["duo_bert_base"] = ("duo_vanilla_bert", WORKLOADS["bert_base"][1], 32)
+WORKLOADS["froyo_vit_base"] = ("froyo_vit", WORKLOADS["vit_base"][1], 32)
+WORKLOAD_LABEL = {"vit_base": "vit_base_imagenette_vanilla", "vit_large": "vit_large_imagenette_vanilla",
+                  "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128",
+                  "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128",
+                  "duo_bert_base": "bert_base_tayp_duo_vanilla seq_len=128", "froyo_vit_base": "vit_base_imagenette froyo"}
 
 EPI_NAMES = {0: "gemm<bias>", 1: "gemm<bias+gelu>", 2: "gemm<bias+residual>", 3: "gemm<bias,f32out>", 4: "gemm<bias+tanh>",
              5: "gemm<bias+gelu+add>", 8: "masked_attention", 9: "layernorm"}
@@ -87,7 +100,7 @@ def flops_executed(kind, p, T, K, frac=1.0):
     last layer's Q-projection/attention/out-proj/MLP on the CLS token only; BERT token pruning (frac = visible
     tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
     H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
-    if kind == "vanilla_bert" and frac < 1.0 and Lr >= 2:
+    if kind in ("vanilla_bert", "duo_vanilla_bert") and frac < 1.0 and Lr >= 2:
         layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
         f = layer - 6 * T * H * H * (K - 1) / K                                   # layer 0: every token, shared QKV
         f += (Lr - 2) * (frac * (8 * T * H * H + 4 * T * H * I) + frac * frac * 4 * T * T * H)
@@ -118,31 +131,57 @@ def collect(cls):
     return ms.value, fl.value, by.value, n.value
 
 
+def kernel_source_sha16():
+    """identity of the kernel build: hash of every source the shared library is built from (a rocprof counter file is only
+    quoted next to numbers of the same kernels)."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "autognothi_amd", "csrc")
+    for name in sorted(os.listdir(src)) + ["../../include/autognothi_hip.h"]:
+        if name.endswith((".hip", ".cpp", ".h", ".sh")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def explainer_flops_per_image(kind, p, T):
+    """GEMM flops of one explainer FORWARD per image (all-ones mask): backbone + explainer_attn layer(s) + MLP head
+    (+ the duo head); SURVEY §8d: 42.7 GFLOP for vanilla ViT-base."""
+    H, I, C_ = p["hidden_size"], p["intermediate_size"], p["num_labels"]
+    hh = p["explainer_head_hidden_size"]
+    layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
+    f = p["num_hidden_layers"] * layer + p["explainer_attn_num_layers"] * layer + 2 * T * (H * hh + hh * hh + hh * C_)
+    if kind.endswith("vit"):
+        f += 2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H
+    return float(f), float(p["num_hidden_layers"] * layer)
+
+
 def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
-    """The torch-CPU port of the reference path (oracle/torch_port.py, fp32, all host cores) timed over a
-    bounded sample of the same workload, the K masked copies materialised as the reference does
-    (scripts/train_explainer.py:159-163)."""
+    """The torch-CPU port of the reference path (oracle/torch_port.py, fp32) timed over a bounded sample of the same
+    workload, the K masked copies materialised as the reference does (scripts/train_explainer.py:159-163).  A 100+-core
+    host oversubscribes these medium-sized GEMMs, so a few thread counts up to ALL logical CPUs are timed (best of 2 each
+    after a warm-up) and the fastest is reported together with the count that produced it."""
     from oracle import torch_port as otp
     if kind.startswith("ltt_"):
         def fn(x, m, sd_, prm):
             with torch.no_grad():
                 return otp.ltt_surrogate_probs(x, m, sd_, prm, "vit" if kind.endswith("vit") else "bert")
     else:
-        fn = otp.vit_surrogate if kind == "vanilla_vit" else otp.bert_surrogate
+        fn = otp.vit_surrogate if kind.endswith("vit") else otp.bert_surrogate
     rows = masks_np.shape[0]
     xs_ext = torch.from_numpy(np.repeat(xs_np, rows // xs_np.shape[0], axis=0))
     masks = torch.from_numpy(masks_np)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
-    # a 100+-core host oversubscribes these medium-sized GEMMs: time a few thread counts, report the best
     best, best_threads, reps_total = float("inf"), torch.get_num_threads(), 0
     t0 = time.perf_counter()
     ncpu = os.cpu_count() or 8
     prev = torch.get_num_threads()
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
-        if time.perf_counter() - t0 > 22.0:
+    tried = []
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64, ncpu)}):
+        if time.perf_counter() - t0 > 24.0:
             break
         torch.set_num_threads(nt)
         fn(xs_ext, masks, sd, params)  # warm-up (thread pool, page-in)
+        tried.append(nt)
         for _ in range(2):
             t1 = time.perf_counter()
             fn(xs_ext, masks, sd, params)
@@ -151,7 +190,134 @@ def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
             if dt < best:
                 best, best_threads = dt, nt
     torch.set_num_threads(prev)
-    return rows / best, rows, reps_total, best_threads
+    return rows / best, rows, reps_total, best_threads, tried
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the one-process-per-GPU job as a CHILD — before this
+    process has made any GPU call (never an exec after one) — and leave with its exit code."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Job:
+    """one workload on this rank: model, resident inputs, mask stream, the step."""
+
+    def __init__(self, workload, dev, rank, world, batch, masks=0, precision="bf16"):
+        self.kind, self.params, k_default = WORKLOADS[workload]
+        self.workload, self.dev, self.rank, self.world = workload, dev, rank, world
+        self.K = masks or k_default
+        self.B = batch
+        self.recipe = get_recipe(self.kind)
+        self.cfg = self.recipe.t_config(**self.params)
+        self.P = self.recipe.n_players(self.cfg)
+        self.T = self.P + 1
+        self.precision = precision
+        self.surrogate = self.recipe.t_surrogate(self.cfg)
+        synth.load_synth_weights(self.surrogate, seed=0)   # random-init weights of the named architecture (no network)
+        self.surrogate = self.surrogate.to(dev).eval()
+        self.vit = self.kind.endswith("vit")
+        from autognothi_amd.distributed import ShardedMaskStream
+        self.stream = ShardedMaskStream(dev, 3407)          # the same generator on every rank
+        self.set_batch(batch)
+
+    def inputs(self, n, seed):
+        p = self.params
+        if self.vit:
+            return synth.synth_images(n, p["img_px_size"], p["img_channels"], seed=seed)
+        return synth.synth_token_ids(n, p["max_position_embeddings"], p["vocab_size"], seed=seed)
+
+    def set_batch(self, batch):
+        self.B = batch
+        self.xs_np = self.inputs(batch, self.rank)
+        self.xs = torch.from_numpy(self.xs_np).to(self.dev)
+        self.R = batch * self.K
+
+    def step(self):
+        """device sampler (this rank's rows of the global mask_shapley_new call) -> K-mask surrogate forward -> v_s"""
+        lo = self.rank * self.B
+        _, bits = self.stream.sample(self.world * self.B, lo, lo + self.B, self.K, self.P)
+        with torch.no_grad():
+            v_s, _ = self.recipe.fw_surrogate(self.surrogate, self.xs, bits)
+        return v_s
+
+
+def timed(fn, steps, warmup, dist, dev):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed, out
+
+
+def train_step_rate(job, dist, n_train, tb, precision):
+    """One reference _explainer_epoch_train body per step (scripts/train_explainer.py:128-207) = K-mask surrogate targets
+    (inference path) + the all-ones grand forward + explainer forward/backward + AdamW.  -> (images/s, flops per step)."""
+    from autognothi_amd import training as _tr
+    from autognothi_amd.scripts import train_explainer as te
+    _tr.MIXED_BF16 = precision == "bf16"   # throughput mode: bf16 GEMM operands (autocast semantics), fp32 everything else
+    recipe, cfg, dev = job.recipe, job.cfg, job.dev
+    m_exp = recipe.t_explainer(cfg)
+    synth.load_synth_weights(m_exp, seed=1)
+    m_exp = m_exp.to(dev)
+    m_exp.train()
+    tx = torch.from_numpy(job.inputs(tb, 200 + job.rank)).to(dev)
+    labels = torch.zeros(tb, dtype=torch.long, device=dev)
+    opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5)
+    v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
+    gen = lambda a, b_: (tx, labels)  # noqa: E731
+    te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * 2, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    tt = time.perf_counter()
+    te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * n_train, recipe, job.surrogate, m_exp, opt, 2, gen, seed=7)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - tt
+    if dist is not None:
+        tm = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        el = float(tm.item())
+    frozen_backbone = not any(q.requires_grad for n_, q in m_exp.named_parameters() if n_.startswith(("vit.", "bert.")))
+    f_exp, f_bb = explainer_flops_per_image(job.kind, job.params, job.T)
+    frac = 1.0
+    if job.kind in ("vanilla_bert", "duo_vanilla_bert"):
+        pr = engine.last_packed_rows(dev)
+        frac = pr / float(tb * job.K * job.T) if pr else 1.0
+    f_targets = tb * job.K * flops_executed(job.kind if job.kind in ("vanilla_vit", "vanilla_bert") else
+                                            ("vanilla_vit" if job.vit else "vanilla_bert"), job.params, job.T, job.K, frac)
+    f_grand = tb * flops_executed("vanilla_vit" if job.vit else "vanilla_bert", job.params, job.T, 1, 1.0)
+    # backward = 2x forward for every trained GEMM; a frozen backbone is forwarded only (no dX below the head either)
+    f_train = tb * (f_exp + 2.0 * (f_exp - (f_bb if frozen_backbone else 0.0)))
+    surrogate_was = job.surrogate.training
+    job.surrogate.eval()
+    del m_exp, opt
+    _tr.MIXED_BF16 = False
+    return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
 def main():
@@ -170,15 +336,15 @@ def main():
     # 220 images x 197 tokens = 170 M-tiles: 510 / 1530 / 2040 tiles for N = 768 / 2304 / 3072 = 1.99 / 5.98 / 7.97 rounds of 256 CUs
     # (128 images leave 42 % of the second round of the N = 768 GEMMs idle: 6.3 k -> 7.6 k attributions/s)
     ap.add_argument("--attr-batch", type=int, default=220, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="the timed hot path only (profiling runs)")
+    ap.add_argument("--graph", action="store_true", help="replay the timed step from a hipGraph (no in-library kernel timing then)")
     args = ap.parse_args()
+    maybe_spawn(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run --nproc-per-node N (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -186,40 +352,25 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    if args.no_secondary:
+        args.attr_batch = args.train_batch = 0
 
-    kind, params, k_default = WORKLOADS[args.workload]
-    K = args.masks or k_default
-    B = args.batch
-    recipe = get_recipe(kind)
-    cfg = recipe.t_config(**params)
-    P = recipe.n_players(cfg)
-    T = P + 1
     engine.set_precision(args.precision)
+    job = Job(args.workload, dev, rank, world, args.batch, args.masks, args.precision)
+    kind, params, K, B, P, T, R = job.kind, job.params, job.K, job.B, job.P, job.T, job.R
+    recipe, cfg, surrogate = job.recipe, job.cfg, job.surrogate
 
-    surrogate = recipe.t_surrogate(cfg)
-    synth.load_synth_weights(surrogate, seed=0)   # random-init weights of the named architecture (no network)
-    surrogate = surrogate.to(dev).eval()
-    if kind.endswith("vit"):
-        xs_np = synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=rank)
-    else:
-        xs_np = synth.synth_token_ids(B, params["max_position_embeddings"], params["vocab_size"], seed=rank)
-    xs = torch.from_numpy(xs_np).to(dev)
-    rng = ops.DeviceMT19937(dev, 3407 + rank)
-    R = B * K
-
-    def step():
-        _, bits = ops.mask_shapley_new(rng, R, P, want_i64=False, want_bits=True)
-        with torch.no_grad():
-            v_s, _ = recipe.fw_surrogate(surrogate, xs, bits)
-        return v_s
-
+    step = job.step
+    if args.graph:
+        step = engine.GraphedStep(job.step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    L.check(L.lib().ag_profile_enable(1))
+    if not args.graph:
+        L.check(L.lib().ag_profile_enable(1))
     for c in EPI_NAMES:
         collect(c)
     t0 = time.perf_counter()
@@ -238,7 +389,51 @@ def main():
     assert bool(torch.isfinite(out).all())
 
     stats = {c: collect(c) for c in EPI_NAMES}
-    packed_rows = engine.LAST_PACKED_ROWS   # (BERT token pruning) visible tokens of the last timed step
+    packed_rows = engine.last_packed_rows(dev)   # (BERT token pruning) visible tokens of the last timed step, read after the timed region
+    secondary = {}
+
+    # ---- SURVEY C2 sweep: the reference's own operating point is 2-4 inputs x K masks per GPU (experiments/*/.hparams.json):
+    # eager launches vs one hipGraph replay per step
+    if not args.no_secondary and args.precision == "bf16":
+        sweep = []
+        for b_s in (1, 4, 16, 48):
+            job.set_batch(b_s)
+            n_s = 30 if b_s <= 4 else 10
+            el_e, _ = timed(job.step, n_s, 3, dist, dev)
+            gstep = engine.GraphedStep(job.step)
+            el_g, _ = timed(gstep, n_s, 2, dist, dev)
+            del gstep
+            sweep.append({"inputs_per_gpu": b_s, "rows_per_gpu": b_s * K, "eager_fwd_per_s": round(b_s * K * world * n_s / el_e, 1),
+                          "graph_fwd_per_s": round(b_s * K * world * n_s / el_g, 1)})
+        job.set_batch(B)
+        secondary["small_batch_sweep"] = {"unit": "masked-forwards/s", "what": "same step at other per-GPU batches; graph = engine.GraphedStep "
+                                          "(one hipGraphLaunch per step: sampler + forward)", "points": sweep}
+
+    # ---- fp32 parity mode (exact-fp32 MFMA): the mode the 1e-4 Shapley criterion is checked in
+    if not args.no_secondary and args.precision == "bf16":
+        engine.set_precision("fp32")
+        job.set_batch(8)
+        el32, _ = timed(job.step, 3, 1, dist, dev)
+        fps32 = 8 * K * world * 3 / el32
+        f_exec32 = flops_executed(kind if kind in ("vanilla_vit", "vanilla_bert") else kind, params, T, K, 1.0)
+        secondary["fp32_parity_mode"] = {"value": round(fps32, 1), "unit": "masked-forwards/s", "inputs_per_gpu": 8, "dtype": "f32",
+                                         "exec_tflops": round(fps32 / world * f_exec32 / 1e12, 1), "peak": PEAK_F32_TFLOPS,
+                                         "exec_frac_of_peak": round(fps32 / world * f_exec32 / 1e12 / PEAK_F32_TFLOPS, 4),
+                                         "note": "v_mfma_f32_16x16x4_f32 (exact fp32 fma chain); token pruning is exact and stays on for BERT"}
+        engine.set_precision(args.precision)
+        job.set_batch(B)
+
+    # ---- BERT: token pruning off next to on (same kernels, every token kept)
+    if not args.no_secondary and kind == "vanilla_bert":
+        keep = engine.PRUNE_BERT_TOKENS
+        engine.PRUNE_BERT_TOKENS = False
+        el_np, _ = timed(job.step, max(3, args.steps // 2), 2, dist, dev)
+        engine.PRUNE_BERT_TOKENS = keep
+        n_np = max(3, args.steps // 2)
+        v_np = R * world * n_np / el_np
+        f_np = flops_executed(kind, params, T, K, 1.0)
+        secondary["token_pruning_off"] = {"value": round(v_np, 1), "unit": "masked-forwards/s", "exec_tflops": round(v_np / world * f_np / 1e12, 1),
+                                          "exec_frac_of_peak": round(v_np / world * f_np / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +
     # surrogate + explainer forwards on all-ones masks -> phi [B, C, P]); untimed by the contract's K steps.
@@ -247,11 +442,7 @@ def main():
         final = recipe.t_final(cfg)
         synth.load_synth_weights(final, seed=1)
         final = final.to(dev).eval()
-        if kind.endswith("vit"):
-            fx_np = synth.synth_images(args.attr_batch, params["img_px_size"], params["img_channels"], seed=100 + rank)
-        else:
-            fx_np = synth.synth_token_ids(args.attr_batch, params["max_position_embeddings"], params["vocab_size"], seed=100 + rank)
-        fx = torch.from_numpy(fx_np).to(dev)
+        fx = torch.from_numpy(job.inputs(args.attr_batch, 100 + rank)).to(dev)
         with torch.no_grad():
             for _ in range(2):
                 _, phi = recipe.fw_final(final, fx)
@@ -274,111 +465,108 @@ def main():
         attrs_per_s = args.attr_batch * world * n_attr / el
         del final, fx, phi
 
-    # ---- training-step rate (SURVEY §8d metric 2): one reference _explainer_epoch_train body per step = K-mask
-    # surrogate targets (bf16 inference path) + explainer forward/backward (fp32 training kernels) + AdamW step
-    train_imgs_per_s = None
+    # ---- training-step rate (SURVEY §8d metric 2) with its own roofline block
+    train_block = None
+    c5 = {}
     if args.train_batch > 0:
-        from autognothi_amd import training as _tr
-        from autognothi_amd.scripts import train_explainer as te
-        _tr.MIXED_BF16 = args.precision == "bf16"   # throughput mode: bf16 GEMM operands (autocast semantics), fp32 everything else
-        m_exp = recipe.t_explainer(cfg)
-        synth.load_synth_weights(m_exp, seed=1)
-        m_exp = m_exp.to(dev)
-        m_exp.train()
-        tb = args.train_batch
-        if kind.endswith("vit"):
-            tx = torch.from_numpy(synth.synth_images(tb, params["img_px_size"], params["img_channels"], seed=200 + rank)).to(dev)
-        else:
-            tx = torch.from_numpy(synth.synth_token_ids(tb, params["max_position_embeddings"], params["vocab_size"], seed=200 + rank)).to(dev)
-        labels = torch.zeros(tb, dtype=torch.long, device=dev)
-        opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5)
-        v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
-        gen = lambda a, b_: (tx, labels)  # noqa: E731
-        te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)], recipe, surrogate, m_exp, opt, 1, gen, seed=7)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        tt = time.perf_counter()
-        n_train = 3
-        te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)] * n_train, recipe, surrogate, m_exp, opt, 2, gen, seed=7)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el = time.perf_counter() - tt
-        if dist is not None:
-            tm = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            el = float(tm.item())
-        train_imgs_per_s = tb * world * n_train / el
-        surrogate.eval()
-        del m_exp, opt
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        rate, f_step, _ = train_step_rate(job, dist, 5, args.train_batch, args.precision)
+        tf = rate / world / args.train_batch * f_step / 1e12
+        train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
+                       "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 "
+                               "accumulate / activations / optimizer state) + AdamW, as scripts/train_explainer.py:128-207",
+                       "roofline": {"bound": "mfma", "gflop_per_step": round(f_step / 1e9, 1), "achieved": round(tf, 1), "peak": peak,
+                                    "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                    "flops": "K-mask targets (F_exec) + grand forward + explainer forward + 2x forward for the backward"}}
+        # BASELINE config 5: duo BERT-base and froyo ViT-base, K=32, the same training step
+        if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16":
+            for wl in ("duo_bert_base", "froyo_vit_base"):
+                j5 = Job(wl, dev, rank, world, args.train_batch, 0, args.precision)
+                r5, f5, frozen = train_step_rate(j5, dist, 5, args.train_batch, args.precision)
+                tf5 = r5 / world / args.train_batch * f5 / 1e12
+                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
+                          "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,
+                          "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
+                                       "frac": round(tf5 / peak, 4)}}
+                del j5
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed
-        frac = packed_rows / float(R * T) if (kind in ("vanilla_bert", "ltt_bert") and packed_rows) else 1.0
+        frac = packed_rows / float(R * T) if (kind in ("vanilla_bert", "duo_vanilla_bert", "ltt_bert") and packed_rows) else 1.0
         f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        # dominant kernel = the instrumented class with the largest total time
-        dom = max(stats, key=lambda c: stats[c][0])
-        ms, fl, by, n = stats[dom]
-        per_kernel = {EPI_NAMES[c]: {"launches": int(s[3]), "avg_us": round(1e3 * s[0] / max(1, s[3]), 2),
-                                     "tflops": round(s[1] / max(s[0], 1e-9) / 1e9, 1),
-                                     "algo_gb_s": round(s[2] / max(s[0], 1e-9) / 1e6, 1)}
-                      for c, s in stats.items() if s[3]}
-        traffic = None
-        try:  # measured in a separate rocprofv3 --pmc run of this same command (tools/profile_round.sh), committed
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if (tj["workload"], tj["batch"], tj["masks"], tj["precision"]) == (args.workload, B, K, args.precision):
-                traffic = tj["traffic_bytes_per_launch"].get(EPI_NAMES[dom])
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {
-            "bound": "mfma", "kernel": EPI_NAMES[dom], "launches": int(n), "avg_launch_us": round(1e3 * ms / max(1, n), 2),
-            "achieved": round(fl / max(ms, 1e-9) / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(by / max(1, n)),
-            "whole_step": {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
-                           "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
-                           "exec_tflops": round(value / world * f_exec / 1e12, 1),
-                           "exec_frac_of_peak": round(value / world * f_exec / 1e12 / peak, 4)},
-            "kernels": per_kernel,
-        }
-        if args.precision == "bf16":
+        roofline = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s"}
+        if not args.graph:
+            # dominant kernel = the instrumented class with the largest total time
+            dom = max(stats, key=lambda c: stats[c][0])
+            ms, fl, by, n = stats[dom]
+            per_kernel = {EPI_NAMES[c]: {"launches": int(s[3]), "avg_us": round(1e3 * s[0] / max(1, s[3]), 2),
+                                         "tflops": round(s[1] / max(s[0], 1e-9) / 1e9, 1),
+                                         "algo_gb_s": round(s[2] / max(s[0], 1e-9) / 1e6, 1)}
+                          for c, s in stats.items() if s[3]}
+            traffic, traffic_note = None, "no counter file for this workload"
+            build = kernel_source_sha16()
+            try:  # measured in a separate rocprofv3 --pmc run of this same command (tools/profile_round.sh), committed
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if (tj["workload"], tj["batch"], tj["masks"], tj["precision"]) == (args.workload, B, K, args.precision):
+                    if tj.get("kernel_source_sha16") == build:
+                        traffic = tj["traffic_bytes_per_launch"].get(EPI_NAMES[dom])
+                        traffic_note = tj.get("source")
+                    else:
+                        traffic_note = (f"profiles/traffic.json was measured on kernel build {tj.get('kernel_source_sha16')}, this is "
+                                        f"{build}: not quoted")
+            except (OSError, KeyError, ValueError):
+                pass
+            roofline.update({
+                "kernel": EPI_NAMES[dom], "launches": int(n), "avg_launch_us": round(1e3 * ms / max(1, n), 2),
+                "achieved": round(fl / max(ms, 1e-9) / 1e9, 1),
+                "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                "kernel_source_sha16": build,
+                "algorithmic_bytes_per_launch": round(by / max(1, n)), "kernels": per_kernel})
+        roofline["whole_step"] = {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
+                                  "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
+                                  "exec_tflops": round(value / world * f_exec / 1e12, 1),
+                                  "exec_frac_of_peak": round(value / world * f_exec / 1e12 / peak, 4)}
+        if args.precision == "bf16" and not args.graph:
             # what the matrix cores of this board sustain on random operands with nothing else running (power cap):
             # context for `frac`, which stays priced against the 2.4 GHz datasheet peak
             tf, ghz = C.c_double(), C.c_double()
             L.check(L.lib().ag_probe_mfma(100000, 0, C.byref(tf), C.byref(ghz), None))
             roofline["power_capped_mfma_probe"] = {"tflops": round(tf.value, 1), "shader_ghz": round(ghz.value, 3),
-                                                   "frac_of_probe": round(fl / max(ms, 1e-9) / 1e9 / max(tf.value, 1e-9), 4)}
+                                                   "frac_of_probe": round(roofline["achieved"] / max(tf.value, 1e-9), 4)}
         line = {
             "metric": "masked-forwards/sec (K=%d)" % K, "value": round(value, 2), "unit": "masked-forwards/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": {"vit_base": "vit_base_imagenette_vanilla", "vit_large": "vit_large_imagenette_vanilla",
-                                    "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128",
-                                    "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128"}[args.workload],
-                       "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_step": R * world, "tokens": T,
-                       "sharding": "rows by input, no data-path collective", "weights": "seeded random init",
+            "config": {"workload": WORKLOAD_LABEL[args.workload],
+                       "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_gpu_per_step": R, "rows_per_step": R * world,
+                       "tokens": T, "ranks": world, "collective_backend": "rccl (torch.distributed nccl)" if world > 1 else "none (1 rank)",
+                       "sharding": "rows by input, no data-path collective; one mask stream, each rank takes its rows of the global call",
+                       "weights": "seeded random init", "launch": "hipGraph replay" if args.graph else "eager",
                        "visible_token_fraction_after_layer0": round(frac, 4)},
             "roofline": roofline,
         }
         if attrs_per_s is not None:
-            line["secondary"] = {"metric": "Shapley-attrs/sec/image", "value": round(attrs_per_s, 1), "unit": "images/s",
-                                 "path": "fw_final (classifier + surrogate + explainer forward -> phi[B,C,P])",
-                                 "images_per_gpu_per_pass": args.attr_batch, "passes": 4}
-            if train_imgs_per_s is not None:
-                line["secondary"]["train_explainer_step"] = {
-                    "value": round(train_imgs_per_s, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                    "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 accumulate / activations / optimizer state) + AdamW, as scripts/train_explainer.py:128-207"}
+            secondary.update({"metric": "Shapley-attrs/sec/image", "value": round(attrs_per_s, 1), "unit": "images/s",
+                              "path": "fw_final (classifier + surrogate + explainer forward -> phi[B,C,P])",
+                              "images_per_gpu_per_pass": args.attr_batch, "passes": 4})
+        if train_block is not None:
+            secondary["train_explainer_step"] = train_block
+        if c5:
+            secondary["config5_train_explainer_step"] = c5
+        if secondary:
+            line["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             sample_b = 1
             masks_np = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), sample_b * K, P)[0].cpu().numpy()
             sd_np = {k: v.detach().cpu().numpy() for k, v in surrogate.state_dict().items()}
-            cpu_v, cpu_rows, cpu_reps, cpu_threads = cpu_baseline(kind, params, xs_np[:sample_b], masks_np, sd_np)
+            cpu_v, cpu_rows, cpu_reps, cpu_threads, tried = cpu_baseline(kind, params, job.xs_np[:sample_b], masks_np, sd_np)
             line["cpu_baseline"] = {"value": round(cpu_v, 2), "unit": "masked-forwards/s", "cores": cpu_threads,
                                     "kind": "port",
-                                    "sample": f"torch-CPU fp32 port of the reference path, {cpu_rows} rows (1 input x K={K}) of the same workload, best of {cpu_reps} runs over 8/16/32/64 threads (host has {os.cpu_count()} logical CPUs)"}
+                                    "sample": f"torch-CPU fp32 port of the reference path, {cpu_rows} rows (1 input x K={K}) of the same workload; "
+                                              f"thread counts {tried} tried (warm-up + best of 2 each), {cpu_threads} of the host's "
+                                              f"{os.cpu_count()} logical CPUs were fastest"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

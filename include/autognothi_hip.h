@@ -60,6 +60,9 @@ int ag_mt19937_seed(void* d_state, uint32_t seed, void* stream);
  * torch.get_rng_state() so the device stream continues the host generator.  Export synchronises. */
 int ag_mt19937_import(void* d_state, const uint32_t* h_mt624, int pos, void* stream);
 int ag_mt19937_export(const void* d_state, uint32_t* h_mt624, int* pos, void* stream);
+/* advance the state by n draws without producing them (a rank of a row-sharded run steps over the other ranks' draws and
+ * stays on the one stream the unsharded reference loop consumes). */
+int ag_mt19937_skip(void* d_state, int64_t n, void* stream);
 /* raw draws (testing / other samplers): out[n] u32, advances the state. */
 int ag_mt19937_raw(void* d_state, uint32_t* d_out, int64_t n, void* stream);
 
@@ -71,6 +74,13 @@ int ag_mt19937_raw(void* d_state, uint32_t* d_out, int64_t n, void* stream);
  * Consumes n/2*P + n/2 draws in the reference's order.  d_scratch: >= n/2*(P+1) uint32. */
 int ag_mask_shapley_new(void* d_state, int n_mask_samples, int n_players, const float* d_prefix,
                         int64_t* d_mask_i64, uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream);
+/* Rows [row_lo, row_hi) (even bounds) of the call ag_mask_shapley_new(n_mask_samples_total, ...): what a rank of a row-sharded
+ * run needs.  The draws of the other rows are stepped over (twists only), the state advances by the whole call, so every rank
+ * of a run stays on the one stream of the unsharded reference loop and the union of the ranks' rows is bit-identical to the
+ * single call.  Outputs hold (row_hi - row_lo) rows; d_scratch: >= (row_hi - row_lo)/2 * (P+1) uint32. */
+int ag_mask_shapley_new_rows(void* d_state, int n_mask_samples_total, int row_lo, int row_hi, int n_players,
+                             const float* d_prefix, int64_t* d_mask_i64, uint32_t* d_mask_bits, uint32_t* d_scratch,
+                             void* stream);
 /* reference models/shapley.py:109-115 mask_purely_uniform(batch, n_features).
  * d_scratch: >= batch*(P+1) uint32. */
 int ag_mask_purely_uniform(void* d_state, int batch, int n_players, int64_t* d_mask_i64,
@@ -301,8 +311,9 @@ int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, 
  * masked: hidden states of masked tokens are dead rows.  ag_bert_encoder_forward_pruned = ag_encoder_forward(...,
  * cls_only_last = 1) for the BERT kind, computing layer 0 on every token (its LN/QKV are shared by the K masks) and
  * layers 1.. on the packed visible tokens only (mask-free varlen attention).  Same output contract (token 0 of
- * every row of d_h [R,T,H]); *packed_rows_out (optional, host) receives the number of visible tokens.  Reads one
- * int back from the device: synchronises the stream once.
+ * every row of d_h [R,T,H]); d_packed_rows_out (optional, DEVICE int) receives the number of visible tokens.  Nothing is
+ * read back to the host: the packed section's launches are sized for the upper bound R*T and clamp to the device-side count
+ * (ag_dynamic_rows), so the call is asynchronous and graph-capturable.
  * Building blocks: ag_seq_compact_plan (cu_seqlens [R+1] by popcount + scan, packed-row -> source-row table [<= R*T]),
  * ag_gather_rows (dst[i,:] = src[index[i],:]), ag_masked_attention_varlen (rows = token ranges of cu_seqlens).
  * ---------------------------------------------------------------------------------------------- */
@@ -317,7 +328,13 @@ int ag_bert_layers_forward_packed(const ag_encoder_desc* desc, const void* d_x, 
                                   void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
 int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
                                    const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
-                                   int* packed_rows_out, void* stream);
+                                   int* d_packed_rows_out, void* stream);
+/* Row counts that only the device knows (the packed token count of a pruned forward): until reset with NULL, the row count
+ * (M / rows / n) passed to ag_gemm, ag_layernorm and ag_gather_rows by THIS host thread is an upper bound that sizes the
+ * launch; the kernels read the actual count from d_rows[0] when they run and skip the rest (surplus workgroups exit at
+ * once; the XCD-aware tile order is built from the actual count).  Lets a data-dependent row count stay inside one
+ * asynchronous, capturable stream of launches instead of a device->host read + synchronise. */
+int ag_dynamic_rows(const int* d_rows);
 
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
  * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per

@@ -14,6 +14,80 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _check_overlapped_reducer(D, rank, world):
+    """GradBucketReducer: parameters reported in backward order, buckets flushed asynchronously as they fill, the tail and
+    un-reported parameters by finish(); result == plain averaged all-reduce; twice-reported parameters are refused."""
+    g = torch.Generator().manual_seed(100 + rank)
+    ps = [torch.nn.Parameter(torch.zeros(s_)) for s_ in ((64, 8), (8,), (32, 32), (5,), (100,))]
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    for q in ps:
+        q.grad = torch.randn(q.shape, generator=g)
+    mine = [q.grad.clone() for q in ps]
+    red = D.GradBucketReducer(ps + [frozen], bucket_bytes=2048, average=True)
+    for q in reversed(ps[1:]):          # ps[0] is never reported: finish() must still reduce it
+        red.ready(q)
+    n_coll = red.finish()
+    assert n_coll >= 2, n_coll
+    for q, m in zip(ps, mine):
+        both = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(both, m)
+        torch.testing.assert_close(q.grad, sum(both) / world, rtol=1e-6, atol=1e-7)
+    red.ready(ps[1])
+    try:
+        red.ready(ps[1])
+        raise AssertionError("second report of a parameter was accepted")
+    except RuntimeError:
+        pass
+    red.finish()
+    for q in ps:
+        q.grad = None                   # zero_grad(set_to_none=True)
+    assert red.finish() == 0            # state is reset between steps; nothing holds a gradient
+
+
+def _check_sharded_step_equals_unsharded(D, rank, world):
+    """One explainer-style training step on a stub (plain torch on the CPU: the sharding contract, not the kernels): rows
+    shard by input, every rank computes the K-mask values, loss and gradients of ITS inputs, gradients are averaged by the
+    bucket reducer, losses / counts summed — and v_s, loss and gradients equal the single-process step on the whole batch."""
+    torch.manual_seed(7)
+    b, k, p, c, dfeat = 4, 6, 5, 3, 8
+    xs = torch.randn(b, dfeat)
+    masks = (torch.rand(b * k, p) > 0.5).long()
+    w_srg = torch.randn(dfeat + p, c)
+    v0 = torch.randn(1, c)
+    model = torch.nn.Linear(dfeat, c * p)
+
+    def values(x, m):               # the "surrogate": one row per (input, mask)
+        kk = m.shape[0] // x.shape[0]
+        return torch.tanh(torch.cat([x.repeat_interleave(kk, 0), m.float()], 1) @ w_srg)
+
+    def loss_of(x, m, vs):
+        nb = x.shape[0]
+        phi = model(x).view(nb, c, p)
+        approx = v0.view(1, 1, c) + m.view(nb, -1, p).float() @ phi.permute(0, 2, 1)
+        return p * torch.nn.functional.mse_loss(approx.reshape(-1, c), vs, reduction="mean")
+
+    model.zero_grad()
+    vs_all = values(xs, masks)
+    full = loss_of(xs, masks, vs_all)
+    full.backward()
+    want = [q.grad.clone() for q in model.parameters()]
+    model.zero_grad()
+    rows, lo, hi = D.shard_rows(masks, b, k)
+    vs_local = values(xs[lo:hi], rows)
+    counts = [(D.shard_range(b, r, world)[1] - D.shard_range(b, r, world)[0]) * k for r in range(world)]
+    torch.testing.assert_close(D.gather_rows(vs_local, counts), vs_all, rtol=0, atol=0)
+    local = loss_of(xs[lo:hi], rows, vs_local)
+    local.backward()
+    red = D.GradBucketReducer(model.parameters(), bucket_bytes=64)
+    for q in reversed(list(model.parameters())):
+        red.ready(q)
+    red.finish()
+    for q, w_ in zip(model.parameters(), want):     # equal rows per rank: the mean of the rank means is the global mean
+        torch.testing.assert_close(q.grad, w_, rtol=1e-5, atol=1e-6)
+    tot, n = D.reduce_scalars([float(local) * (hi - lo), hi - lo], torch.device("cpu"))
+    assert abs(tot / n - float(full)) < 1e-5
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,6 +125,8 @@ def _worker(rank, world, port, out):
         part = float((r2.double() ** 2).sum())
         assert abs(D.reduce_scalars([part], torch.device("cpu"))[0] - float((m2.double() ** 2).sum())) < 1e-9
         assert D.shard_auto(masks, n_inputs, k)[1] == "input"
+        _check_overlapped_reducer(D, rank, world)
+        _check_sharded_step_equals_unsharded(D, rank, world)
         out[rank] = 1
     finally:
         dist.destroy_process_group()

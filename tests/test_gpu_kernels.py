@@ -328,3 +328,49 @@ def test_empty_inputs(cuda_device):
     x = torch.zeros((0, 192), device=dev)
     y, _ = ops.layernorm(x, torch.ones(192, device=dev), torch.zeros(192, device=dev), 1e-12, F32, rows=0, ldx=192)
     assert y.shape[0] == 0
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_dynamic_row_counts(cuda_device, dtype):
+    """ag_dynamic_rows: launches sized for an upper bound, the actual row count read from device memory (the packed token
+    count of a pruned BERT forward never visits the host): rows below the count are computed exactly as by an exact-size
+    launch, rows at or above it are left untouched — for the 128-tile GEMM, the ring GEMM, LayerNorm and the row gather."""
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    g = np.random.default_rng(4)
+    upper, actual, k, n = 2304, 1237, 768, 776
+    a = g.standard_normal((upper, k)).astype(np.float32)
+    w = (g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = g.standard_normal(n).astype(np.float32)
+    A, W, B = _to_store(a, dtype, dev), _to_store(w, dtype, dev), torch.from_numpy(b).to(dev)
+    cnt = torch.tensor([actual], dtype=torch.int32, device=dev)
+    sentinel = 777.0
+
+    def run(fn):
+        L.check(L.lib().ag_dynamic_rows(L.ptr(cnt)))
+        try:
+            return fn()
+        finally:
+            L.check(L.lib().ag_dynamic_rows(None))
+
+    for m_up in (upper, 600):         # ring kernel (bf16, M >= 1024) and the 128-tile kernel
+        act = min(actual, m_up) if m_up == upper else 333
+        cnt.fill_(act)
+        want = ops.gemm(A[:act], W, B, L.AG_EPI_BIAS_GELU, dtype).float()
+        out = torch.full((m_up, n), sentinel, dtype=want.dtype if dtype == F32 else torch.bfloat16, device=dev)
+        run(lambda: ops.gemm(A[:m_up], W, B, L.AG_EPI_BIAS_GELU, dtype, out=out))
+        assert torch.equal(out[:act].float(), want)
+        assert bool((out[act:].float() == sentinel).all())
+    cnt.fill_(actual)
+    x = _to_store(a, dtype, dev)
+    gam, bet = torch.from_numpy(g.standard_normal(k).astype(np.float32)).to(dev), torch.from_numpy(g.standard_normal(k).astype(np.float32)).to(dev)
+    want, _ = ops.layernorm(x[:actual], gam, bet, 1e-12, dtype)
+    got, _ = run(lambda: ops.layernorm(x, gam, bet, 1e-12, dtype))
+    assert torch.equal(got[:actual], want)
+    idx = torch.from_numpy(g.permutation(upper).astype(np.int32)).to(dev)
+    want = ops.gather_rows(x, idx, actual, dtype)
+    dst = run(lambda: ops.gather_rows(x, idx, upper, dtype))
+    assert torch.equal(dst[:actual], want)
+    # the state is per host thread and was reset: an ordinary call afterwards sees its full row count
+    full = ops.gemm(A, W, B, L.AG_EPI_BIAS, dtype)
+    assert bool(torch.isfinite(full.float()).all()) and float(full[actual:].float().abs().max()) > 0

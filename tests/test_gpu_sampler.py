@@ -167,3 +167,35 @@ def test_perturbed_masks_with_ties(cuda_device):
         want = np.zeros(196, dtype=np.int64)
         want[rank_dev[:st]] = 1
         assert np.array_equal(masks[0, s].cpu().numpy(), want)
+
+
+def test_sharded_mask_stream_is_the_unsharded_stream(cuda_device):
+    """row-sharded ranks (distributed.ShardedMaskStream / ag_mask_shapley_new_rows): each rank's rows of the global call are
+    bit-identical to the single call's rows, for every rank count, and every rank's generator ends where the single
+    generator ends (the next step stays in lockstep).  Reference: one mask_shapley_new(B*K, P) per step, models/shapley.py:56-79."""
+    from autognothi_amd import ops
+    from autognothi_amd.distributed import ShardedMaskStream
+    dev = cuda_device
+    n_inputs, k, p = 8, 6, 196
+    rng = ops.DeviceMT19937(dev, 3407)
+    want1, wbits1 = ops.mask_shapley_new(rng, n_inputs * k, p)
+    want2, _ = ops.mask_shapley_new(rng, n_inputs * k, p)
+    tail = rng.raw(5).cpu().numpy()
+    for world in (1, 2, 4, 8):
+        per = n_inputs // world
+        got1, got2, bits1, tails = [], [], [], []
+        for r in range(world):
+            st = ShardedMaskStream(dev, 3407)
+            m1, b1 = st.sample(n_inputs, r * per, (r + 1) * per, k, p, want_i64=True)
+            m2, _ = st.sample(n_inputs, r * per, (r + 1) * per, k, p, want_i64=True)
+            got1.append(m1); got2.append(m2); bits1.append(b1)
+            tails.append(st.rng.raw(5).cpu().numpy())
+        assert torch.equal(torch.cat(got1), want1) and torch.equal(torch.cat(got2), want2), world
+        assert torch.equal(torch.cat(bits1), wbits1)
+        assert all(np.array_equal(t, tail) for t in tails)
+    # skip == drawing and discarding, across twists
+    a, b = ops.DeviceMT19937(dev, 11), ops.DeviceMT19937(dev, 11)
+    for n in (1, 623, 624, 625, 5000):
+        a.raw(n)
+        b.skip(n)
+        assert np.array_equal(a.raw(3).cpu().numpy(), b.raw(3).cpu().numpy()), n

@@ -4,7 +4,7 @@
 LIBS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done; [ "$1" == "--" ] && shift
 for i in 1 2 3; do
   for lib in "${LIBS[@]}"; do
-    AG_HIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --train-batch 0 --attr-batch 0 --steps 20 --warmup 5 "$@" 2>/dev/null |
+    AG_HIP_LIB=$PWD/$lib python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 "$@" 2>/dev/null |
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); k=d['roofline']['kernels']; print('$lib', d['value'], d['ms_per_step'], {n:v['avg_us'] for n,v in k.items()})"
   done
 done

@@ -3,7 +3,7 @@
 # default bench command.  Outputs land in gpurun_out/prof_<tag>/ ; tools/summarize_profile.py turns them into profiles/.
 set -u
 R=$GRAFT_REPO_ROOT; TAG=${1:-final}; shift || true
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --attr-batch 0 --train-batch 0 $*"   # the timed hot path only: secondary lines reuse the same kernels at other shapes
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-secondary $*"   # the timed hot path only: secondary lines reuse the same kernels at other shapes
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}/stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}/fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1

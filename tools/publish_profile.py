@@ -17,7 +17,9 @@ names = {"gemm<bias>": "gemm_ring_kernel<0, 1, false>", "gemm<bias+gelu>": "gemm
 attn = [k for k in summ if k.startswith("attn_bf16_kernel")]
 if attn:
     names["masked_attention"] = attn[0]
-out = {"workload": workload, "batch": batch, "masks": masks, "precision": "bf16",
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_source_sha16: the counters are only quoted next to numbers of the same kernel build)
+out = {"workload": workload, "batch": batch, "masks": masks, "precision": "bf16", "kernel_source_sha16": bench.kernel_source_sha16(),
        "source": f"profiles/{tag}_pmc_summary_{suffix}.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; "
                  "bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per MI355X_MICROARCH.md HBM section)",
        "traffic_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
