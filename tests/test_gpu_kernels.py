@@ -344,7 +344,7 @@ def test_dynamic_row_counts(cuda_device, dtype):
     b = g.standard_normal(n).astype(np.float32)
     A, W, B = _to_store(a, dtype, dev), _to_store(w, dtype, dev), torch.from_numpy(b).to(dev)
     cnt = torch.tensor([actual], dtype=torch.int32, device=dev)
-    sentinel = 777.0
+    sentinel = 768.0      # (exactly representable in bf16)
 
     def run(fn):
         L.check(L.lib().ag_dynamic_rows(L.ptr(cnt)))
