@@ -275,8 +275,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 const int mm = mw0 + (sm - 1) * 16 + rr;
                 if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
                     uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (p.nt_store) {
-                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                         __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dstp));
                     } else *dstp = val;
                 }
@@ -548,7 +548,8 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     {
         const int tiles_n = ceil_div(N, BT);
         const double wbytes = (double)N * K * 2.0;
-        int groups = (wbytes > 4.0 * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (2.5 * 1024 * 1024) + 0.999) : 1;
+        const double wfit_mb = getenv("AG_GEMM_WFIT_MB") ? atof(getenv("AG_GEMM_WFIT_MB")) : 4.0;   // (experiment knob)
+        int groups = (wbytes > wfit_mb * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (2.5 * 1024 * 1024) + 0.999) : 1;
         int g = ngrp_env > 0 ? ngrp_env : ceil_div(tiles_n, groups);
         // wide outputs (16 or more N-tiles: none in the encoder): the 32 tiles an XCD runs at a time would be ONE row of
         // tiles (1 A slice + 32 W slices per half-step); groups of 4 columns make them an 8 x 4 block (8 + 4 slices) that

@@ -42,6 +42,30 @@ def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_sampl
     return bits, v_s, v_1
 
 
+def surrogate_targets_lookahead(recipe: ModelRecipe, m_surrogate, xs_list, n_mask_samples: int, n_players: int, rng):
+    """The surrogate is frozen while the explainer trains, so the K-mask targets of the NEXT batches do not depend on
+    anything the optimiser does: the masked forwards of several consecutive batches are run as ONE forward over their
+    concatenated inputs — the hot path then always works on a few thousand rows, whatever the training batch size is (the
+    reference trains on 2-4 inputs per step: 64-128 rows, a fraction of one round of GEMM tiles).  Masks are drawn per
+    batch, in batch order, from the same device stream, so every batch gets exactly the masks (and values) it would get
+    from ``surrogate_targets`` called batch by batch.  -> list of (bits, v_s, v_1) per batch."""
+    bits_l = [ops.mask_shapley_new(rng, x.shape[0] * n_mask_samples, n_players, want_i64=False, want_bits=True)[1] for x in xs_list]
+    xs_all = torch.cat(list(xs_list), dim=0) if len(xs_list) > 1 else xs_list[0]
+    bits_all = torch.cat(bits_l, dim=0) if len(bits_l) > 1 else bits_l[0]
+    m_surrogate.eval()
+    with torch.no_grad():
+        v_s, _ = recipe.fw_surrogate(m_surrogate, xs_all, bits_all)
+        ones = torch.ones((xs_all.shape[0], n_players), dtype=torch.long, device=xs_all.device)
+        v_1, _ = recipe.fw_surrogate(m_surrogate, xs_all, ones)
+    out, r0, b0 = [], 0, 0
+    for x, bits in zip(xs_list, bits_l):
+        b = x.shape[0]
+        out.append((bits, v_s[r0:r0 + b * n_mask_samples], v_1[b0:b0 + b]))
+        r0 += b * n_mask_samples
+        b0 += b
+    return out
+
+
 def explainer_batch_loss(recipe: ModelRecipe, m_explainer, xs: Tensor, bits: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor,
                          n_mask_samples: int, n_players: int, want_grad: bool = False):
     """reference :184-196 (forward): -> (loss [1] device tensor, phi [B,C,P], dphi or None, logits or None)."""
@@ -75,7 +99,8 @@ def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_
 def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                           d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                           optimizer: torch.optim.Optimizer, epoch: int,
-                          gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None) -> float:
+                          gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
+                          target_rows: int = 1536) -> float:
     """reference _explainer_epoch_train (:128-207) / _duo_explainer_epoch_train: per batch — K-mask surrogate
     targets (no grad, HIP inference path), explainer forward + Shapley loss + backward (HIP training kernels,
     autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean)."""
@@ -92,10 +117,29 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
     # as the backward has finished them (distributed.GradBucketReducer); a no-op at N = 1
     _, n_ranks = distributed.world()
     reducer = distributed.GradBucketReducer(m_explainer.parameters()) if n_ranks > 1 else None
-    for batch_idx, (_inputs, _targets) in enumerate(d_items):
-        xs, zs = gen_input(_inputs, _targets)
+    # surrogate targets are computed for groups of consecutive batches at once (surrogate_targets_lookahead): as many batches
+    # as it takes to reach `target_rows` masked rows per forward (1536 = 48 inputs x 32 masks, the size the kernels are
+    # tuned for); target_rows = 0 computes them batch by batch
+    def grouped(items):
+        group, rows = [], 0
+        for idx, (_inputs, _targets) in enumerate(items):
+            xs_, zs_ = gen_input(_inputs, _targets)
+            group.append((idx, xs_, zs_))
+            rows += xs_.shape[0] * n_mask_samples
+            if rows >= target_rows:
+                yield group
+                group, rows = [], 0
+        if group:
+            yield group
+
+    def batches():
+        for group in grouped(d_items):
+            tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, rng)
+            for (idx, xs_, zs_), t_ in zip(group, tg):
+                yield idx, xs_, zs_, t_
+
+    for batch_idx, xs, zs, (bits, v_s, v_1) in batches():
         optimizer.zero_grad()
-        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
         _training.GRAD_SINK = reducer.ready if reducer is not None else None
         try:
             loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
@@ -143,7 +187,9 @@ def train_explainer(env: Any, device: torch.device) -> None:
     if epoch_explainer >= tcfg.epochs:
         env.log("[[[ explainer already trained ]]]")
         return
-    optimizer = torch.optim.AdamW(m_explainer.parameters(), lr=tcfg.lr)
+    # the reference's optimiser (scripts/train_explainer.py:47-49: AdamW, default betas / eps / weight decay) in torch's
+    # single-pass fused form: the same update, one kernel per parameter group instead of eight elementwise passes
+    optimizer = torch.optim.AdamW(m_explainer.parameters(), lr=tcfg.lr, fused=True)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, tcfg.epochs)
     v_0 = surrogate_null(m_recipe, m_config, m_misc, m_surrogate, device)
     for epoch in range(epoch_explainer + 1, tcfg.epochs + 1):

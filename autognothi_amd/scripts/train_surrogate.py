@@ -107,7 +107,7 @@ def train_surrogate(env: Any, device: torch.device) -> None:
     if epoch_surrogate >= tcfg.epochs:
         env.log("[[[ surrogate already trained ]]]")
         return
-    optimizer = torch.optim.AdamW(m_surrogate.parameters(), lr=tcfg.lr)
+    optimizer = torch.optim.AdamW(m_surrogate.parameters(), lr=tcfg.lr, fused=True)   # (same update, single-pass kernel)
     scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, tcfg.epochs)
     for epoch in range(epoch_surrogate + 1, tcfg.epochs + 1):
         seed = set_iterative_seed(config.seed, f"train_surrogate[epoch={epoch}]")

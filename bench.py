@@ -285,7 +285,7 @@ def train_step_rate(job, dist, n_train, tb, precision):
     m_exp.train()
     tx = torch.from_numpy(job.inputs(tb, 200 + job.rank)).to(dev)
     labels = torch.zeros(tb, dtype=torch.long, device=dev)
-    opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5)
+    opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5, fused=True)
     v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
     gen = lambda a, b_: (tx, labels)  # noqa: E731
     te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * 2, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
@@ -470,11 +470,13 @@ def main():
     c5 = {}
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        rate, f_step, _ = train_step_rate(job, dist, 5, args.train_batch, args.precision)
+        rate, f_step, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision)
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                       "body": "K-mask surrogate targets (bf16) + explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 "
-                               "accumulate / activations / optimizer state) + AdamW, as scripts/train_explainer.py:128-207",
+                       "steps": 12,
+                       "body": "K-mask surrogate targets (bf16; computed for groups of consecutive batches at once: the surrogate is frozen) + "
+                               "explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 accumulate / activations / "
+                               "optimizer state) + AdamW, as scripts/train_explainer.py:128-207",
                        "roofline": {"bound": "mfma", "gflop_per_step": round(f_step / 1e9, 1), "achieved": round(tf, 1), "peak": peak,
                                     "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "flops": "K-mask targets (F_exec) + grand forward + explainer forward + 2x forward for the backward"}}
@@ -482,7 +484,7 @@ def main():
         if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16":
             for wl in ("duo_bert_base", "froyo_vit_base"):
                 j5 = Job(wl, dev, rank, world, args.train_batch, 0, args.precision)
-                r5, f5, frozen = train_step_rate(j5, dist, 5, args.train_batch, args.precision)
+                r5, f5, frozen = train_step_rate(j5, dist, 12, args.train_batch, args.precision)
                 tf5 = r5 / world / args.train_batch * f5 / 1e12
                 c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
                           "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,

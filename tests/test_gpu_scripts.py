@@ -160,3 +160,49 @@ def test_performance_report(cuda_device):
     want_cls = (nl - 1) * layer + last_cls_only + embed + 2 * h * ncls
     assert abs(rep.classifier.gflops * 1e9 - want_cls) / want_cls < 0.02
     assert rep.explainer.gflops > rep.surrogate.gflops > 0
+
+
+def test_target_lookahead_equals_batch_by_batch(cuda_device):
+    """surrogate_targets_lookahead (the K-mask targets of several consecutive batches in ONE forward) gives every batch the
+    masks and values of surrogate_targets called batch by batch (reference order: one mask_shapley_new + two fw_surrogate per
+    batch, scripts/train_explainer.py:153-179); the epoch loss does not depend on the grouping."""
+    from autognothi_amd import engine, ops
+    from autognothi_amd.scripts import train_explainer as te
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    srg = c["surrogate"].to(dev)
+    from autognothi_amd.utils import synth
+    prm = c["meta"]["params"]
+    batches = [torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=40 + i)).to(dev)
+               for i, n in enumerate((2, 3, 1, 2))]
+    k, p = 6, c["P"]
+    rng = ops.DeviceMT19937(dev, 99)
+    one_by_one = [te.surrogate_targets(recipe, srg, x, k, p, rng) for x in batches]
+    rng.seed(99)
+    grouped = te.surrogate_targets_lookahead(recipe, srg, batches, k, p, rng)
+    for (b1, vs1, v11), (b2, vs2, v12) in zip(one_by_one, grouped):
+        assert torch.equal(b1, b2)
+        torch.testing.assert_close(vs2, vs1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(v12, v11, rtol=1e-5, atol=1e-6)
+    # the epoch: same loss whether targets are grouped (default) or computed per batch (target_rows=0); eval-mode dropout-free
+    exp = c["explainer"].to(dev)
+    v0 = torch.from_numpy(c["g"]["v_0"]).to(dev)
+    it = iter(batches)
+    items = [(None, None)] * len(batches)
+    losses = []
+    for rows in (10 ** 6, 0):
+        import copy
+        e2 = copy.deepcopy(exp)
+        for m in e2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        e2.config = e2.config.model_copy(update={"hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0})
+        for sub in e2.modules():
+            if hasattr(sub, "config") and sub is not e2 and hasattr(sub.config, "hidden_dropout_prob"):
+                sub.config = sub.config.model_copy(update={"hidden_dropout_prob": 0.0, "attention_probs_dropout_prob": 0.0})
+        opt = torch.optim.SGD(e2.parameters(), lr=0.0)
+        it = iter(batches)
+        gen = lambda a, b_: (lambda x: (x, torch.zeros(x.shape[0], dtype=torch.long, device=dev)))(next(it))  # noqa: E731
+        losses.append(te.explainer_epoch_train(None, dev, k, p, v0, items, recipe, srg, e2, opt, 1, gen, seed=5, target_rows=rows))
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
