@@ -147,9 +147,15 @@ def explainer_flops_per_image(kind, p, T):
     """GEMM flops of one explainer FORWARD per image (all-ones mask): backbone + explainer_attn layer(s) + MLP head
     (+ the duo head); SURVEY §8d: 42.7 GFLOP for vanilla ViT-base."""
     H, I, C_ = p["hidden_size"], p["intermediate_size"], p["num_labels"]
-    hh = p["explainer_head_hidden_size"]
     layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
-    f = p["num_hidden_layers"] * layer + p["explainer_attn_num_layers"] * layer + 2 * T * (H * hh + hh * hh + hh * C_)
+    if kind.startswith("ltt_"):   # frozen backbone + ONE ladder (maps + h-wide side layers) + side explainer layer(s) + MLP head
+        h, i_s, hh = p["s_attn_hidden_size"], p["s_attn_intermediate_size"], p["explainer_s_head_hidden_size"]
+        side = 8 * T * h * h + 4 * T * T * h + 4 * T * h * i_s
+        f = p["num_hidden_layers"] * (layer + 2 * T * H * h + side) + p["explainer_s_attn_num_layers"] * side
+        f += 2 * T * (h * hh + hh * hh + hh * C_)
+    else:
+        hh = p["explainer_head_hidden_size"]
+        f = p["num_hidden_layers"] * layer + p["explainer_attn_num_layers"] * layer + 2 * T * (H * hh + hh * hh + hh * C_)
     if kind.endswith("vit"):
         f += 2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H
     return float(f), float(p["num_hidden_layers"] * layer)
