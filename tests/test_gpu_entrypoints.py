@@ -1,0 +1,110 @@
+"""The three pipeline entry points with the reference's signatures — train_surrogate(env, device), train_explainer(env, device),
+measure_faithfulness(env, device, d_loader, resolution) (scripts/train_surrogate.py:16, train_explainer.py:19,
+measure_faithfulness.py:41) — run end to end on a duck-typed environment: resume from checkpoints in the reference's wire
+format, per-epoch reseeding, train + eval epochs, scheduler, metrics, checkpoint rotation, report."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import build_case
+
+pytestmark = pytest.mark.gpu
+
+
+class _Loader:
+    """any object with .train(bs) / .test(bs) iterables of (raw inputs, raw targets) (the reference's DatasetLoader shape)."""
+
+    def __init__(self, xs, ys):
+        self.xs, self.ys = xs, ys
+
+    def _it(self, bs):
+        for i in range(0, len(self.xs), bs):
+            yield self.xs[i:i + bs], self.ys[i:i + bs]
+
+    def train(self, bs):
+        return self._it(bs)
+
+    def test(self, bs):
+        return self._it(bs)
+
+
+class _Env:
+    def __init__(self, config, model_path, loader):
+        self.config, self.model_path, self.d_loader = config, model_path, loader
+        self.lines, self.entries, self.flushed = [], [], 0
+
+    def log(self, msg):
+        self.lines.append(msg)
+
+    def metrics(self, entry):
+        self.entries.append(entry)
+
+    def flush_cfg(self):
+        self.flushed += 1
+
+
+def _train_cfg(**kw):
+    base = dict(epochs=2, ckpt_when="_:%1==0", lr=1e-3, batch_size=2, EXPERIMENTAL_progressive_training=None)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_pipelines_run_from_checkpoints(cuda_device, tmp_path):
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import resources as rs
+    from autognothi_amd.scripts.measure_faithfulness import measure_faithfulness
+    from autognothi_amd.scripts.train_explainer import train_explainer
+    from autognothi_amd.scripts.train_surrogate import train_surrogate
+    from autognothi_amd.utils import synth
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    recipe, dev = c["recipe"], cuda_device
+    prm = dict(c["meta"]["params"], num_hidden_layers=2)
+    cfg = recipe.t_config(**prm)
+    cls, srg, exp = recipe.t_classifier(cfg), recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
+    synth.load_synth_weights(cls, seed=3)
+    synth.load_synth_weights(srg, seed=0)
+    synth.load_synth_weights(exp, seed=1)
+    for section, m in (("classifier", cls), ("surrogate", srg), ("explainer", exp)):
+        rs.save_epoch_ckpt(tmp_path, section, "_:%1==0", 2, 0, m)
+    n = 6
+    imgs = torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=9))
+    loader = _Loader([imgs[i] for i in range(n)], [i % prm["num_labels"] for i in range(n)])
+    config = types.SimpleNamespace(
+        seed=3407, net=types.SimpleNamespace(kind="vanilla_vit", params=prm), dataset=None,
+        train_classifier=_train_cfg(epochs=0), train_surrogate=_train_cfg(epochs=1),
+        train_explainer=_train_cfg(epochs=2, n_mask_samples=4, lambda_efficiency=0.0, lambda_norm=0.0),
+        eval_faithfulness=types.SimpleNamespace(dataset=None, batch_size=4, resolution=5))
+    env = _Env(config, tmp_path, loader)
+
+    train_surrogate(env, dev)
+    assert rs.get_epoch_ckpts(tmp_path, "surrogate", 5) == [0, 1]
+    assert env.entries[-1]["epoch"] == 1 and np.isfinite(env.entries[-1]["train_kld_loss"])
+    before = torch.load(rs.ckpt_path(tmp_path, "surrogate", 0), weights_only=False)
+    after = torch.load(rs.ckpt_path(tmp_path, "surrogate", 1), weights_only=False)
+    assert list(before.keys()) == list(after.keys()) == list(srg.state_dict().keys())
+    assert any(not torch.equal(before[k], after[k]) for k in before)            # the optimiser moved the weights
+    train_surrogate(env, dev)                                                   # resume: nothing left to do
+    assert any("already trained" in ln for ln in env.lines)
+
+    train_explainer(env, dev)
+    assert rs.get_epoch_ckpts(tmp_path, "explainer", 5) == [0, 1, 2]
+    exp_entries = [e for e in env.entries if "train_reg_loss" in e]
+    assert [e["epoch"] for e in exp_entries] == [1, 2]
+    assert all(np.isfinite(e["train_reg_loss"]) and np.isfinite(e["test_reg_loss"]) for e in exp_entries)
+    assert exp_entries[1]["train_reg_loss"] < exp_entries[0]["train_reg_loss"]   # AdamW lr 1e-3 on 6 images: the loss goes down
+    assert env.flushed >= 3
+
+    # final checkpoint (reference stage machine: conv_explainer_final), then the faithfulness report
+    _, m_cls = rs.load_epoch_model_env(env, recipe, "classifier", dev)
+    _, m_srg = rs.load_epoch_model_env(env, recipe, "surrogate", dev)
+    _, m_exp = rs.load_epoch_model_env(env, recipe, "explainer", dev)
+    final = recipe.conv_explainer_final(cfg, None, m_cls, m_srg, m_exp)
+    rs.save_epoch_ckpt(tmp_path, "final", "_:%1==0", 0, 0, final)
+    rep = measure_faithfulness(env, dev, None, None)
+    assert len(rep["data_cls"]) == n and set(rep) >= {"insertion", "deletion", "insertion_non_ok", "deletion_non_ok"}
+    for key in ("insertion", "deletion"):
+        assert 0.0 <= rep[key]["auc"] <= 1.0 and len(rep[key]["avg"]) == 5      # probabilities, resolution 5 stops
+    assert any("FINAL RESULTS" in ln for ln in env.lines)
