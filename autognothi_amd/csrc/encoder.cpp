@@ -14,6 +14,7 @@
 //   * with cls_only_last the last layer's attention / out-projection / MLP run on the CLS token only
 //     (the only row the surrogate/classifier heads read, models/vanilla_vit.py:54).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -80,6 +81,8 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
     const size_t es = dtype_size(dt);
     const int M = R * T;
     const bool vit = d->kind == AG_MASK_VIT_MUL;
+    static const bool side_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
+    const bool side_mlp = !side_off && ag_side_mlp_supported(H, I, dt);
     if (chain_stats) ws.st1 = chain_stats;
     if (stats_written) *stats_written = 0;
 
@@ -128,6 +131,10 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
                     nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, stream));
         if (vit) {
+            if (side_mlp && !fold2) {
+                // narrow layer (LTT ladder): LN2 + fc1 + GELU + fc2 + residual in one register-resident kernel
+                TRY(ag_side_mlp(ws.hx, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 0, d_h, ld_tok, stream));
+            } else {
             if (fold2) {
                 TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
                             ws.st2, w.s_fc1_ln, d->ln_eps, nullptr, stream));
@@ -139,6 +146,7 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
             // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, stream));
+            }
             st1_ready = next_fold1;
             if (chain_out && stats_written) *stats_written = next_fold1 ? 1 : 0;
         } else {
@@ -147,12 +155,24 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                 TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
                 a = ws.ha;
             }
+            AG_REQUIRE(w.ln2_g, "ag_encoder_forward: BERT output.LayerNorm missing in layer %d", l);
+            if (side_mlp) {   // narrow layer (LTT ladder): fc1 + GELU + fc2 + residual + LN2 in one kernel
+                char* dst = last_cls ? ws.ctx : (char*)d_h;
+                TRY(ag_side_mlp(a, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, stream));
+                if (last_cls) {
+                    hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R,
+                                                    hipMemcpyDeviceToDevice, hs);
+                    if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
+                }
+                h_in = (const char*)d_h;
+                in_share = 1;
+                continue;
+            }
             TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
                         nullptr, nullptr, 0.f, nullptr, stream));
             char* pre = (a == ws.hx) ? ws.ha : ws.hx;
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, nullptr, stream));
-            AG_REQUIRE(w.ln2_g, "ag_encoder_forward: BERT output.LayerNorm missing in layer %d", l);
             if (last_cls) {
                 // LayerNorm the compact [R,H] rows, then scatter them to token 0 of d_h
                 TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
@@ -290,6 +310,8 @@ extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const voi
     carve(d, R, (char*)d_workspace, &ws);
     const int T = d->T, H = d->H, I = d->I, dt = d->dtype;
     const char* x = (const char*)d_x;
+    static const bool side_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
+    const bool side_mlp = !side_off && ag_side_mlp_supported(H, I, dt);
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         AG_REQUIRE(w.ln2_g, "ag_bert_layers_forward_packed: BERT output.LayerNorm missing in layer %d", l);
@@ -301,11 +323,16 @@ extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const voi
             TRY(ag_layernorm(ws.hx, dt, H, N, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
             a = ws.ha;
         }
+        // the last layer writes the caller's buffer; intermediate ones ping-pong through ws.xs (never an input of this loop)
+        char* dst = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
+        if (side_mlp) {
+            TRY(ag_side_mlp(a, H, N, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, stream));
+            x = dst;
+            continue;
+        }
         TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, stream));
         char* pre = (a == ws.hx) ? ws.ha : ws.hx;
         TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, N, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
-        // the last layer writes the caller's buffer; intermediate ones ping-pong through ws.xs (never an input of this loop)
-        char* dst = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
         TRY(ag_layernorm(pre, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst, nullptr, dt, stream));
         x = dst;
     }

@@ -238,6 +238,19 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     return out
 
 
+def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], ln_g: Optional[Tensor],
+             ln_b: Optional[Tensor], eps: float, post_ln: bool) -> Tensor:
+    """fused MLP half of a narrow layer (ag_side_mlp): x [M, h] bf16 -> [M, h] bf16."""
+    L.require_gpu(x, w1, w2, b1, b2, ln_g, ln_b)
+    x = x.contiguous()
+    m, h = x.shape
+    out = torch.empty_like(x)
+    with L.on(x.device):
+        L.check(L.lib().ag_side_mlp(L.ptr(x), h, m, h, w1.shape[0], L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(ln_g), L.ptr(ln_b),
+                                    float(eps), 1 if post_ln else 0, L.ptr(out), h, L.stream()))
+    return out
+
+
 def stat_slabs(h: int) -> int:
     return (h + 255) // 256
 

@@ -130,6 +130,17 @@ int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, 
             int M, int N, int K, int epilogue, int dtype,
             const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, void* stream);
 int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype);
+/* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
+ * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
+ * kernel, bf16:   post_ln = 0 (ViT, models/vanilla_vit.py:373-376):  out = x + fc2(gelu(fc1(LN(x))))     (ln_g NULL: no LN)
+ *                 post_ln = 1 (BERT, models/vanilla_bert.py:576-577,:601-603):  out = LN(x + fc2(gelu(fc1(x))))
+ * x [M, h] (row stride ldx), w1 [I, h], w2 [h, I] bf16, biases / LN parameters fp32, out [M, h] (row stride ldo).  Both weight
+ * matrices stay in LDS, the I-wide intermediate never leaves registers.  ag_side_mlp_supported: h in {32, 64, 96, 128},
+ * I % 32 == 0, weights fit the LDS.  Honours ag_dynamic_rows. */
+int ag_side_mlp_supported(int h, int I, int dtype);
+int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, const void* d_w1, const float* d_b1, const void* d_w2,
+                const float* d_b2, const float* d_ln_g, const float* d_ln_b, float ln_eps, int post_ln, void* d_out, int64_t ldo,
+                void* stream);
 /* row statistics (layout above) of a bf16 [rows,H] tensor -> d_stats [ceil(H/256), rows, 2]. */
 int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream);
 

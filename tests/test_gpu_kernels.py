@@ -374,3 +374,38 @@ def test_dynamic_row_counts(cuda_device, dtype):
     # the state is per host thread and was reset: an ordinary call afterwards sees its full row count
     full = ops.gemm(A, W, B, L.AG_EPI_BIAS, dtype)
     assert bool(torch.isfinite(full.float()).all()) and float(full[actual:].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("post_ln", [False, True])
+@pytest.mark.parametrize("m,h,i", [(1000, 96, 384), (257, 96, 384), (5000, 128, 256), (300, 64, 256), (33, 32, 128), (70000, 96, 384)])
+def test_side_mlp_fused(cuda_device, post_ln, m, h, i):
+    """ag_side_mlp (LN + fc1 + GELU + fc2 + residual of a narrow layer in one kernel, csrc/side_mlp.hip) against the numpy
+    oracle's layer arithmetic: ViT block x + fc2(gelu(fc1(LN(x)))) (models/vanilla_vit.py:373-376) and BERT block
+    LN(x + fc2(gelu(fc1(x)))) (models/vanilla_bert.py:576-577,:601-603); ragged row counts, every supported width."""
+    from autognothi_amd import _lib as L, ops
+    assert L.lib().ag_side_mlp_supported(h, i, BF16) == 1
+    g = np.random.default_rng(m + h + i)
+    x = _bf16_round((g.standard_normal((m, h)) * 1.3 + 0.2).astype(np.float32))
+    w1 = _bf16_round((g.standard_normal((i, h)) / np.sqrt(h)).astype(np.float32))
+    w2 = _bf16_round((g.standard_normal((h, i)) / np.sqrt(i)).astype(np.float32))
+    b1, b2 = g.standard_normal(i).astype(np.float32) * 0.3, g.standard_normal(h).astype(np.float32) * 0.3
+    gam, bet = (1 + 0.1 * g.standard_normal(h)).astype(np.float32), (0.1 * g.standard_normal(h)).astype(np.float32)
+    sd = {"ln.weight": gam, "ln.bias": bet}
+    eps = 1e-12
+    if post_ln:
+        f = _bf16_round(otr.gelu((x.astype(np.float64) @ w1.astype(np.float64).T + b1).astype(np.float32)))
+        ref = otr.layer_norm((f.astype(np.float64) @ w2.astype(np.float64).T + b2 + x).astype(np.float32), sd, "ln", eps)
+    else:
+        u = _bf16_round(otr.layer_norm(x, sd, "ln", eps))
+        f = _bf16_round(otr.gelu((u.astype(np.float64) @ w1.astype(np.float64).T + b1).astype(np.float32)))
+        ref = f.astype(np.float64) @ w2.astype(np.float64).T + b2 + x
+    dev = cuda_device
+    t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+    out = ops.side_mlp(t(x).to(torch.bfloat16), t(w1).to(torch.bfloat16), t(b1), t(w2).to(torch.bfloat16), t(b2), t(gam), t(bet), eps, post_ln)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=3e-2)
+    if not post_ln:   # Identity LayerNorm (explainer side layer 0: repl_norm_1 / no LN parameters)
+        f = _bf16_round(otr.gelu((x.astype(np.float64) @ w1.astype(np.float64).T + b1).astype(np.float32)))
+        ref = f.astype(np.float64) @ w2.astype(np.float64).T + b2 + x
+        out = ops.side_mlp(t(x).to(torch.bfloat16), t(w1).to(torch.bfloat16), t(b1), t(w2).to(torch.bfloat16), t(b2), None, None, eps, False)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=3e-2)
+    assert L.lib().ag_side_mlp_supported(24, 96, BF16) == 0 and L.lib().ag_side_mlp_supported(96, 384, F32) == 0

@@ -192,3 +192,26 @@ def test_torch_cpu_generator_state_fields_round_trip():
         h.manual_seed(1)
         h.set_state(ops.fill_torch_cpu_state(h.get_state(), mt, pos))
         assert torch.equal(torch.rand(1500, generator=h), torch.rand(1500, generator=g)), n
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a
+    child (before any GPU call) and leaves with its exit code; under a launcher (WORLD_SIZE set) or at N = 1 it does nothing."""
+    import argparse
+    import sys
+    import bench
+    calls = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench.maybe_spawn(argparse.Namespace(gpus=4))
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[-5]) == "bench.py" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    bench.maybe_spawn(argparse.Namespace(gpus=1))                 # single GPU: in-process
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.maybe_spawn(argparse.Namespace(gpus=4))                 # already a rank of a launched job
+    assert len(calls) == 1
