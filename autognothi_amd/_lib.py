@@ -54,6 +54,8 @@ SIGNATURES = {
     "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
     "ag_side_mlp_supported": (i32, [i32, i32, i32]),
     "ag_side_mlp": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp]),
+    "ag_side_linear_supported": (i32, [i32, i32, i32, i32]),
+    "ag_side_linear": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, f32, vp, i64, vp]),
     "ag_row_stats_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),

@@ -83,6 +83,8 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
     const bool vit = d->kind == AG_MASK_VIT_MUL;
     static const bool side_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
     const bool side_mlp = !side_off && ag_side_mlp_supported(H, I, dt);
+    const bool side_qkv = !side_off && ag_side_linear_supported(H, 3 * H, 0, dt);
+    const bool side_lin_o = !side_off && ag_side_linear_supported(H, H, 1, dt);
     if (chain_stats) ws.st1 = chain_stats;
     if (stats_written) *stats_written = 0;
 
@@ -115,6 +117,10 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
             if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
             TRY(ag_gemm(h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
                         ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, stream));
+        } else if (side_qkv) {
+            // narrow layer (LTT ladder): (LN1 +) QKV in one register-resident kernel
+            TRY(ag_side_linear(h_in, H, Min, H, 3 * H, w.w_qkv, w.b_qkv, vit ? w.ln1_g : nullptr, vit ? w.ln1_b : nullptr,
+                               nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, stream));
         } else {
             const char* att_in = h_in;
             if (vit && w.ln1_g) {
@@ -128,8 +134,18 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
         // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
+        // narrow layer: out-proj + residual (+ BERT's attention-output LayerNorm) fused; needs row-aligned residual rows
+        const bool side_o = side_lin_o && in_share == 1 && !last_cls;
+        bool ln1_done = false;
+        if (side_o) {
+            const bool post = !vit && w.ln1_g;
+            TRY(ag_side_linear(ws.ctx, H, Mo, H, H, w.w_o, w.b_o, nullptr, nullptr, h_in, H, post ? w.ln1_g : nullptr,
+                               post ? w.ln1_b : nullptr, d->ln_eps, post ? ws.ha : ws.hx, H, stream));
+            ln1_done = post;
+        } else {
         TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
                     nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, stream));
+        }
         if (vit) {
             if (side_mlp && !fold2) {
                 // narrow layer (LTT ladder): LN2 + fc1 + GELU + fc2 + residual in one register-resident kernel
@@ -151,7 +167,9 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
             if (chain_out && stats_written) *stats_written = next_fold1 ? 1 : 0;
         } else {
             const char* a = ws.hx;  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
-            if (w.ln1_g) {
+            if (ln1_done) {
+                a = ws.ha;
+            } else if (w.ln1_g) {
                 TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
                 a = ws.ha;
             }
@@ -312,16 +330,25 @@ extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const voi
     const char* x = (const char*)d_x;
     static const bool side_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
     const bool side_mlp = !side_off && ag_side_mlp_supported(H, I, dt);
+    const bool side_lin = !side_off && ag_side_linear_supported(H, 3 * H, 0, dt) && ag_side_linear_supported(H, H, 1, dt);
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         AG_REQUIRE(w.ln2_g, "ag_bert_layers_forward_packed: BERT output.LayerNorm missing in layer %d", l);
+        const char* a = ws.hx;
+        if (side_lin) {   // narrow layers (LTT ladder): QKV, and out-proj + residual + LayerNorm, as one kernel each
+            TRY(ag_side_linear(x, H, N, H, 3 * H, w.w_qkv, w.b_qkv, nullptr, nullptr, nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, stream));
+            TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
+            TRY(ag_side_linear(ws.ctx, H, N, H, H, w.w_o, w.b_o, nullptr, nullptr, x, H, w.ln1_g, w.ln1_b, d->ln_eps,
+                               w.ln1_g ? ws.ha : ws.hx, H, stream));
+            if (w.ln1_g) a = ws.ha;
+        } else {
         TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
         TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
         TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
-        const char* a = ws.hx;
         if (w.ln1_g) {
             TRY(ag_layernorm(ws.hx, dt, H, N, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
             a = ws.ha;
+        }
         }
         // the last layer writes the caller's buffer; intermediate ones ping-pong through ws.xs (never an input of this loop)
         char* dst = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;

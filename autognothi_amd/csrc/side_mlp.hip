@@ -228,6 +228,212 @@ __global__ __launch_bounds__(NT, 2) void side_mlp_kernel(SideArgs p) {
     }
 }
 
+// ---- one Linear of a narrow layer with its neighbours fused -------------------------------------------------------------
+//     out[M, N] = LN_post( resid + W . LN_pre(x) + b )          (each of LN_pre, resid, LN_post optional)
+// N <= 384 features out of h <= 128: the attention half of a side layer — LN1 + QKV (ViT, models/vanilla_vit.py:369,:437-441),
+// QKV alone (BERT), out-proj + residual (ViT :372,:477) and out-proj + residual + LN1 (BERT, models/vanilla_bert.py:557-559).
+// Same transposed, register-resident scheme as the MLP kernel; W (<= 80 KB) stays in LDS, two workgroups per CU.  The rows of W
+// are laid out in LDS so that an MFMA lane ends up with 8 CONSECUTIVE output features of a row (fragment row i of 16-block ob
+// holds feature 32 (ob >> 1) + 8 (i >> 2) + 4 (ob & 1) + (i & 3)): residual loads and output stores are 16 bytes per lane.
+struct LinArgs {
+    const bf16_t* x; long ldx;
+    const bf16_t* w; const float* b;     // [N, h], [N]
+    const bf16_t* resid; long ldr;       // [M, N] or NULL
+    bf16_t* out; long ldo;
+    const float* g0; const float* b0;    // LN_pre gamma / beta [h] or NULL
+    const float* g1; const float* b1;    // LN_post gamma / beta [N] or NULL (N <= 128)
+    float eps;
+    int M, h, N;
+    const int* dyn;
+};
+
+template <int H, bool POST>
+__global__ __launch_bounds__(NT, 2) void side_linear_kernel(LinArgs p) {
+    constexpr int KS = H / 32;
+    constexpr int W_ROWB = H * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = p.N;
+    char* const lw = smem;                                              // [N][W_ROWB], rows in fragment order
+    float* const lb = reinterpret_cast<float*>(lw + (size_t)N * W_ROWB);   // [N] bias, feature order
+    float* const lg0 = lb + N;                                          // [H]
+    float* const lb0 = lg0 + H;                                         // [H]
+    float* const lg1 = lb0 + H;                                         // [N]
+    float* const lb1 = lg1 + N;                                         // [N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int M = ag_dyn_clamp(p.M, p.dyn);
+    for (int i = tid; i < N * (H / 8); i += NT) {
+        const int dr = i / (H / 8), pc = i - dr * (H / 8);             // destination row = 16-block ob, fragment row fi
+        const int ob = dr >> 4, fi = dr & 15;
+        const int feat = 32 * (ob >> 1) + 8 * (fi >> 2) + 4 * (ob & 1) + (fi & 3);
+        *reinterpret_cast<uint4*>(lw + (size_t)dr * W_ROWB + pc * 16) = *reinterpret_cast<const uint4*>(p.w + (size_t)feat * H + pc * 8);
+    }
+    for (int i = tid; i < N; i += NT) {
+        lb[i] = p.b ? p.b[i] : 0.f;
+        lg1[i] = p.g1 ? p.g1[i] : 1.f;
+        lb1[i] = p.b1 ? p.b1[i] : 0.f;
+    }
+    for (int i = tid; i < H; i += NT) {
+        lg0[i] = p.g0 ? p.g0[i] : 1.f;
+        lb0[i] = p.b0 ? p.b0[i] : 0.f;
+    }
+    __syncthreads();
+    const int nchunks = (M + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE;
+    const float inv_h = 1.0f / (float)H, inv_n = 1.0f / (float)N;
+    for (int chunk = blockIdx.x * (NT / 64) + wave; chunk < nchunks; chunk += gridDim.x * (NT / 64)) {
+        const int row0 = chunk * ROWS_PER_WAVE;
+        uint4 xf[2][KS];
+        int rowc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int r = row0 + rb * 16 + c;
+            rowc[rb] = r < M ? r : M - 1;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+                xf[rb][s_] = *reinterpret_cast<const uint4*>(p.x + (size_t)rowc[rb] * p.ldx + s_ * 32 + q * 8);
+        }
+        if (p.g0) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float v[KS][8];
+                float sum = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const uint32_t w_[4] = {xf[rb][s_].x, xf[rb][s_].y, xf[rb][s_].z, xf[rb][s_].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[s_][2 * e] = __uint_as_float(w_[e] << 16);
+                        v[s_][2 * e + 1] = __uint_as_float(w_[e] & 0xFFFF0000u);
+                        sum += v[s_][2 * e] + v[s_][2 * e + 1];
+                    }
+                }
+                const float mean = quad_rows_sum(sum) * inv_h;
+                float sq = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dd = v[s_][e] - mean; sq = fmaf(dd, dd, sq); }
+                const float rstd = rsqrtf(quad_rows_sum(sq) * inv_h + p.eps);
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const int k0 = s_ * 32 + q * 8;
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = fmaf((v[s_][e] - mean) * rstd, lg0[k0 + e], lb0[k0 + e]);
+                    xf[rb][s_] = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+                }
+            }
+        }
+        // 32 output features (two 16-blocks) at a time: lane (q, c) ends with features 32 g + 8 q + {0..7} of row c
+        const int ngrp = N / 32;
+        float rsum[2] = {0.f, 0.f};
+        auto group = [&](const int g, float (&kp)[2][8]) {     // kp: where POST keeps this group's values (static index at the call)
+            f32x4_t d[2][2];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const float4 bias = *reinterpret_cast<const float4*>(lb + g * 32 + 8 * q + 4 * hb);
+                d[0][hb] = f32x4_t{bias.x, bias.y, bias.z, bias.w};
+                d[1][hb] = d[0][hb];
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(lw + (size_t)((2 * g + hb) * 16 + c) * W_ROWB + (s_ * 32 + q * 8) * 2);
+                    d[0][hb] = mfma(a, xf[0][s_], d[0][hb]);
+                    d[1][hb] = mfma(a, xf[1][s_], d[1][hb]);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float o[8] = {d[rb][0][0], d[rb][0][1], d[rb][0][2], d[rb][0][3], d[rb][1][0], d[rb][1][1], d[rb][1][2], d[rb][1][3]};
+                const int f0 = g * 32 + 8 * q;
+                if (p.resid) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(p.resid + (size_t)rowc[rb] * p.ldr + f0);
+                    const uint32_t w_[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[2 * e] += __uint_as_float(w_[e] << 16);
+                        o[2 * e + 1] += __uint_as_float(w_[e] & 0xFFFF0000u);
+                    }
+                }
+                if (POST) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { kp[rb][e] = o[e]; rsum[rb] += o[e]; }
+                } else {
+                    const int r = row0 + rb * 16 + c;
+                    if (r < M)
+                        *reinterpret_cast<uint4*>(p.out + (size_t)r * p.ldo + f0) =
+                            make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+                }
+            }
+        };
+        if (POST) {
+            float k0[2][8], k1[2][8], k2[2][8], k3[2][8];     // named (statically indexed) so that they stay in registers
+            group(0, k0);
+            if (ngrp > 1) group(1, k1);
+            if (ngrp > 2) group(2, k2);
+            if (ngrp > 3) group(3, k3);
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                mean[rb] = quad_rows_sum(rsum[rb]) * inv_n;
+                float sq = 0.f;
+                auto add_sq = [&](const float (&k)[2][8]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dd = k[rb][e] - mean[rb]; sq = fmaf(dd, dd, sq); }
+                };
+                add_sq(k0);
+                if (ngrp > 1) add_sq(k1);
+                if (ngrp > 2) add_sq(k2);
+                if (ngrp > 3) add_sq(k3);
+                rstd[rb] = rsqrtf(quad_rows_sum(sq) * inv_n + p.eps);
+            }
+            auto emit = [&](const int g, const float (&k)[2][8]) {
+                const int f0 = g * 32 + 8 * q;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = fmaf((k[rb][e] - mean[rb]) * rstd[rb], lg1[f0 + e], lb1[f0 + e]);
+                    const int r = row0 + rb * 16 + c;
+                    if (r < M)
+                        *reinterpret_cast<uint4*>(p.out + (size_t)r * p.ldo + f0) =
+                            make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+                }
+            };
+            emit(0, k0);
+            if (ngrp > 1) emit(1, k1);
+            if (ngrp > 2) emit(2, k2);
+            if (ngrp > 3) emit(3, k3);
+        } else {
+            float unused[2][8];
+            for (int g = 0; g < ngrp; ++g) group(g, unused);
+        }
+    }
+}
+
+size_t lin_lds_bytes(int h, int N) { return (size_t)N * (h * 2 + 16) + (size_t)(3 * N + 2 * h) * sizeof(float); }
+
+template <int H, bool POST>
+int launch_lin_p(const LinArgs& a, hipStream_t s) {
+    static size_t attr_bytes = 0;
+    const size_t lds = lin_lds_bytes(a.h, a.N);
+    if (lds > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(side_linear_kernel<H, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(side_linear): %s", hipGetErrorString(e));
+        attr_bytes = lds;
+    }
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int chunks = ceil_div(a.M, ROWS_PER_WAVE), want = ceil_div(chunks, NT / 64);
+    const int grid = want < 256 * per_cu ? want : 256 * per_cu;
+    hipLaunchKernelGGL((side_linear_kernel<H, POST>), dim3(grid), dim3(NT), lds, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+template <int H>
+int launch_lin(const LinArgs& a, hipStream_t s) {
+    return a.g1 ? launch_lin_p<H, true>(a, s) : launch_lin_p<H, false>(a, s);
+}
+
 size_t side_lds_bytes(int h, int I) {
     return (size_t)I * (h * 2 + 16) + (size_t)h * (I * 2 + 16) + (size_t)(I + 3 * h) * sizeof(float);
 }
@@ -276,5 +482,33 @@ extern "C" int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, co
         case 64: return launch_side<64>(a, s);
         case 96: return launch_side<96>(a, s);
         default: return launch_side<128>(a, s);
+    }
+}
+
+extern "C" int ag_side_linear_supported(int h, int N, int post_ln, int dtype) {
+    return (dtype == AG_BF16 && (h == 32 || h == 64 || h == 96 || h == 128) && N >= 32 && N % 32 == 0 && N <= 384 &&
+            (!post_ln || N <= 128) && lin_lds_bytes(h, N) <= 160 * 1024) ? 1 : 0;
+}
+
+extern "C" int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N, const void* d_w, const float* d_b,
+                              const float* d_pre_g, const float* d_pre_b, const void* d_resid, int64_t ldr,
+                              const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, void* stream) {
+    if (M == 0) return AG_OK;
+    AG_REQUIRE(d_x && d_w && d_out && M > 0, "ag_side_linear: null pointer");
+    AG_REQUIRE(ag_side_linear_supported(h, N, d_post_g != nullptr, AG_BF16), "ag_side_linear: h=%d N=%d unsupported", h, N);
+    AG_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && (!d_resid || ldr % 8 == 0), "ag_side_linear: rows must be 16-byte aligned");
+    AG_REQUIRE((d_pre_g == nullptr) == (d_pre_b == nullptr) && (d_post_g == nullptr) == (d_post_b == nullptr), "ag_side_linear: gamma without beta");
+    LinArgs a;
+    a.x = (const bf16_t*)d_x; a.ldx = ldx; a.w = (const bf16_t*)d_w; a.b = d_b; a.resid = (const bf16_t*)d_resid; a.ldr = ldr;
+    a.out = (bf16_t*)d_out; a.ldo = ldo; a.g0 = d_pre_g; a.b0 = d_pre_b; a.g1 = d_post_g; a.b1 = d_post_b; a.eps = ln_eps;
+    a.M = M; a.h = h; a.N = N; a.dyn = g_ag_dyn_rows;
+    hipStream_t s = (hipStream_t)stream;
+    AgProfScope prof(d_resid ? AG_EPI_BIAS_RESID : AG_EPI_BIAS, 2.0 * M * (double)h * N,
+                     (double)M * (h + N + (d_resid ? N : 0)) * 2.0 + 2.0 * h * N, s, g_ag_dyn_rows ? (double)M : 0.0);
+    switch (h) {
+        case 32: return launch_lin<32>(a, s);
+        case 64: return launch_lin<64>(a, s);
+        case 96: return launch_lin<96>(a, s);
+        default: return launch_lin<128>(a, s);
     }
 }

@@ -251,6 +251,23 @@ def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Option
     return out
 
 
+def side_linear(x: Tensor, w: Tensor, b: Optional[Tensor], pre_ln=None, resid: Optional[Tensor] = None, post_ln=None,
+                eps: float = 1e-12) -> Tensor:
+    """fused narrow Linear (ag_side_linear): LN_post(resid + W . LN_pre(x) + b); pre_ln / post_ln = (gamma, beta) or None."""
+    L.require_gpu(x, w, b, resid)
+    x = x.contiguous()
+    m, h = x.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    g0, b0 = pre_ln if pre_ln is not None else (None, None)
+    g1, b1 = post_ln if post_ln is not None else (None, None)
+    r = resid.contiguous() if resid is not None else None
+    with L.on(x.device):
+        L.check(L.lib().ag_side_linear(L.ptr(x), h, m, h, n, L.ptr(w), L.ptr(b), L.ptr(g0), L.ptr(b0), L.ptr(r), n, L.ptr(g1), L.ptr(b1),
+                                       float(eps), L.ptr(out), n, L.stream()))
+    return out
+
+
 def stat_slabs(h: int) -> int:
     return (h + 255) // 256
 

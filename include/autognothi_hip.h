@@ -141,6 +141,15 @@ int ag_side_mlp_supported(int h, int I, int dtype);
 int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, const void* d_w1, const float* d_b1, const void* d_w2,
                 const float* d_b2, const float* d_ln_g, const float* d_ln_b, float ln_eps, int post_ln, void* d_out, int64_t ldo,
                 void* stream);
+/* One Linear of a narrow layer with its neighbours fused (bf16; the attention half of the ladder's side layers):
+ *     out[M, N] = LN_post( resid + W . LN_pre(x) + b )       each of LN_pre (gamma/beta over h), resid [M,N], LN_post (over N) optional
+ * = LN1 + QKV (ViT, models/vanilla_vit.py:369,:437-441), QKV (BERT), out-proj + residual (ViT :372,:477), out-proj + residual +
+ * attention-output LayerNorm (BERT, models/vanilla_bert.py:557-559).  x [M, h], W [N, h]; h in {32,64,96,128}, N % 32 == 0,
+ * N <= 384 (LN_post: N <= 128).  Honours ag_dynamic_rows. */
+int ag_side_linear_supported(int h, int N, int post_ln, int dtype);
+int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N, const void* d_w, const float* d_b,
+                   const float* d_pre_g, const float* d_pre_b, const void* d_resid, int64_t ldr,
+                   const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, void* stream);
 /* row statistics (layout above) of a bf16 [rows,H] tensor -> d_stats [ceil(H/256), rows, 2]. */
 int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream);
 

@@ -409,3 +409,35 @@ def test_side_mlp_fused(cuda_device, post_ln, m, h, i):
         out = ops.side_mlp(t(x).to(torch.bfloat16), t(w1).to(torch.bfloat16), t(b1), t(w2).to(torch.bfloat16), t(b2), None, None, eps, False)
         np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=3e-2)
     assert L.lib().ag_side_mlp_supported(24, 96, BF16) == 0 and L.lib().ag_side_mlp_supported(96, 384, F32) == 0
+
+
+@pytest.mark.parametrize("m,h,n,pre,res,post", [(1000, 96, 288, True, False, False), (257, 96, 288, False, False, False),
+                                                (1000, 96, 96, False, True, False), (3001, 96, 96, False, True, True),
+                                                (500, 128, 384, True, False, False), (300, 64, 64, False, True, True),
+                                                (90, 32, 96, True, True, False), (70000, 96, 288, True, False, False)])
+def test_side_linear_fused(cuda_device, m, h, n, pre, res, post):
+    """ag_side_linear: LN_post(resid + W . LN_pre(x) + b) for the attention half of a narrow layer — LN1 + QKV (ViT
+    models/vanilla_vit.py:369,:437-441), QKV (BERT), out-proj + residual (ViT :372,:477), out-proj + residual + LayerNorm
+    (BERT models/vanilla_bert.py:557-559) — against the numpy oracle; the output feature permutation inside the kernel
+    (16-byte stores) must be invisible."""
+    from autognothi_amd import _lib as L, ops
+    assert L.lib().ag_side_linear_supported(h, n, 1 if post else 0, BF16) == 1
+    g = np.random.default_rng(m + h + n)
+    x = _bf16_round((g.standard_normal((m, h)) * 1.3 + 0.2).astype(np.float32))
+    w = _bf16_round((g.standard_normal((n, h)) / np.sqrt(h)).astype(np.float32))
+    b = (g.standard_normal(n) * 0.3).astype(np.float32)
+    r = _bf16_round(g.standard_normal((m, n)).astype(np.float32))
+    g0, b0 = (1 + 0.1 * g.standard_normal(h)).astype(np.float32), (0.1 * g.standard_normal(h)).astype(np.float32)
+    g1, b1 = (1 + 0.1 * g.standard_normal(n)).astype(np.float32), (0.1 * g.standard_normal(n)).astype(np.float32)
+    eps = 1e-12
+    u = _bf16_round(otr.layer_norm(x, {"ln.weight": g0, "ln.bias": b0}, "ln", eps)) if pre else x
+    ref = u.astype(np.float64) @ w.astype(np.float64).T + b
+    if res:
+        ref = ref + r
+    if post:
+        ref = otr.layer_norm(ref.astype(np.float32), {"ln.weight": g1, "ln.bias": b1}, "ln", eps)
+    t = lambda a: torch.from_numpy(a).to(cuda_device)   # noqa: E731
+    out = ops.side_linear(t(x).to(torch.bfloat16), t(w).to(torch.bfloat16), t(b), (t(g0), t(b0)) if pre else None,
+                          t(r).to(torch.bfloat16) if res else None, (t(g1), t(b1)) if post else None, eps)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=3e-2)
+    assert L.lib().ag_side_linear_supported(96, 288, 1, BF16) == 0      # a LayerNorm over 288 outputs is not built
