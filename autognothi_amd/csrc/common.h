@@ -146,6 +146,11 @@ __device__ __forceinline__ int ag_dyn_clamp(int rows, const int* dyn) {
     return rows;
 }
 
+// side_mlp.hip: wide -> narrow Linear (+ GELU, + additive residual) with the weights resident in LDS
+bool ag_side_map_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, bool has_resid);
+int ag_side_map(const void* d_x, int64_t ldx, const void* d_w, const float* d_b, const void* d_resid, int64_t ldr, void* d_out,
+                int64_t ldo, int M, int N, int K, int gelu, hipStream_t s);
+
 // gemm_big.hip
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,

@@ -434,6 +434,132 @@ int launch_lin(const LinArgs& a, hipStream_t s) {
     return a.g1 ? launch_lin_p<H, true>(a, s) : launch_lin_p<H, false>(a, s);
 }
 
+// ---- the ladder's map: a wide stream into a narrow one -------------------------------------------------------------------
+//     out[M, N] = resid + gelu(W[N, K] . x + b)        N <= 128 features out of K = 768 (reference models/ltt_vit.py:431
+// `side = side + gelu(map(hidden))`, models/ltt_bert.py:492).  HBM-bound: the 768-wide backbone stream is read once; W (147 KB for
+// 96 x 768) fills the LDS of a CU for the whole launch; a wave walks K in 32-deep steps with its 32 rows' fragments loaded straight
+// from global memory (8 loads in flight), 6 weight fragments from LDS and 12 MFMAs per step.
+struct MapArgs {
+    const bf16_t* x; long ldx;
+    const bf16_t* w; const float* b;
+    const bf16_t* resid; long ldr;
+    bf16_t* out; long ldo;
+    int M, N, K, gelu;
+    const int* dyn;
+};
+
+template <int NOUT>
+__global__ __launch_bounds__(NT, 2) void side_map_kernel(MapArgs p) {
+    constexpr int OB = NOUT / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = p.K, W_ROWB = K * 2 + 16;
+    char* const lw = smem;                                                  // [NOUT][W_ROWB], rows in fragment order
+    float* const lb = reinterpret_cast<float*>(lw + (size_t)NOUT * W_ROWB);   // [NOUT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    const int M = ag_dyn_clamp(p.M, p.dyn);
+    for (int i = tid; i < NOUT * (K / 8); i += NT) {
+        const int dr = i / (K / 8), pc = i - dr * (K / 8);
+        const int ob = dr >> 4, fi = dr & 15;
+        const int feat = 32 * (ob >> 1) + 8 * (fi >> 2) + 4 * (ob & 1) + (fi & 3);      // lane ends with 8 consecutive features
+        *reinterpret_cast<uint4*>(lw + (size_t)dr * W_ROWB + pc * 16) = *reinterpret_cast<const uint4*>(p.w + (size_t)feat * K + pc * 8);
+    }
+    for (int i = tid; i < NOUT; i += NT) lb[i] = p.b ? p.b[i] : 0.f;
+    __syncthreads();
+    const int nchunks = (M + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE;
+    const int nks = K / 32;
+    for (int chunk = blockIdx.x * (NT / 64) + wave; chunk < nchunks; chunk += gridDim.x * (NT / 64)) {
+        const int row0 = chunk * ROWS_PER_WAVE;
+        const bf16_t* xr[2];
+        int rowc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int r = row0 + rb * 16 + c;
+            rowc[rb] = r < M ? r : M - 1;
+            xr[rb] = p.x + (size_t)rowc[rb] * p.ldx + q * 8;
+        }
+        f32x4_t acc[2][OB];
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) {
+            const float4 bias = *reinterpret_cast<const float4*>(lb + 32 * (ob >> 1) + 8 * q + 4 * (ob & 1));
+            acc[0][ob] = f32x4_t{bias.x, bias.y, bias.z, bias.w};
+            acc[1][ob] = acc[0][ob];
+        }
+        // K loop, PF steps of activations (2 x PF KiB per wave) in flight: the stream is HBM-bound
+        constexpr int PF = 8;
+        uint4 xb[PF][2];
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) xb[j][rb] = *reinterpret_cast<const uint4*>(xr[rb] + (j < nks ? j : 0) * 32);
+        for (int s0 = 0; s0 < nks; s0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int s_ = s0 + j;
+                if (s_ < nks) {
+                    const uint4 x0 = xb[j][0], x1 = xb[j][1];
+                    const int nx = s_ + PF;
+                    if (nx < nks) {
+                        xb[j][0] = *reinterpret_cast<const uint4*>(xr[0] + nx * 32);
+                        xb[j][1] = *reinterpret_cast<const uint4*>(xr[1] + nx * 32);
+                    }
+#pragma unroll
+                    for (int ob = 0; ob < OB; ++ob) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(lw + (size_t)(ob * 16 + c) * W_ROWB + (s_ * 32 + q * 8) * 2);
+                        acc[0][ob] = mfma(a, x0, acc[0][ob]);
+                        acc[1][ob] = mfma(a, x1, acc[1][ob]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int r = row0 + rb * 16 + c;
+#pragma unroll
+            for (int g = 0; g < OB / 2; ++g) {
+                float o[8] = {acc[rb][2 * g][0], acc[rb][2 * g][1], acc[rb][2 * g][2], acc[rb][2 * g][3],
+                              acc[rb][2 * g + 1][0], acc[rb][2 * g + 1][1], acc[rb][2 * g + 1][2], acc[rb][2 * g + 1][3]};
+                if (p.gelu) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) { const f32x2_t gg = fast_gelu2(f32x2_t{o[e], o[e + 1]}); o[e] = gg.x; o[e + 1] = gg.y; }
+                }
+                const int f0 = g * 32 + 8 * q;
+                if (p.resid) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(p.resid + (size_t)rowc[rb] * p.ldr + f0);
+                    const uint32_t w_[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[2 * e] += __uint_as_float(w_[e] << 16);
+                        o[2 * e + 1] += __uint_as_float(w_[e] & 0xFFFF0000u);
+                    }
+                }
+                if (r < M)
+                    *reinterpret_cast<uint4*>(p.out + (size_t)r * p.ldo + f0) =
+                        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            }
+        }
+    }
+}
+
+size_t map_lds_bytes(int N, int K) { return (size_t)N * (K * 2 + 16) + (size_t)N * sizeof(float); }
+
+template <int NOUT>
+int launch_map(const MapArgs& a, hipStream_t s) {
+    static size_t attr_bytes = 0;
+    const size_t lds = map_lds_bytes(a.N, a.K);
+    if (lds > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(side_map_kernel<NOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(side_map): %s", hipGetErrorString(e));
+        attr_bytes = lds;
+    }
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int chunks = ceil_div(a.M, ROWS_PER_WAVE), want = ceil_div(chunks, NT / 64);
+    const int grid = want < 256 * per_cu ? want : 256 * per_cu;
+    hipLaunchKernelGGL(side_map_kernel<NOUT>, dim3(grid), dim3(NT), lds, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 size_t side_lds_bytes(int h, int I) {
     return (size_t)I * (h * 2 + 16) + (size_t)h * (I * 2 + 16) + (size_t)(I + 3 * h) * sizeof(float);
 }
@@ -510,5 +636,25 @@ extern "C" int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N,
         case 64: return launch_lin<64>(a, s);
         case 96: return launch_lin<96>(a, s);
         default: return launch_lin<128>(a, s);
+    }
+}
+
+// wide -> narrow Linear with (GELU and) an additive residual, weights resident in LDS: selected by ag_gemm for the ladder's map
+bool ag_side_map_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, bool has_resid) {
+    return M >= 2048 && (N == 32 || N == 64 || N == 96 || N == 128) && K % 32 == 0 && K >= 128 && lda % 8 == 0 && ldc % 8 == 0 &&
+           (!has_resid || ldr % 8 == 0) && (epilogue == AG_EPI_BIAS_GELU || epilogue == AG_EPI_BIAS_GELU_ADD) &&
+           map_lds_bytes(N, K) <= 160 * 1024;
+}
+
+int ag_side_map(const void* d_x, int64_t ldx, const void* d_w, const float* d_b, const void* d_resid, int64_t ldr, void* d_out,
+                int64_t ldo, int M, int N, int K, int gelu, hipStream_t s) {
+    MapArgs a;
+    a.x = (const bf16_t*)d_x; a.ldx = ldx; a.w = (const bf16_t*)d_w; a.b = d_b; a.resid = (const bf16_t*)d_resid; a.ldr = ldr;
+    a.out = (bf16_t*)d_out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.dyn = g_ag_dyn_rows;
+    switch (N) {
+        case 32: return launch_map<32>(a, s);
+        case 64: return launch_map<64>(a, s);
+        case 96: return launch_map<96>(a, s);
+        default: return launch_map<128>(a, s);
     }
 }

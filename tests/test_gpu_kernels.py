@@ -157,7 +157,8 @@ def test_masked_attention_narrow_heads(cuda_device, dtype, mode, d, t, heads, ro
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("m,n,k", [(394, 96, 768), (197, 24, 192), (260, 288, 96), (130, 96, 384), (64, 40, 24)])
+@pytest.mark.parametrize("m,n,k", [(394, 96, 768), (197, 24, 192), (260, 288, 96), (130, 96, 384), (64, 40, 24),
+                                   (2100, 96, 768), (70001, 96, 768), (3000, 128, 256), (2500, 64, 1024), (2049, 32, 128)])
 def test_gemm_ladder_shapes(cuda_device, dtype, m, n, k):
     """LTT ladder GEMMs: K not a multiple of the 128-byte LDS slice (zero-sourced K tail) and the
     side = side + gelu(Linear(hidden)) epilogue (reference models/ltt_vit.py:431)."""
@@ -176,6 +177,10 @@ def test_gemm_ladder_shapes(cuda_device, dtype, m, n, k):
     np.testing.assert_allclose(ops.gemm(A, W, B, L.AG_EPI_BIAS_F32, dtype).cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
     out = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=R).float().cpu().numpy()
     np.testing.assert_allclose(out, otr.gelu(ref.astype(np.float32)) + r, **tol)
+    # (bf16, M >= 2048, N in {32, 64, 96, 128}: the LDS-resident map kernel of csrc/side_mlp.hip, also for the first ladder layer's
+    # plain GELU epilogue)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, dtype).float().cpu().numpy()
+    np.testing.assert_allclose(out, otr.gelu(ref.astype(np.float32)), **tol)
     # NaN/Inf in the bytes after a row must not leak into the K tail: the tail chunks come from a zero buffer
     pad = torch.full((m, k + 40), float("nan"), device=cuda_device, dtype=A.dtype)
     pad[:, :k] = A
