@@ -517,6 +517,13 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
 
 // Eligibility: bf16, vectorisable epilogue, K a multiple of 32 with at least 4 half-steps.
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue) {
+    // Problems of fewer than 48 tiles (< 1/5 of the CUs busy, each for a whole 256^2 tile's latency) go to the 128 / 64-tile
+    // kernel: more, shorter workgroups.  These are the explainer-training GEMMs (M = 8 images x 197 tokens: 7 row panels):
+    // training step +11 % (vanilla ViT-base) / +23 % (duo BERT-base) at 8 images; a threshold of 100 would also catch the
+    // N = 768 GEMMs of a single-input inference step (75 tiles, K up to 3072), where the ring is 7 % faster.
+    const char* mt = getenv("AG_GEMM_BIG_MIN_TILES");       // (read per call: the kernel parity tests pin the ring with it)
+    const int min_tiles = mt ? atoi(mt) : 48;
+    if ((long)ceil_div(M, BT) * ceil_div(N, BT) < min_tiles) return false;
     return M >= 1024 && N >= 256 && (N % 8) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);
 }
