@@ -70,6 +70,7 @@ SIGNATURES = {
     "ag_kl_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "ag_transpose_f32": (i32, [vp, i32, i32, i64, vp, i64, vp]),
     "ag_transpose_f32_bf16": (i32, [vp, i32, i32, i64, vp, i64, vp]),
+    "ag_cast_transpose_f32_bf16": (i32, [vp, i32, i32, i64, vp, vp, i64, vp]),
     "ag_colsum_f32": (i32, [vp, i32, i32, i64, vp, i32, vp]),
     "ag_gelu_f32": (i32, [vp, vp, i64, vp]),
     "ag_gelu_bwd_f32": (i32, [vp, vp, vp, i64, vp]),

@@ -28,13 +28,19 @@ __global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, i
 
 // the same with a bf16 destination (mixed-precision dW operands: transpose and cast in one pass); the WHOLE padded
 // destination [Cc, ldd] is written (zeros beyond R), so the caller needs no memset
-__global__ void transpose_bf16_kernel(const float* __restrict__ src, int R, int Cc, int64_t lds_, bf16_t* __restrict__ dst, int64_t ldd) {
+// `plain` (optional): the un-transposed bf16 copy [R, Cc] from the same pass — a mixed-precision Linear needs x and x^T (dy and
+// dy^T, W and W^T) as bf16 operands: one launch instead of a cast plus a transpose
+__global__ void transpose_bf16_kernel(const float* __restrict__ src, int R, int Cc, int64_t lds_, bf16_t* __restrict__ dst, int64_t ldd,
+                                      bf16_t* __restrict__ plain) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = by + i, c = bx + tx;
-        tile[i][tx] = (r < R && c < Cc) ? src[(int64_t)r * lds_ + c] : 0.f;
+        const bool in = r < R && c < Cc;
+        const float v = in ? src[(int64_t)r * lds_ + c] : 0.f;
+        tile[i][tx] = v;
+        if (plain && in) plain[(int64_t)r * Cc + c] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu);
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -667,7 +673,16 @@ extern "C" int ag_transpose_f32_bf16(const float* d_src, int rows, int cols, int
     AG_REQUIRE(d_src && d_dst && rows >= 0 && cols >= 0 && lds >= cols && ldd >= rows, "ag_transpose_f32_bf16: bad arguments");
     if (rows == 0 || cols == 0) return AG_OK;
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(ldd, 32)), dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, lds,
-                       (bf16_t*)d_dst, ldd);
+                       (bf16_t*)d_dst, ldd, (bf16_t*)nullptr);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+extern "C" int ag_cast_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_plain, void* d_dst_t, int64_t ldd,
+                                          void* stream) {
+    AG_REQUIRE(d_src && d_plain && d_dst_t && rows >= 0 && cols >= 0 && lds >= cols && ldd >= rows, "ag_cast_transpose_f32_bf16: bad arguments");
+    if (rows == 0 || cols == 0) return AG_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 32), ceil_div(ldd, 32)), dim3(256), 0, (hipStream_t)stream, d_src, rows, cols, lds,
+                       (bf16_t*)d_dst_t, ldd, (bf16_t*)d_plain);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

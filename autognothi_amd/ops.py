@@ -432,6 +432,18 @@ def transpose_bf16(src: Tensor, pad_cols_to: int = 1) -> Tensor:
     return dst
 
 
+def cast_transpose_bf16(src: Tensor, pad_cols_to: int = 1) -> Tuple[Tensor, Tensor]:
+    """[R,C] fp32 -> ([R,C] bf16, [C,Rp] bf16): both operand forms of a mixed-precision Linear in one launch."""
+    s = _f32c(src)
+    r, c = s.shape
+    rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    plain = torch.empty((r, c), dtype=torch.bfloat16, device=s.device)
+    dst = torch.empty((c, rp), dtype=torch.bfloat16, device=s.device)
+    with L.on(s.device):
+        L.check(L.lib().ag_cast_transpose_f32_bf16(L.ptr(s), r, c, c, L.ptr(plain), L.ptr(dst), rp, L.stream()))
+    return plain, dst
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     x = _f32c(x)
     m, n = x.shape

@@ -111,6 +111,7 @@ class Lin:
     def __init__(self, mods: Sequence[nn.Module]):
         self.mods = list(mods)
         self.x: Optional[Tensor] = None
+        self.xt: Optional[Tensor] = None      # mixed mode: X^T bf16 [K, Mp] saved instead of x (the dW operand)
 
     def _key(self):
         return tuple((p.data_ptr(), p._version) for m in self.mods for p in (m.weight, m.bias))
@@ -138,53 +139,90 @@ class Lin:
                 d[form] = ops.cast(w, L.AG_BF16)
             elif form == "t":
                 d[form] = ops.transpose(w, pad_cols_to=PAD) if w.shape[0] % PAD else ops.transpose(w)
-            elif form == "t_bf16":
-                d[form] = ops.cast(self._w_form("t"), L.AG_BF16)
+            elif form == "t_bf16":     # transpose + round in one pass (no fp32 transposed copy, no cast launch)
+                d[form] = ops.transpose_bf16(w, pad_cols_to=PAD)
         return d[form]
 
     def trainable(self) -> bool:
         return any(p.requires_grad for m in self.mods for p in (m.weight, m.bias))
 
+    def _w_pair(self) -> Tuple[Tensor, Tensor]:
+        """(W bf16 [N,K], W^T bf16 [K,Np]) of the current weight from ONE launch (they change with every optimiser step)."""
+        w, _ = self._w()
+        d = self._derived
+        if "pair" not in d:
+            d["pair"] = ops.cast_transpose_bf16(w, pad_cols_to=PAD)
+        return d["pair"]
+
     def forward(self, x: Tensor, epilogue: int = L.AG_EPI_BIAS, save: bool = True) -> Tensor:
         w, b = self._w()
+        mixed = MIXED_BF16 and epilogue in (L.AG_EPI_BIAS, L.AG_EPI_BIAS_F32) and x.shape[-1] % 8 == 0
+        self.xt = None
+        if mixed:
+            # bf16 operands, fp32 accumulate / output.  A trainable Linear needs x^T for dW later: both forms in one launch
+            wb = self._w_pair()[0]
+            if save and self.trainable():
+                xb, self.xt = ops.cast_transpose_bf16(x, pad_cols_to=PAD)
+            else:
+                xb = ops.cast(x, L.AG_BF16)
+                if save:
+                    self.x = x
+            return ops.gemm(xb, wb, b, L.AG_EPI_BIAS_F32, L.AG_BF16, m=x.shape[0])
         if save:
             self.x = x
-        mixed = MIXED_BF16 and epilogue in (L.AG_EPI_BIAS, L.AG_EPI_BIAS_F32) and x.shape[-1] % 8 == 0
-        return _mm(x, w, b, epilogue, x.shape[0], self._w_form("bf16") if mixed else None)
+        return _mm(x, w, b, epilogue, x.shape[0], None)
 
     def backward(self, dy: Tensor, need_dx: bool = True) -> Optional[Tensor]:
         w, _ = self._w()
         n, k = w.shape
         m = dy.shape[0]
         dx = None
-        if need_dx:
-            # dX[M,K] = dY[M,N] · W[N,K]  ==  NT GEMM against Wᵀ [K, N]; pad N (the contraction) to 32
-            wt = self._w_form("t")
-            if n % PAD:
-                npad = (n + PAD - 1) // PAD * PAD
-                dyp = torch.zeros((m, npad), dtype=torch.float32, device=dy.device)
-                dyp[:, :n].copy_(dy)
-                dx = _mm(dyp, wt, None, L.AG_EPI_BIAS, m, self._w_form("t_bf16") if MIXED_BF16 else None)
+        train = self.trainable()
+        if MIXED_BF16 and n % PAD == 0 and k % 8 == 0:
+            # dy and dy^T as bf16 from one launch; dX = dY . W against W^T [K, N], dW = dY^T . X against X^T [K, Mp]
+            if train:
+                dyb, dyt = ops.cast_transpose_bf16(dy, pad_cols_to=PAD)
             else:
-                dx = _mm(dy, wt, None, L.AG_EPI_BIAS, m, self._w_form("t_bf16") if MIXED_BF16 else None)
-        if self.trainable():
-            # dW[N,K] = dYᵀ[N,M] · X[M,K]  ==  NT GEMM of dYᵀ [N,Mp] against Xᵀ [K,Mp]
-            if MIXED_BF16:   # (Mp % 32 == 0 keeps the bf16 rows 16-byte aligned)
-                dw = ops.gemm(ops.transpose_bf16(dy, pad_cols_to=PAD), ops.transpose_bf16(self.x, pad_cols_to=PAD), None,
-                              L.AG_EPI_BIAS_F32, L.AG_BF16, m=n)
-            else:
-                dw = _mm(ops.transpose(dy, pad_cols_to=PAD), ops.transpose(self.x, pad_cols_to=PAD), None, L.AG_EPI_BIAS, n)
+                dyb, dyt = ops.cast(dy, L.AG_BF16), None
+            if need_dx:
+                dx = ops.gemm(dyb, self._w_pair()[1], None, L.AG_EPI_BIAS_F32, L.AG_BF16, m=m)
+            if train:
+                xt = self.xt if self.xt is not None else ops.transpose_bf16(self.x, pad_cols_to=PAD)
+                dw = ops.gemm(dyt, xt, None, L.AG_EPI_BIAS_F32, L.AG_BF16, m=n)
+        else:
+            if need_dx:
+                # dX[M,K] = dY[M,N] · W[N,K]  ==  NT GEMM against Wᵀ [K, N]; pad N (the contraction) to 32
+                wt = self._w_form("t")
+                wt_b = self._w_form("t_bf16") if MIXED_BF16 else None
+                if n % PAD:
+                    npad = (n + PAD - 1) // PAD * PAD
+                    dyp = torch.zeros((m, npad), dtype=torch.float32, device=dy.device)
+                    dyp[:, :n].copy_(dy)
+                    dx = _mm(dyp, wt, None, L.AG_EPI_BIAS, m, wt_b)
+                else:
+                    dx = _mm(dy, wt, None, L.AG_EPI_BIAS, m, wt_b)
+            if train:
+                # dW[N,K] = dYᵀ[N,M] · X[M,K]  ==  NT GEMM of dYᵀ [N,Mp] against Xᵀ [K,Mp]
+                if MIXED_BF16:   # (Mp % 32 == 0 keeps the bf16 rows 16-byte aligned)
+                    xt = self.xt if self.xt is not None else ops.transpose_bf16(self.x, pad_cols_to=PAD)
+                    dw = ops.gemm(ops.transpose_bf16(dy, pad_cols_to=PAD), xt, None, L.AG_EPI_BIAS_F32, L.AG_BF16, m=n)
+                else:
+                    dw = _mm(ops.transpose(dy, pad_cols_to=PAD), ops.transpose(self.x, pad_cols_to=PAD), None, L.AG_EPI_BIAS, n)
+        if train:
             db = ops.colsum(dy)
             off = 0
             for mod in self.mods:
                 rows = mod.weight.shape[0]
                 whole = len(self.mods) == 1
+                # (row slices of the fused q|k|v gradient are contiguous and nobody else holds dw / db: they become the .grad
+                # tensors themselves, three views of one buffer, instead of three copies)
                 if mod.weight.requires_grad:
-                    _acc_grad(mod.weight, dw[off:off + rows] if not whole else dw, fresh=whole)
+                    _acc_grad(mod.weight, dw[off:off + rows] if not whole else dw, fresh=True)
                 if mod.bias.requires_grad:
-                    _acc_grad(mod.bias, db[off:off + rows] if not whole else db, fresh=whole)
+                    _acc_grad(mod.bias, db[off:off + rows] if not whole else db, fresh=True)
                 off += rows
         self.x = None
+        self.xt = None
         return dx
 
 
@@ -293,7 +331,7 @@ def _module_n_players(m: nn.Module) -> int:
 def _drop_block_saved(blk: "Block") -> None:
     blk.saved = None
     for lin in (blk.qkv, blk.o, blk.fc1, blk.fc2):
-        lin.x = None
+        lin.x = lin.xt = None
     blk.n1.x = blk.n2.x = None
 
 
@@ -341,7 +379,7 @@ class ViTBackboneTrainer:
         """forget the activations of a forward whose backward will not run (frozen backbone)."""
         for blk in self.blocks:
             _drop_block_saved(blk)
-        self.ln_f.x = self.proj.x = None
+        self.ln_f.x = self.proj.x = self.proj.xt = None
         self.saved = None
 
     def backward(self, dz: Tensor) -> None:
@@ -543,9 +581,9 @@ class ExplainerTrainer:
             dz_extra = torch.zeros((b, t, h), dtype=torch.float32, device=dphi.device)
             dz_extra[:, 0, :].copy_(dz_cls)
         elif self.duo:
-            self.cls.x = None
+            self.cls.x = self.cls.xt = None
             if self.pool is not None:
-                self.pool.x = None
+                self.pool.x = self.pool.xt = None
         dpred = ops.shapley_normalize_bwd(dphi, t, normalize=bool(cfg.explainer_normalize)).view(b * t, c)
         d = ops.dropout(self.mlp.backward(dpred), ph, s_exp)
         for blk in reversed(self.attn):

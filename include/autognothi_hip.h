@@ -277,6 +277,9 @@ int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t lds, float*
 /* The same with a bf16 destination (mixed-precision training: the dW operands dYᵀ, Xᵀ are transposed and rounded in one
  * pass); every element of dst [cols, ldd] is written, zeros beyond `rows`. */
 int ag_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_dst, int64_t ldd, void* stream);
+/* Both bf16 operand forms of an fp32 matrix in one pass: d_plain [rows, cols] (dense) and d_dst_t [cols, ldd] (as above). */
+int ag_cast_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_plain, void* d_dst_t, int64_t ldd,
+                               void* stream);
 /* out[n] (+)= sum_m x[m, n]  (bias gradients). */
 int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream);
 /* exact-erf GELU (nn.GELU default) and its derivative: du = dy * gelu'(u). */

@@ -15,7 +15,7 @@ engine.set_precision("bf16")
 srg = recipe.t_surrogate(cfg); synth.load_synth_weights(srg, seed=0); srg = srg.to(dev).eval()
 exp = recipe.t_explainer(cfg); synth.load_synth_weights(exp, seed=1); exp = exp.to(dev); exp.train()
 xs = torch.from_numpy(synth.synth_images(B, params["img_px_size"], params["img_channels"], seed=3)).to(dev)
-opt = torch.optim.AdamW([q for q in exp.parameters() if q.requires_grad], lr=1e-5)
+opt = torch.optim.AdamW([q for q in exp.parameters() if q.requires_grad], lr=1e-5, fused=True)
 v0 = torch.full((1, cfg.num_labels), 0.1, device=dev)
 gen = lambda a, b: (xs, torch.zeros(B, dtype=torch.long, device=dev))
 te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)], recipe, srg, exp, opt, 1, gen, seed=7)
