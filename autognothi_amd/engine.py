@@ -32,9 +32,9 @@ def last_packed_rows(device=None) -> int:
     return int(t) if isinstance(t, int) else int(t.item())
 
 
-def note_packed_rows(device, n: int) -> None:
-    """(paths that already hold the packed row count on the host: the LTT-BERT ladder driver)"""
-    _PACKED_ROWS[str(device)] = int(n)
+def note_packed_rows(device, n) -> None:
+    """(the LTT-BERT ladder driver: a host int, or the device int32 [1] tensor that holds the count)"""
+    _PACKED_ROWS[str(device)] = n if isinstance(n, torch.Tensor) else int(n)
 FOLD_LAYERNORM = os.environ.get("AG_LN_FOLD", "1") != "0"  # bf16 ViT: fold LayerNorm into the consuming GEMM epilogue
 
 

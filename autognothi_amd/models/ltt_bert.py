@@ -186,7 +186,10 @@ class LttBertModel(nn.Module):
         branches = sorted(set(int(x) for x in side_layer_branches))
         # layer 0 on every token (its QKV is shared by the K masks of an input), then pack
         hidden = self._bb[t][0].forward(self.embed(input_ids, token_type_ids, dtype), rows, rows // b, bits, False, dtype)
-        cu, src, n = ops.seq_compact_plan(bits, t)
+        # the packed row count stays on the device: the packed section is sized for the upper bound rows * t and its kernels
+        # clamp to cu[rows] (ops.dynamic_rows): no host read, the whole forward can be captured into a hipGraph
+        cu, src, n = ops.seq_compact_plan(bits, t, sync=False)
+        n_dev = cu[rows:rows + 1]
         side: Dict[int, Optional[Tensor]] = {i_b: None for i_b in branches}
         if 0 < enc._ltt_freeze_layer:
             flat = hidden.view(rows * t, c.hidden_size)
@@ -194,18 +197,20 @@ class LttBertModel(nn.Module):
                 w, bias = self._maps[f"{i_b}_0"].get(dtype)
                 s0 = ops.gemm(flat, w, bias, L.AG_EPI_BIAS_GELU, dtype)
                 s0 = self._side[(t, f"{i_b}_0")].forward(s0.view(rows, t, c.s_attn_hidden_size), rows, 1, bits, False, dtype)
-                side[i_b] = ops.gather_rows(s0, src, n, dtype)
-        hidden = ops.gather_rows(hidden, src, n, dtype)
-        for i_ly in range(1, enc.num_layers):
-            hidden = self._bb[t][i_ly].forward_packed(hidden, cu, rows, n, dtype)
-            if i_ly >= enc._ltt_freeze_layer:
-                continue
-            for i_b in branches:
-                key = f"{i_b}_{i_ly}"
-                w, bias = self._maps[key].get(dtype)
-                s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1)
-                side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype)
-        engine.note_packed_rows(hidden.device, n)
+                with ops.dynamic_rows(n_dev):
+                    side[i_b] = ops.gather_rows(s0, src, n, dtype)
+        with ops.dynamic_rows(n_dev):
+            hidden = ops.gather_rows(hidden, src, n, dtype)
+            for i_ly in range(1, enc.num_layers):
+                hidden = self._bb[t][i_ly].forward_packed(hidden, cu, rows, n, dtype)
+                if i_ly >= enc._ltt_freeze_layer:
+                    continue
+                for i_b in branches:
+                    key = f"{i_b}_{i_ly}"
+                    w, bias = self._maps[key].get(dtype)
+                    s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1)
+                    side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype)
+        engine.note_packed_rows(hidden.device, n_dev)
         h_cls = ops.gather_rows(hidden, cu, rows, dtype).view(rows, 1, c.hidden_size)
         s_cls = [ops.gather_rows(side[i_b], cu, rows, dtype).view(rows, 1, c.s_attn_hidden_size) for i_b in branches]
         return h_cls, s_cls, rows

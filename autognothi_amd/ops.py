@@ -366,16 +366,34 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
     return loss, d
 
 
-def seq_compact_plan(mask_bits: Tensor, t: int):
-    """BERT token pruning plan: key bits [R, Tw] -> (cu_seqlens int32 [R+1], packed-row source table int32 [R*t], N);
-    reads the packed row count back (one 4-byte device->host copy)."""
+def seq_compact_plan(mask_bits: Tensor, t: int, sync: bool = True):
+    """BERT token pruning plan: key bits [R, Tw] -> (cu_seqlens int32 [R+1], packed-row source table int32 [R*t], N).
+    sync=True reads the packed row count N back (a 4-byte device->host copy); sync=False returns the upper bound R*t
+    instead: run the packed section under ``dynamic_rows(cu[R:])`` and nothing leaves the device."""
     L.require_gpu(mask_bits)
     rows = mask_bits.shape[0]
     cu = torch.empty(rows + 1, dtype=torch.int32, device=mask_bits.device)
     src = torch.empty(rows * t, dtype=torch.int32, device=mask_bits.device)
     with L.on(mask_bits.device):
         L.check(L.lib().ag_seq_compact_plan(L.ptr(mask_bits.contiguous()), rows, t, L.ptr(cu), L.ptr(src), L.stream()))
-    return cu, src, int(cu[rows].item())
+    return cu, src, (int(cu[rows].item()) if sync else rows * t)
+
+
+class dynamic_rows:
+    """context: the row counts passed to gemm / layernorm / gather_rows / side_* inside are upper bounds; the kernels read
+    the actual count from ``count`` (a device int32 tensor, first element) when they run (ag_dynamic_rows)."""
+
+    def __init__(self, count: Tensor):
+        L.require_gpu(count)
+        self.count = count
+
+    def __enter__(self):
+        L.check(L.lib().ag_dynamic_rows(L.ptr(self.count)))
+        return self
+
+    def __exit__(self, *exc):
+        L.check(L.lib().ag_dynamic_rows(None))
+        return False
 
 
 def gather_rows(src: Tensor, index: Tensor, n: int, dtype: int) -> Tensor:

@@ -165,7 +165,7 @@ def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
     """The torch-CPU port of the reference path (oracle/torch_port.py, fp32) timed over a bounded sample of the same
     workload, the K masked copies materialised as the reference does (scripts/train_explainer.py:159-163).  A 100+-core
     host oversubscribes these medium-sized GEMMs, so a few thread counts up to ALL logical CPUs are timed (best of 2 each
-    after a warm-up) and the fastest is reported together with the count that produced it."""
+    after a warm-up; the ladder stops once two counts in a row were slower than the best) and the fastest is reported together with the count that produced it."""
     from oracle import torch_port as otp
     if kind.startswith("ltt_"):
         def fn(x, m, sd_, prm):
@@ -182,9 +182,11 @@ def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
     ncpu = os.cpu_count() or 8
     prev = torch.get_num_threads()
     tried = []
+    worse = 0
     for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64, ncpu)}):
-        if time.perf_counter() - t0 > 24.0:
+        if time.perf_counter() - t0 > 24.0 or worse >= 2:   # (two thread counts in a row slower than the best: oversubscribed)
             break
+        before = best
         torch.set_num_threads(nt)
         fn(xs_ext, masks, sd, params)  # warm-up (thread pool, page-in)
         tried.append(nt)
@@ -195,6 +197,7 @@ def cpu_baseline(kind, params, xs_np, masks_np, sd_np):
             reps_total += 1
             if dt < best:
                 best, best_threads = dt, nt
+        worse = 0 if best < before else worse + 1
     torch.set_num_threads(prev)
     return rows / best, rows, reps_total, best_threads, tried
 

@@ -9,7 +9,8 @@ from util import build_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tag,precision", [("vit_tiny_c1", "fp32"), ("vit_tiny_c1", "bf16"), ("vit_base_l12", "bf16"), ("bert_base_l12", "bf16")])
+@pytest.mark.parametrize("tag,precision", [("vit_tiny_c1", "fp32"), ("vit_tiny_c1", "bf16"), ("vit_base_l12", "bf16"), ("bert_base_l12", "bf16"),
+                                           ("ltt_bert_base_l2", "bf16"), ("ltt_vit_tiny_l3", "bf16")])
 def test_graphed_step_equals_eager(cuda_device, tag, precision):
     from autognothi_amd import engine, ops
     c = build_case(tag)
