@@ -3,12 +3,12 @@
 // Replaces every nn.Linear on the masked-forward path (reference models/vanilla_vit.py:422-424,
 // :477, :491, :510; models/vanilla_bert.py:488-490, :557, :576, :601).
 //
-// Structure (v1, "128x128x128B, two barriers per K tile"):
-//   * block = 256 threads = 4 waves (2 along M x 2 along N); block tile 128(M) x 128(N); each wave
+// Structure ("128x128x128B, one barrier per K slice"):
+//   * block = 256 threads = 4 waves (2 along M x 2 along N); block tile 128(M) x 128(N) (or 64 x 64); each wave
 //     owns 64x64 = 4x4 MFMA 16x16 sub-tiles (64 accumulator VGPRs).
 //   * K is walked in 128-byte slices per row (64 bf16 / 32 fp32), so both storage dtypes use the
 //     same staging code: each tile row is 8 x 16-B chunks, staged global->LDS with
-//     global_load_lds_dwordx4 (no VGPR round trip), double-buffered.
+//     global_load_lds_dwordx4 (no VGPR round trip), through a 2- or 4-slot LDS ring (counted vmcnt).
 //   * LDS image is lane-linear (what LDS-DMA requires); the bank-conflict swizzle
 //     slot = chunk ^ (row & 7) is applied on the SOURCE address and again on the ds_read_b128.
 //   * operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so a lane ends up with
@@ -55,9 +55,15 @@ template <> struct Mma<float> {
     }
 };
 
+// LDS-DMA through inline asm on purpose (as in gemm_big.hip): with the builtin hipcc sees "LDS written by a pending VMEM
+// op" and drains vmcnt to 0 in front of the first ds_read of every K slice, which would turn the NST-slot ring below into a
+// one-slice-deep one.  The only waits on these loads are the counted s_waitcnt vmcnt(N) of the main loop; the "memory"
+// clobber keeps LDS accesses from moving across.  M0 (compiler-reserved) carries the wave-uniform LDS address and is restored.
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    const uint32_t lds_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
 }
 
 // stage one 128-row x 128-byte operand tile; rows beyond `rows_total` are clamped (their products
@@ -82,11 +88,29 @@ __device__ __forceinline__ uint4 lds_frag(const char* lds_tile, int row, int chu
     return *reinterpret_cast<const uint4*>(lds_tile + row * ROWB + ((chunk ^ (row & 7)) << 4));
 }
 
-template <typename T, int EPI, int BT>
+// leave the `newer` most recently issued stages (LPS LDS-DMA loads per wave each) in flight: the immediate must be a literal
+template <int LPS>
+__device__ __forceinline__ void wait_stages(int newer) {
+    switch (newer) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPS) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPS) : "memory"); break;
+    }
+}
+
+// NST-slot LDS ring, NST-1 K slices in flight (counted vmcnt, one barrier per slice).  These launches are the ones too small
+// for the 256x256 ring kernel (a few hundred to a few thousand rows: the explainer's training step, heads).
+template <typename T, int EPI, int BT, int NST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs pin) {
     GemmArgs p = pin;
     p.M = ag_dyn_clamp(p.M, p.dyn);    // the grid was sized for the upper bound: surplus workgroups leave at once
     constexpr int BM = BT, BN = BT, TILE_BYTES = BT * ROWB, NS = BT / 32, WT = BT / 2;   // NS sub-tiles per wave and dim
+    constexpr int LPS = BT / 16;       // LDS-DMA loads per wave and K slice (A + W)
+    static_assert((NST - 2) * LPS <= 63 && NST >= 2 && NST <= 8, "vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,21 +132,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs pin) {
         for (int j = 0; j < NS; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)((p.kbytes + ROWB - 1) / ROWB);
-    // LDS: [buf0: A tile | W tile][buf1: A tile | W tile]
-    stage_tile<BT>(p.A, p.lda_b, m0, p.M, 0, smem, wave, lane, p.kbytes, p.zeros);
-    stage_tile<BT>(p.W, p.ldw_b, n0, p.N, 0, smem + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // LDS: NST slots of [A tile | W tile]
+    auto stage = [&](int kt, int slot) {
+        char* dst = smem + slot * 2 * TILE_BYTES;
+        stage_tile<BT>(p.A, p.lda_b, m0, p.M, (long)kt * ROWB, dst, wave, lane, p.kbytes, p.zeros);
+        stage_tile<BT>(p.W, p.ldw_b, n0, p.N, (long)kt * ROWB, dst + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
+    };
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+        if (s_ < nk) stage(s_, s_);
 
     const int frow = lane & 15, fq = lane >> 4;
+    int slot = 0, slot_in = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile<BT>(p.A, p.lda_b, m0, p.M, (long)(kt + 1) * ROWB, nxt, wave, lane, p.kbytes, p.zeros);
-            stage_tile<BT>(p.W, p.ldw_b, n0, p.N, (long)(kt + 1) * ROWB, nxt + TILE_BYTES, wave, lane, p.kbytes, p.zeros);
-        }
-        const char* tA = smem + cur * 2 * TILE_BYTES;
+        // slice kt of this wave has landed (newer slices stay in flight); behind the barrier so have everyone's, and every
+        // wave has finished reading the slot of slice kt-1, which the next request overwrites
+        wait_stages<LPS>(min(nk - 1 - kt, NST - 2));
+        __syncthreads();
+        if (kt + NST - 1 < nk) stage(kt + NST - 1, slot_in);
+        const char* tA = smem + slot * 2 * TILE_BYTES;
         const char* tW = tA + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -137,8 +165,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs pin) {
 #pragma unroll
                 for (int sm = 0; sm < NS; ++sm) Mma<T>::run(fw[sn], fx[sm], acc[sn][sm]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        slot_in = slot_in + 1 == NST ? 0 : slot_in + 1;
     }
 
     // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15) per sub-tile ----
@@ -211,17 +239,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs pin) {
     }
 }
 
-template <typename T, int EPI, int BT>
+template <typename T, int EPI, int BT, int NST>
 int launch_bt(const GemmArgs& a, hipStream_t s) {
     static bool attr_set = false;
+    constexpr int LDS = NST * 2 * BT * ROWB;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, EPI, BT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BT * ROWB);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, EPI, BT, NST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm): %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
-    hipLaunchKernelGGL((gemm_kernel<T, EPI, BT>), dim3(tiles), dim3(NTHREADS), 4 * BT * ROWB, s, a);
+    hipLaunchKernelGGL((gemm_kernel<T, EPI, BT, NST>), dim3(tiles), dim3(NTHREADS), LDS, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
@@ -229,11 +258,18 @@ int launch_bt(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
     // 128^2 tiles unless they would leave most of the 256 CUs (2 workgroups each) without work: the training steps run
-    // on a few images (M = B*T ~ 1.5 k rows) and their dW GEMMs have N x K outputs of a few dozen 128^2 tiles
+    // on a few images (M = B*T ~ 1.5 k rows) and their dW GEMMs have N x K outputs of a few dozen 128^2 tiles.
+    // Ring depth (tools/gemm_small.py, L2-warm): two slots of 16 / 32 KiB leave room for more workgroups per CU and win on
+    // short K; 64^2 tiles with K >= 4 KiB per row (fc2 and its dX: 48 slices) gain 12-27 % from four slots.  The 8-slot
+    // variant (one workgroup per CU) lost everywhere and is gone.  AG_GEMM_NST = 2 / 4 overrides (dev knob, read once).
     const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
     static const int bt_env = getenv("AG_GEMM_BT") ? atoi(getenv("AG_GEMM_BT")) : 0;
-    if (bt_env == 64 || (bt_env == 0 && tiles128 < 384)) return launch_bt<T, EPI, 64>(a, s);
-    return launch_bt<T, EPI, 128>(a, s);
+    static const int nst_env = getenv("AG_GEMM_NST") ? atoi(getenv("AG_GEMM_NST")) : 0;
+    if (bt_env == 64 || (bt_env == 0 && tiles128 < 384)) {
+        if (nst_env == 4 || (nst_env == 0 && a.kbytes >= 4096)) return launch_bt<T, EPI, 64, 4>(a, s);
+        return launch_bt<T, EPI, 64, 2>(a, s);
+    }
+    return launch_bt<T, EPI, 128, 2>(a, s);
 }
 
 template <typename T>

@@ -49,22 +49,59 @@ __global__ void transpose_bf16_kernel(const float* __restrict__ src, int R, int 
     }
 }
 
-// ---- column sums: out[n] (+)= sum_m x[m][n] ; block = 64 columns x one row slab (gridDim.y slabs), 4 row lanes ----
-// One slab: plain store / read-modify-write.  Several slabs (tall inputs: a 64-column block alone would walk all M rows
-// on one CU): partial sums are combined with float atomics into an output the launcher zeroed (or that accumulates).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ldx, float* __restrict__ out, int accumulate) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    const int rows_per = (M + gridDim.y - 1) / gridDim.y;
-    const int m_lo = blockIdx.y * rows_per, m_hi = min(M, m_lo + rows_per);
-    float s = 0.f;
-    if (c < N) for (int m = m_lo + w; m < m_hi; m += 4) s += x[(int64_t)m * ldx + c];
-    part[w][threadIdx.x & 63] = s;
+// ---- column sums: out[n] (+)= sum_m x[m][n] (bias gradients) ----
+// One launch, no atomics, nothing to zero: a block owns CPB columns for ALL rows (256 threads = CPB/4 float4 lanes x RG row
+// groups), every row group walks its rows in order and the RG partials are added in a fixed tree through LDS, so the sums are
+// bit-reproducible (the previous version combined row slabs with float atomics behind a hipMemsetAsync).
+template <int CPB>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int N, int64_t ldx, float* __restrict__ out, int accumulate,
+                                                     int vec_ok) {
+    constexpr int VL = CPB / 4, RG = 256 / VL;
+    __shared__ float4 part[RG][VL];
+    const int vl = threadIdx.x % VL, rg = threadIdx.x / VL;
+    const int c = blockIdx.x * CPB + vl * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec_ok && c + 3 < N) {
+        int m = rg;
+        for (; m + 3 * RG < M; m += 4 * RG) {          // four independent loads in flight per thread
+            const float4 a0 = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + c);
+            const float4 a1 = *reinterpret_cast<const float4*>(x + (int64_t)(m + RG) * ldx + c);
+            const float4 a2 = *reinterpret_cast<const float4*>(x + (int64_t)(m + 2 * RG) * ldx + c);
+            const float4 a3 = *reinterpret_cast<const float4*>(x + (int64_t)(m + 3 * RG) * ldx + c);
+            s.x += (a0.x + a1.x) + (a2.x + a3.x); s.y += (a0.y + a1.y) + (a2.y + a3.y);
+            s.z += (a0.z + a1.z) + (a2.z + a3.z); s.w += (a0.w + a1.w) + (a2.w + a3.w);
+        }
+        for (; m < M; m += RG) {
+            const float4 a0 = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + c);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        }
+    } else if (c < N) {                                 // ragged last columns / rows not 16-byte aligned: scalar
+        for (int m = rg; m < M; m += RG) {
+            const float* r = x + (int64_t)m * ldx + c;
+            s.x += r[0];
+            if (c + 1 < N) s.y += r[1];
+            if (c + 2 < N) s.z += r[2];
+            if (c + 3 < N) s.w += r[3];
+        }
+    }
+    part[rg][vl] = s;
     __syncthreads();
-    if (w == 0 && c < N) {
-        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        if (gridDim.y > 1) atomicAdd(out + c, t);
-        else out[c] = accumulate ? out[c] + t : t;
+#pragma unroll
+    for (int h = RG / 2; h >= 1; h >>= 1) {
+        if (rg < h) {
+            const float4 o = part[rg + h][vl];
+            float4 t = part[rg][vl];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            part[rg][vl] = t;
+        }
+        __syncthreads();
+    }
+    if (rg == 0 && c < N) {
+        const float4 t = part[0][vl];
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < N) out[c + j] = accumulate ? out[c + j] + v[j] : v[j];
     }
 }
 
@@ -688,12 +725,10 @@ extern "C" int ag_cast_transpose_f32_bf16(const float* d_src, int rows, int cols
 }
 extern "C" int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream) {
     AG_REQUIRE(d_x && d_out && M >= 0 && N >= 1, "ag_colsum_f32: bad arguments");
-    int slabs = M / 128;                       // >= 128 rows per slab; enough blocks to cover the chip
-    const int want = 1024 / ceil_div(N, 64);
-    if (slabs > want) slabs = want;
-    if (slabs < 1) slabs = 1;
-    if (slabs > 1 && !accumulate) AG_HIP_CHECK(hipMemsetAsync(d_out, 0, (size_t)N * sizeof(float), (hipStream_t)stream));
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64), slabs), dim3(256), 0, (hipStream_t)stream, d_x, M, N, ldx, d_out, accumulate);
+    const int vec_ok = ((ldx % 4) == 0 && ((uintptr_t)d_x % 16) == 0) ? 1 : 0;   // float4 row segments
+    // 16-column blocks (64-byte row segments) unless 32-column ones (whole 128-byte lines) already give the chip >= 64 blocks
+    if (N >= 64 * 32) hipLaunchKernelGGL(colsum_kernel<32>, dim3(ceil_div(N, 32)), dim3(256), 0, (hipStream_t)stream, d_x, M, N, ldx, d_out, accumulate, vec_ok);
+    else hipLaunchKernelGGL(colsum_kernel<16>, dim3(ceil_div(N, 16)), dim3(256), 0, (hipStream_t)stream, d_x, M, N, ldx, d_out, accumulate, vec_ok);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -355,12 +355,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):   # under a launcher: also a 1-rank job runs the
+        import torch.distributed as dist                                       # RCCL barriers / reductions (1-GPU boxes test them)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
     if args.no_secondary:
         args.attr_batch = args.train_batch = 0
 

@@ -448,3 +448,22 @@ def test_side_linear_fused(cuda_device, m, h, n, pre, res, post):
                           t(r).to(torch.bfloat16) if res else None, (t(g1), t(b1)) if post else None, eps)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=3e-2)
     assert L.lib().ag_side_linear_supported(96, 288, 1, BF16) == 0      # a LayerNorm over 288 outputs is not built
+
+
+@pytest.mark.parametrize("m,n", [(1576, 768), (1576, 3072), (12608, 2304), (37, 10), (8, 2), (5000, 70), (1, 768), (333, 4099)])
+def test_colsum_bias_gradients(cuda_device, m, n):
+    """ag_colsum_f32 (bias gradients of the training step): one launch, fixed summation tree — against float64 sums, with
+    the accumulate form, unaligned widths (num_labels = 10 / 2), and bit-identical from launch to launch."""
+    from autognothi_amd import ops
+    g = torch.Generator().manual_seed(m * 31 + n)
+    x = torch.randn((m, n), generator=g)
+    xd = x.to(cuda_device)
+    want = x.double().sum(0)
+    got = ops.colsum(xd)
+    tol = 2e-6 * float(x.abs().double().sum(0).max()) + 1e-6
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), rtol=0, atol=tol)
+    for _ in range(3):
+        assert torch.equal(ops.colsum(xd), got)
+    acc = torch.full((n,), 2.0, device=cuda_device)
+    ops.colsum(xd, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().double().numpy(), want.numpy() + 2.0, rtol=0, atol=tol)

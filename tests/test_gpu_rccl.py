@@ -1,0 +1,91 @@
+"""RCCL on the box's one GPU (world size 1): the collectives of the N > 1 path issued for real — bucketed asynchronous gradient
+all-reduce overlapped with the manual backward (distributed.GradBucketReducer through training.GRAD_SINK), scalar reductions,
+and bench.py launched by torch.distributed.run.  Values cannot differ across ranks here; what is checked is that the exchange
+runs on RCCL streams next to the HIP kernels and leaves exactly the gradients of the plain step (scaled by the averaging)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from util import build_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def rccl_group(cuda_device):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_reducer_overlapped_with_backward_on_rccl(cuda_device, rccl_group, monkeypatch):
+    """one explainer training step (ViT-tiny fixture) with every gradient passing through the bucket reducer — pretending
+    two ranks, so the all-reduce (a sum over the ONE real rank) is followed by the division by two — against the plain step."""
+    from autognothi_amd import distributed as D, engine, ops, training as T
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    engine.set_precision("fp32")
+    srg = c["surrogate"].to(dev).eval()
+    exp = c["explainer"].to(dev)
+    exp.train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    b, k, p = c["B"], c["K"], c["P"]
+    _, bits = ops.mask_shapley_new(ops.DeviceMT19937(dev, 3407), b * k, p, want_i64=False, want_bits=True)
+    with torch.no_grad():
+        v_s, _ = recipe.fw_surrogate(srg, xs, bits)
+        v_1, _ = recipe.fw_surrogate(srg, xs, torch.ones((b, p), dtype=torch.int64, device=dev))
+    v_0 = torch.full((1, v_s.shape[1]), 1.0 / v_s.shape[1], device=dev)
+    trainer = T.make_explainer_trainer(recipe, exp)
+    params = [q for q in exp.parameters() if q.requires_grad]
+
+    def step(sink):
+        for q in params:
+            q.grad = None
+        T.GRAD_SINK = sink
+        try:
+            loss, _ = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, k, train=False, seed=1)
+        finally:
+            T.GRAD_SINK = None
+        return loss
+
+    step(None)
+    want = [q.grad.clone() for q in params]
+    monkeypatch.setattr(D, "world", lambda: (0, 2))
+    red = D.GradBucketReducer(params, bucket_bytes=1 << 20)      # ViT-tiny: 22 MB of gradients = many buckets in flight
+    step(red.ready)
+    n_coll = red.finish()
+    torch.cuda.synchronize()
+    assert n_coll >= 4, n_coll
+    gscale = max(float(w.abs().max()) for w in want)
+    for q, w in zip(params, want):     # (two runs of the backward agree to fp32 rounding, not bit for bit: dX of LayerNorm / attention
+        torch.testing.assert_close(q.grad, w / 2, rtol=1e-4, atol=1e-6 * gscale)   # accumulate in launch-dependent order)
+    assert D.reduce_scalars([3.0, 4.0], dev) == [3.0, 4.0]
+
+
+def test_bench_under_launcher_runs_rccl_barriers():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py`: the driver's N > 1 launch line with one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k_, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--no-cpu-baseline", "--train-batch", "2", "--attr-batch", "4"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["secondary"]["train_explainer_step"]["value"] > 0
