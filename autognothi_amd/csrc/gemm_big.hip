@@ -521,8 +521,10 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
     // kernel: more, shorter workgroups.  These are the explainer-training GEMMs (M = 8 images x 197 tokens: 7 row panels):
     // training step +11 % (vanilla ViT-base) / +23 % (duo BERT-base) at 8 images; a threshold of 100 would also catch the
     // N = 768 GEMMs of a single-input inference step (75 tiles, K up to 3072), where the ring is 7 % faster.
+    // fp32-output launches are the training step's (bf16 operands, fp32 activations): nothing folds a LayerNorm into them and
+    // with the counted-vmcnt ring of the 64-tile kernel the break-even moved up: 130 tiles (duo BERT-base step -5 %, ViT -1.5 %).
     const char* mt = getenv("AG_GEMM_BIG_MIN_TILES");       // (read per call: the kernel parity tests pin the ring with it)
-    const int min_tiles = mt ? atoi(mt) : 48;
+    const int min_tiles = mt ? atoi(mt) : (epilogue == AG_EPI_BIAS_F32 ? 130 : 48);
     if ((long)ceil_div(M, BT) * ceil_div(N, BT) < min_tiles) return false;
     return M >= 1024 && N >= 256 && (N % 8) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);

@@ -69,8 +69,16 @@ class _Workspace:
 WORKSPACE = _Workspace()
 
 
+def param_key(p: Tensor) -> Tuple:
+    """identity of a parameter's current VALUE for the weight caches: storage, torch's in-place version counter, and the count
+    of gradients this package's backward has written into it (``_ag_step``, bumped by training._acc_grad / _grad).  The last
+    one matters: ``torch.optim.AdamW(fused=True)`` (and the other fused / foreach optimisers that update through
+    ``torch._fused_*``) do NOT advance ``_version``, so a cache keyed on it alone keeps serving the weights of step 1."""
+    return (p.data_ptr(), p._version, p.__dict__.get("_ag_step", 0))
+
+
 def _versions(params: Sequence[Tensor]) -> Tuple:
-    return tuple((p.data_ptr(), p._version) for p in params)
+    return tuple(param_key(p) for p in params)
 
 
 class PackedLinear:

@@ -55,7 +55,15 @@ def _final(*params: Tensor) -> None:
                 GRAD_SINK(p)
 
 
+def _touch(p: Tensor) -> None:
+    """a gradient is being written into p: whatever optimiser runs next will change its value, whether or not it advances
+    ``p._version`` (fused AdamW does not) — engine.param_key counts these writes so that every weight cache (operand forms
+    here, the inference packs in engine.py) is rebuilt before the next forward."""
+    p.__dict__["_ag_step"] = p.__dict__.get("_ag_step", 0) + 1
+
+
 def _grad(p: Tensor) -> Tensor:
+    _touch(p)
     if p.grad is None:
         p.grad = torch.zeros_like(p, dtype=torch.float32)
     return p.grad
@@ -66,6 +74,7 @@ def _acc_grad(p: Tensor, src: Tensor, fresh: bool = False) -> None:
     gradient buffer itself (``fresh``: src is a whole tensor nobody else holds) or one copy of it — instead of a zero fill
     plus an add per parameter and step."""
     src = src.reshape(p.shape)
+    _touch(p)
     if p.grad is None:
         p.grad = src if (fresh and src.is_contiguous()) else src.clone(memory_format=torch.contiguous_format)
     else:
@@ -114,7 +123,7 @@ class Lin:
         self.xt: Optional[Tensor] = None      # mixed mode: X^T bf16 [K, Mp] saved instead of x (the dW operand)
 
     def _key(self):
-        return tuple((p.data_ptr(), p._version) for m in self.mods for p in (m.weight, m.bias))
+        return tuple(engine.param_key(p) for m in self.mods for p in (m.weight, m.bias))
 
     def _w(self) -> Tuple[Tensor, Tensor]:
         """fused fp32 [N,K] weight and [N] bias, rebuilt only when a parameter changed (optimizer step / load): the forward
@@ -604,9 +613,11 @@ class ExplainerTrainer:
         phi, base = self.forward_phi(xs, v_0, v_1, train, seed)
         loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)
         total, dbase = loss, None
+        self.last_parts = (loss, None, base)               # (Shapley loss, classification loss, base_Ys) of this step: duo reports
         if self.duo:
             ce, dbase = _cross_entropy(base, labels)     # duo-ViT: CE on probabilities, duo-BERT: on raw logits (A.5)
             total = loss + ce
+            self.last_parts = (loss, ce, base)
         self.backward_phi(dphi, dbase)
         return total, phi
 

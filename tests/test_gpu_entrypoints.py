@@ -1,6 +1,7 @@
-"""The three pipeline entry points with the reference's signatures — train_surrogate(env, device), train_explainer(env, device),
-measure_faithfulness(env, device, d_loader, resolution) (scripts/train_surrogate.py:16, train_explainer.py:19,
-measure_faithfulness.py:41) — run end to end on a duck-typed environment: resume from checkpoints in the reference's wire
+"""The pipeline entry points with the reference's signatures — train_surrogate(env, device), train_explainer(env, device),
+train_duo_explainer(env, device), measure_faithfulness(env, device, d_loader, resolution), measure_accuracy(env, device, d_loader),
+measure_cls_acc(env, device, d_loader) (scripts/train_surrogate.py:16, train_explainer.py:19, train_duo_explainer.py:20,
+measure_faithfulness.py:41, measure_accuracy.py:26, measure_cls_acc.py:32) — run end to end on a duck-typed environment: resume from checkpoints in the reference's wire
 format, per-epoch reseeding, train + eval epochs, scheduler, metrics, checkpoint rotation, report."""
 import types
 
@@ -108,3 +109,73 @@ def test_pipelines_run_from_checkpoints(cuda_device, tmp_path):
     for key in ("insertion", "deletion"):
         assert 0.0 <= rep[key]["auc"] <= 1.0 and len(rep[key]["avg"]) == 5      # probabilities, resolution 5 stops
     assert any("FINAL RESULTS" in ln for ln in env.lines)
+
+    # accuracy reports with the reference's signatures (scripts/measure_accuracy.py:26, scripts/measure_cls_acc.py:32)
+    from autognothi_amd.scripts.measure_accuracy import measure_accuracy, measure_cls_acc
+    config.eval_accuracy = types.SimpleNamespace(dataset=None, resolution=3)
+    config.eval_cls_acc = types.SimpleNamespace(dataset=None, on_exp_epochs=None)
+    config.train_classifier.batch_size = 3
+    acc = measure_accuracy(env, dev, None)
+    assert acc.masked_players == [0, c["P"] // 2, c["P"]] and all(0.0 <= a <= 1.0 for a in acc.accuracy)
+    cls_acc = measure_cls_acc(env, dev, loader)
+    assert cls_acc.epochs == [2] and 0.0 <= cls_acc.accuracy[0] <= 1.0           # None: the last explainer epoch only
+    config.eval_cls_acc.on_exp_epochs = "_:%1==0"
+    assert measure_cls_acc(env, dev, loader).epochs == [0, 1, 2]
+    # the last entry is the accuracy of the Final model assembled above (same three checkpoints) on the six images
+    fin_probs, _ = recipe.fw_final(final.to(dev).eval(), torch.stack(loader.xs).to(dev))
+    want = float((fin_probs.argmax(1).cpu() == torch.tensor(loader.ys)).float().mean())
+    assert abs(measure_cls_acc(env, dev, loader).accuracy[-1] - want) < 1e-6
+
+
+def test_duo_pipeline_runs_from_checkpoints(cuda_device, tmp_path):
+    """train_duo_explainer(env, device) (scripts/train_duo_explainer.py:20): classification + Shapley heads trained together;
+    the ten-field metrics entry, checkpoints, and a plain (non-duo) recipe is skipped as the reference skips it."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import resources as rs
+    from autognothi_amd.scripts.train_duo_explainer import train_duo_explainer
+    from autognothi_amd.utils import synth
+    engine.set_precision("fp32")
+    c = build_case("duo_vit_tiny_l3")
+    recipe, dev = c["recipe"], cuda_device
+    prm = dict(c["meta"]["params"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg = recipe.t_config(**prm)
+    srg, exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
+    synth.load_synth_weights(srg, seed=0)
+    synth.load_synth_weights(exp, seed=1)
+    rs.save_epoch_ckpt(tmp_path, "surrogate", "_:%1==0", 0, 0, srg)
+    rs.save_epoch_ckpt(tmp_path, "explainer", "_:%1==0", 3, 0, exp)
+    n = 6
+    imgs = torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=9))
+    loader = _Loader([imgs[i] for i in range(n)], [i % prm["num_labels"] for i in range(n)])
+    config = types.SimpleNamespace(
+        seed=3407, net=types.SimpleNamespace(kind="duo_vanilla_vit", params=prm), dataset=None,
+        train_classifier=_train_cfg(epochs=0), train_surrogate=_train_cfg(epochs=0),
+        train_explainer=_train_cfg(epochs=3, n_mask_samples=4, lr=1e-4, lambda_efficiency=0.0, lambda_norm=0.0))
+    env = _Env(config, tmp_path, loader)
+    train_duo_explainer(env, dev)
+    assert rs.get_epoch_ckpts(tmp_path, "explainer", 5) == [0, 1, 2, 3]
+    assert [e["epoch"] for e in env.entries] == [1, 2, 3]
+    keys = {"train_cls_loss", "train_reg_loss", "train_loss", "train_cls_acc", "test_cls_loss", "test_reg_loss", "test_loss",
+            "test_cls_acc", "test_plots"}
+    for e in env.entries:
+        assert keys <= set(e) and all(np.isfinite(e[k]) for k in keys - {"test_plots"})
+        assert abs(e["train_loss"] - (e["train_cls_loss"] + e["train_reg_loss"])) < 1e-6
+        assert 0.0 <= e["train_cls_acc"] <= 1.0 and 0.0 <= e["test_cls_acc"] <= 1.0
+    assert env.entries[-1]["test_loss"] < env.entries[0]["test_loss"]          # both heads learn the six images
+    # eval figures of the last epoch against plain torch on the same outputs (cross entropy of the recipe's class output)
+    _, m_exp = rs.load_epoch_model_env(env, recipe, "explainer", dev)
+    xs = torch.stack(loader.xs).to(dev)
+    ones = torch.ones((n, c["P"]), dtype=torch.long, device=dev)
+    with torch.no_grad():
+        v1, _ = recipe.fw_surrogate(srg.to(dev).eval(), xs, ones)
+        _, base = recipe.fw_explainer(m_exp, xs, ones, v1, torch.full((1, v1.shape[1]), 0.1, device=dev))
+    zs = torch.tensor(loader.ys, device=dev)
+    want_acc = float((base.argmax(1) == zs).float().mean())
+    assert abs(env.entries[-1]["test_cls_acc"] - want_acc) < 1e-6
+    ce_batches = [float(torch.nn.functional.cross_entropy(base[i:i + 2].float(), zs[i:i + 2])) for i in range(0, n, 2)]
+    assert abs(env.entries[-1]["test_cls_loss"] - sum(ce_batches) / n) < 1e-5
+    # a recipe without the duo head is skipped (reference :23-26)
+    env2 = _Env(types.SimpleNamespace(seed=1, net=types.SimpleNamespace(kind="vanilla_vit", params=build_case("vit_tiny_c1")["meta"]["params"]),
+                                      train_explainer=_train_cfg()), tmp_path, loader)
+    train_duo_explainer(env2, dev)
+    assert any("skip" in ln for ln in env2.lines)

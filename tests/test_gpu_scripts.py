@@ -119,7 +119,7 @@ def test_accuracy_reports(cuda_device):
     labels = torch.tensor([3, 5])
     gen = lambda a, b: (xs, labels.to(dev))  # noqa: E731
     random.seed(11)
-    rep = ma.measure_accuracy(None, dev, c["P"], 3, lambda: [(None, None)] * 2, recipe, srg, 1, gen)
+    rep = ma.measure_accuracy_loaded(None, dev, c["P"], 3, lambda: [(None, None)] * 2, recipe, srg, 1, gen)
     assert rep.masked_players == [0, 98, 196]
     random.seed(11)
     want = []

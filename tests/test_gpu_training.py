@@ -322,3 +322,55 @@ def test_attention_backward_mixed_matches_fp32(cuda_device, mode, t, heads, rows
         scale = float(np.abs(r).max())
         assert float(np.abs(o - r).max()) <= 3e-2 * scale, (name, float(np.abs(o - r).max()), scale)
         assert float(np.abs(o - r).mean()) <= 4e-3 * scale, name
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("tag", ["vit_tiny_c1", "duo_bert_base_l2"])
+def test_fused_optimizer_leaves_no_stale_weight_cache(cuda_device, tag, mixed):
+    """torch.optim.AdamW(fused=True) — what train_explainer(env, device) builds — updates parameters without advancing
+    ``_version``.  After a few steps both families of weight caches must still follow the parameters: the trainer's operand
+    forms (fused q|k|v, bf16 W / W^T pairs) and the inference packs (engine.Packed*): the same module must compute what a
+    fresh copy of its state dict computes, in the training forward and in fw_explainer, and must differ from step 0."""
+    from autognothi_amd import engine, ops, training as T
+    from autognothi_amd.utils import synth
+    c = build_case(tag)
+    dev, g, recipe = cuda_device, c["g"], c["recipe"]
+    engine.set_precision("fp32")
+    prm = _zero_dropout(c["meta"])
+    cfg = recipe.t_config(**prm)
+    exp = recipe.t_explainer(cfg)
+    synth.load_synth_weights(exp, seed=1)
+    exp = exp.to(dev)
+    exp.train()
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    bits = ops.pack_mask(torch.from_numpy(c["masks"]).to(dev))
+    v0, vs, v1 = [torch.from_numpy(g[k]).to(dev) for k in ("v_0", "v_s", "v_1")]
+    labels = torch.tensor([1, 0][:c["B"]], dtype=torch.long, device=dev)
+    ones = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
+    T.MIXED_BF16 = mixed
+    try:
+        tr = T.make_explainer_trainer(recipe, exp)
+        opt = torch.optim.AdamW([q for q in exp.parameters() if q.requires_grad], lr=1e-3, fused=True)
+        with torch.no_grad():
+            phi_start, _ = recipe.fw_explainer(exp, xs, ones, v1, v0)
+        for _ in range(3):
+            opt.zero_grad()
+            tr.loss_and_grads(xs, bits, v0, vs, v1, c["K"], labels=labels, train=True, seed=3)
+            opt.step()
+        fresh = recipe.t_explainer(cfg)
+        fresh.load_state_dict(exp.state_dict())
+        fresh = fresh.to(dev)
+        fresh.train()
+        phi_a, base_a = tr.forward_phi(xs, v0, v1, False, 0)
+        phi_b, base_b = T.make_explainer_trainer(recipe, fresh).forward_phi(xs, v0, v1, False, 0)
+        assert torch.equal(phi_a, phi_b), float((phi_a - phi_b).abs().max())
+        if base_a is not None:
+            assert torch.equal(base_a, base_b)
+        exp.eval(); fresh.eval()
+        with torch.no_grad():
+            inf_a, _ = recipe.fw_explainer(exp, xs, ones, v1, v0)
+            inf_b, _ = recipe.fw_explainer(fresh, xs, ones, v1, v0)
+        assert torch.equal(inf_a, inf_b), float((inf_a - inf_b).abs().max())
+        assert float((inf_a - phi_start).abs().max()) > 1e-4          # (and the three steps did move the explainer)
+    finally:
+        T.MIXED_BF16 = False
