@@ -266,6 +266,21 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     const int N = R * T;                   // upper bound of the packed rows
     const int* dN = cu + R;
     if (d_packed_rows_out) AG_HIP_CHECK(hipMemcpyAsync(d_packed_rows_out, dN, sizeof(int), hipMemcpyDeviceToDevice, hs));
+    // LayerNorm-free packed section (bf16, ring-kernel shapes, folded weights present): from layer 1's out-projection on, the
+    // stream holds PRE-LayerNorm rows h plus their slab statistics; LN(h) is folded into the GEMMs that consume it (QKV / fc1:
+    // ag_gemm's d_ln_stats) and recomputed inside the epilogues that add it as the residual (ag_gemm_resid_ln).  No LayerNorm
+    // output is written or read between layer 1's attention and the last layer's CLS rows: 2 of the 7 launches per layer
+    // (and their 2 x N x H round trips) disappear.
+    static const bool fold_off = getenv("AG_BERT_LN_FOLD") && atoi(getenv("AG_BERT_LN_FOLD")) == 0;
+    bool fold = !fold_off && dt == AG_BF16 && d->n_layers >= 3 &&
+                ag_gemm_supports_ln_fold(R * T, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt) &&
+                ag_gemm_supports_ln_fold(R * T, I, H, H, I, 0, AG_EPI_BIAS_GELU, dt) &&
+                ag_gemm_supports_ln_fold(R * T, H, H, H, H, H, AG_EPI_BIAS_RESID, dt) &&
+                ag_gemm_resid_ln_supported(R * T, H, H, H, H, H) && ag_gemm_resid_ln_supported(R * T, H, I, I, H, H);
+    for (int l = 1; fold && l < d->n_layers; ++l) {
+        const ag_layer_weights& w = d->layers[l];
+        if (!w.ln1_g || !w.ln2_g || !w.w_fc1_ln || (l >= 2 && !w.w_qkv_ln)) fold = false;
+    }
     struct DynScope {                      // launches inside run on *dN rows; restored on every exit path
         const int* prev;
         explicit DynScope(const int* p) : prev(g_ag_dyn_rows) { g_ag_dyn_rows = p; }
@@ -276,20 +291,47 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     char* x = ws.xs;                       // packed stream entering the layer
     TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, stream));
     char* xn = (char*)d_h;                 // d_h is free again (only token 0 of each row is defined at exit): ping-pong
+    bool x_pre = false;                    // fold: x holds pre-LN rows of the previous layer's output.LayerNorm, ws.st2 their statistics
     for (int l = 1; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         const bool last = l == d->n_layers - 1;
         AG_REQUIRE(w.ln2_g, "ag_bert_encoder_forward_pruned: BERT output.LayerNorm missing in layer %d", l);
-        TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        const ag_layer_weights& wp = d->layers[l - 1];
+        if (x_pre)
+            TRY(ag_gemm(x, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, ws.st2, w.s_qkv_ln,
+                        d->ln_eps, nullptr, stream));
+        else
+            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
         TRY(ag_masked_attention_varlen(ws.qkv, cu, ws.ctx, R, T, H, d->heads, last ? 1 : 0, dt, stream));
+        if (fold && !last) {
+            // h1 = ctx Wo^T + bo + (l == 1 ? x : LN2_prev(x)) with statistics; inter = gelu(LN1(h1) W1^T + b1) folded;
+            // h2 = inter W2^T + b2 + LN1(h1) recomputed, with statistics: the next layer's input
+            if (x_pre)
+                TRY(ag_gemm_resid_ln(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, ws.st2, wp.ln2_g, wp.ln2_b, d->ln_eps, N, H, H, ws.st1, stream));
+            else
+                TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, stream));
+            TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, ws.st1, w.s_fc1_ln,
+                        d->ln_eps, nullptr, stream));
+            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, xn, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, stream));
+            char* t = x; x = xn; xn = t;
+            x_pre = true;
+            continue;
+        }
         const char* ctx = ws.ctx;
         const char* res = x;
         int Mo = N;
         if (last) {   // CLS rows only: compact [R,H] copies of the attention output and of the residual; exact row count from here on
             dyn.off();
             TRY(ag_gather_rows(ws.ctx, H, cu, ws.inter, H, R, H, dt, stream));
-            TRY(ag_gather_rows(x, H, cu, ws.inter + (size_t)R * H * es, H, R, H, dt, stream));
-            ctx = ws.inter; res = ws.inter + (size_t)R * H * es; Mo = R;
+            char* rres = ws.inter + (size_t)R * H * es;
+            if (x_pre) {   // the residual is LN2_prev of the (pre-LN) CLS rows: R rows, normalised here
+                char* tmp = ws.inter + 2 * (size_t)R * H * es;
+                TRY(ag_gather_rows(x, H, cu, tmp, H, R, H, dt, stream));
+                TRY(ag_layernorm(tmp, dt, H, R, H, wp.ln2_g, wp.ln2_b, d->ln_eps, rres, nullptr, dt, stream));
+            } else {
+                TRY(ag_gather_rows(x, H, cu, rres, H, R, H, dt, stream));
+            }
+            ctx = ws.inter; res = rres; Mo = R;
         }
         TRY(ag_gemm(ctx, H, w.w_o, w.b_o, ws.hx, H, res, H, 1, 1, Mo, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
         const char* a = ws.hx;

@@ -44,7 +44,10 @@ struct BigArgs {
     const float* ln_stats; const float* ln_s; float ln_eps; float ln_inv_h;
     float* stats_out;
     long stats_slab;   // floats between slabs (= 2 M)
-    int ln_nslab;      // slabs of ln_stats (= ceil(K / 256))
+    int ln_nslab;      // slabs of ln_stats (= ceil(K / 256); residual-LayerNorm variant: ceil(N / 256))
+    // residual-LayerNorm variant (BERT post-LN, VAR = 3): the residual operand R holds PRE-LayerNorm rows h, ln_stats their
+    // statistics; the epilogue adds LN(h)[m, n] = (h - mean[m]) * rstd[m] * rln_g[n] + rln_b[n] instead of h
+    const float* rln_g; const float* rln_b;
     unsigned long long* dbg;  // diagnostic build only
     const int* dyn;  // ag_dynamic_rows(): actual row count (NULL: M is exact)
     int ngrp;      // N-tiles per tile-order group (>= 1)
@@ -115,7 +118,7 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
 // requested up front in one batch and the residual rows are prefetched one 16-row block ahead: the epilogue
 // runs with the matrix cores idle, so every exposed L2 round trip in it is paid in full.
 // Out-of-range rows / columns are clamped for the loads and masked at the stores; no divergent branches.
-template <int EPI, bool LNF, bool STATS>
+template <int EPI, bool LNF, bool STATS, bool RLN = false>
 __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
                                               char* stg, const int lane, const char* smem_base, const int tile_n) {
     const int frow = lane & 15, fq = lane >> 4;
@@ -134,7 +137,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     float2* const stat_lds = reinterpret_cast<float2*>(const_cast<char*>(smem_base) + NSLOT * SLOT_BYTES);
     const int wave_id = (int)((stg - smem_base) >> 14);
     float2 racc = make_float2(0.f, 0.f);
-    if (LNF && lane < 32) {
+    constexpr bool ROWST = LNF || RLN;   // this tile's rows need (mean, rstd): of the A rows (fold) or of the residual rows
+    if (ROWST && lane < 32) {
         int m = mw0 + (wave_id & 3) * 32 + lane;
         m = m < p.M ? m : p.M - 1;
         const float* sp = p.ln_stats + 2 * (long)m;
@@ -170,7 +174,15 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn) sv[sn] = *reinterpret_cast<const float4*>(p.ln_s + ncl[sn]);
     }
-    if (LNF) {
+    float4 gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
+    if (RLN) {
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+            gv[sn] = *reinterpret_cast<const float4*>(p.rln_g + ncl[sn]);
+            btv[sn] = *reinterpret_cast<const float4*>(p.rln_b + ncl[sn]);
+        }
+    }
+    if (ROWST) {
         if (lane < 32) {
             const float mean = racc.x * p.ln_inv_h;
             const float rstd = rsqrtf(fmaxf(racc.y * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
@@ -219,7 +231,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             }
         }
         float ln_mean = 0.f, ln_rstd = 1.f;
-        if (LNF) {
+        if (ROWST) {
             const float2 mr = stat_lds[(wave_id >> 2) * 128 + sm * 16 + frow];
             ln_mean = mr.x; ln_rstd = mr.y;
         }
@@ -235,7 +247,14 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 v[2] = ln_rstd * fmaf(nm, sv[sn].z, v[2]); v[3] = ln_rstd * fmaf(nm, sv[sn].w, v[3]);
             }
             v[0] += bv[sn].x; v[1] += bv[sn].y; v[2] += bv[sn].z; v[3] += bv[sn].w;
-            if (RESID) {
+            if (RESID && RLN) {   // residual = LayerNorm of the stored pre-LN row (never materialised)
+                constexpr int SI = RLN ? 1 : 0;    // (gv / btv have one element in the other instantiations)
+                const float nm = -ln_mean;
+                const float h0 = (__uint_as_float(rcur[sn].x << 16) + nm) * ln_rstd, h1 = (__uint_as_float(rcur[sn].x & 0xFFFF0000u) + nm) * ln_rstd;
+                const float h2 = (__uint_as_float(rcur[sn].y << 16) + nm) * ln_rstd, h3 = (__uint_as_float(rcur[sn].y & 0xFFFF0000u) + nm) * ln_rstd;
+                v[0] += fmaf(h0, gv[sn * SI].x, btv[sn * SI].x); v[1] += fmaf(h1, gv[sn * SI].y, btv[sn * SI].y);
+                v[2] += fmaf(h2, gv[sn * SI].z, btv[sn * SI].z); v[3] += fmaf(h3, gv[sn * SI].w, btv[sn * SI].w);
+            } else if (RESID) {
                 v[0] += __uint_as_float(rcur[sn].x << 16); v[1] += __uint_as_float(rcur[sn].x & 0xFFFF0000u);
                 v[2] += __uint_as_float(rcur[sn].y << 16); v[3] += __uint_as_float(rcur[sn].y & 0xFFFF0000u);
             }
@@ -303,7 +322,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     }
 }
 
-// VAR: 0 plain, 1 LayerNorm-folded consumer (ln_stats / ln_s), 2 row-statistics producer (stats_out)
+// VAR: 0 plain, 1 LayerNorm-folded consumer (ln_stats / ln_s), 2 row-statistics producer (stats_out), 3 producer whose
+// residual is the LayerNorm of the stored pre-LN rows (BERT post-LN: ln_stats / rln_g / rln_b describe R)
 template <int EPI, int VAR = 0, bool DBG = false>
 __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
     BigArgs p = pin;
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
     // ---- epilogue ----
     AG_MARK(123)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (already true: the last half-step waited for 0)
-    wave_epilogue<EPI, VAR == 1, VAR == 2>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
+    wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
     AG_MARK(124)
     if (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     AG_MARK(125)
@@ -530,10 +550,12 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);
 }
 
-int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
-                const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
-                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s) {
+static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                   const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
+                   const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out,
+                   const float* d_rln_g, const float* d_rln_b, hipStream_t s) {
     BigArgs a;
+    a.rln_g = d_rln_g; a.rln_b = d_rln_b;
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
     a.W = (const char*)d_W; a.ldw_b = (long)K * 2;
     a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = (const bf16_t*)d_R; a.ldr = ldr;
@@ -541,6 +563,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     a.M = M; a.N = N; a.K = K;
     a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K; a.stats_out = d_stats_out;
     a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, BT);
+    if (d_rln_g) { a.ln_inv_h = 1.0f / (float)N; a.ln_nslab = ceil_div(N, BT); }   // the statistics describe the residual rows [M, N]
     a.dbg = nullptr;
     a.dyn = g_ag_dyn_rows;
     if (getenv("AG_GEMM_DBG")) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
@@ -570,6 +593,7 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
     }
     const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
     a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
+    if (d_rln_g) return launch_ring_var<AG_EPI_BIAS_RESID, 3>(a, s);
     switch (epilogue) {
         case AG_EPI_BIAS: return launch_ring<AG_EPI_BIAS>(a, s);
         case AG_EPI_BIAS_GELU: return launch_ring<AG_EPI_BIAS_GELU>(a, s);
@@ -578,4 +602,31 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
         case AG_EPI_BIAS_TANH: return launch_ring<AG_EPI_BIAS_TANH>(a, s);
         default: return ag_fail(AG_ERR_INVALID, "ag_gemm_big: unknown epilogue %d", epilogue);
     }
+}
+
+int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
+                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s) {
+    return run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue, d_ln_stats, d_ln_colsum,
+                   ln_eps, d_stats_out, nullptr, nullptr, s);
+}
+
+// C = A·Wᵀ + bias + LayerNorm(Rpre) with the LayerNorm recomputed in the epilogue from the pre-LN rows and their slab
+// statistics, and the statistics of the rows written handed on (see include/autognothi_hip.h).
+extern "C" int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                                const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b,
+                                float ln_eps, int M, int N, int K, float* d_stats_out, void* stream) {
+    if (M == 0) return AG_OK;
+    AG_REQUIRE(d_A && d_W && d_C && d_Rpre && d_r_stats && d_ln_g && d_ln_b && d_stats_out, "ag_gemm_resid_ln: null pointer");
+    AG_REQUIRE(ag_gemm_resid_ln_supported(M, N, K, lda, ldc, ldr), "ag_gemm_resid_ln: shape M=%d N=%d K=%d is not served by the large-M "
+               "bf16 kernel (check ag_gemm_resid_ln_supported first)", M, N, K);
+    AgProfScope prof(AG_EPI_BIAS_RESID, 2.0 * M * (double)N * K, ((double)M * K + (double)N * K + 2.0 * (double)M * N) * 2.0, (hipStream_t)stream,
+                     g_ag_dyn_rows ? (double)M : 0.0);
+    return run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_Rpre, ldr, 1, 1, M, N, K, AG_EPI_BIAS_RESID, d_r_stats, nullptr, ln_eps, d_stats_out,
+                   d_ln_g, d_ln_b, (hipStream_t)stream);
+}
+
+extern "C" int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr) {
+    static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
+    return (!force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID)) ? 1 : 0;
 }

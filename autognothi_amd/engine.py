@@ -74,7 +74,16 @@ def param_key(p: Tensor) -> Tuple:
     of gradients this package's backward has written into it (``_ag_step``, bumped by training._acc_grad / _grad).  The last
     one matters: ``torch.optim.AdamW(fused=True)`` (and the other fused / foreach optimisers that update through
     ``torch._fused_*``) do NOT advance ``_version``, so a cache keyed on it alone keeps serving the weights of step 1."""
-    return (p.data_ptr(), p._version, p.__dict__.get("_ag_step", 0))
+    return (p.data_ptr(), p._version, p.__dict__.get("_ag_step", 0), _WEIGHTS_EPOCH[0])
+
+
+_WEIGHTS_EPOCH = [0]
+
+
+def invalidate_weight_caches() -> None:
+    """Rebuild every weight cache before its next use.  Needed only after parameter updates nothing above can see: in-place
+    writes through ``p.data`` (which carries no version counter) by code that never ran this package's backward."""
+    _WEIGHTS_EPOCH[0] += 1
 
 
 def _versions(params: Sequence[Tensor]) -> Tuple:
@@ -152,6 +161,15 @@ class PackedEncoder:
                                                                 ly.layernorm_before)
                 self.lin[-1]["fc1_ln"] = PackedFoldedLinear([ly.intermediate.dense.weight], [ly.intermediate.dense.bias],
                                                             ly.layernorm_after)
+            else:   # BERT (post-LN): QKV consumes the PREVIOUS layer's output.LayerNorm, fc1 this layer's attention.output.LayerNorm
+                i_ly = len(self.lin) - 1
+                if i_ly >= 1:
+                    self.lin[-1]["qkv_ln"] = PackedFoldedLinear([att.self.query.weight, att.self.key.weight, att.self.value.weight],
+                                                                [att.self.query.bias, att.self.key.bias, att.self.value.bias],
+                                                                self.layers[i_ly - 1].output.LayerNorm)
+                if not isinstance(att.output.LayerNorm, nn.Identity):
+                    self.lin[-1]["fc1_ln"] = PackedFoldedLinear([ly.intermediate.dense.weight], [ly.intermediate.dense.bias],
+                                                                att.output.LayerNorm)
         self._keep: List = []
 
     def _ln(self, ly: nn.Module, which: int) -> Tuple[Optional[Tensor], Optional[Tensor]]:
@@ -173,7 +191,8 @@ class PackedEncoder:
                 keep += [w, b]
                 setattr(lw, cw, w.data_ptr())
                 setattr(lw, cb, b.data_ptr())
-            if dtype == L.AG_BF16 and FOLD_LAYERNORM:
+            # (BERT: only the token-pruned forward reads the folded forms; they are packed when it can run: >= 3 layers)
+            if dtype == L.AG_BF16 and FOLD_LAYERNORM and (self.kind == L.AG_MASK_VIT_MUL or (PRUNE_BERT_TOKENS and len(self.layers) >= 3)):
                 for name, cw, cb, cs in (("qkv_ln", "w_qkv_ln", "b_qkv_ln", "s_qkv_ln"), ("fc1_ln", "w_fc1_ln", "b_fc1_ln", "s_fc1_ln")):
                     if name in self.lin[i]:
                         w, b, s_ = self.lin[i][name].get(dtype)

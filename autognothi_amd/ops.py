@@ -238,6 +238,22 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     return out
 
 
+def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r_stats: Tensor, ln_g: Tensor, ln_b: Tensor,
+                  ln_eps: float, stats_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """A @ W^T + bias + LayerNorm(r_pre) with the LayerNorm recomputed in the epilogue from r_pre's slab statistics
+    (ag_gemm_resid_ln; bf16, ring-kernel shapes only) -> (out [M,N] bf16, its slab statistics)."""
+    L.require_gpu(a, w, bias, r_pre, r_stats, ln_g, ln_b)
+    n, k = w.shape
+    m = a.numel() // k
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    if stats_out is None:
+        stats_out = new_row_stats(m, n, a.device)
+    with L.on(a.device):
+        L.check(L.lib().ag_gemm_resid_ln(L.ptr(a), k, L.ptr(w), L.ptr(bias), L.ptr(out), n, L.ptr(r_pre), n, L.ptr(r_stats), L.ptr(ln_g),
+                                         L.ptr(ln_b), float(ln_eps), m, n, k, L.ptr(stats_out), L.stream()))
+    return out, stats_out
+
+
 def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], ln_g: Optional[Tensor],
              ln_b: Optional[Tensor], eps: float, post_ln: bool) -> Tensor:
     """fused MLP half of a narrow layer (ag_side_mlp): x [M, h] bf16 -> [M, h] bf16."""

@@ -130,6 +130,17 @@ int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, 
             int M, int N, int K, int epilogue, int dtype,
             const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, void* stream);
 int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype);
+/* Post-LN residual without the LayerNorm pass (BERT, models/vanilla_bert.py:556-560 and :600-604: hidden = LayerNorm(dense(x) + input)
+ * where `input` is itself the previous LayerNorm's output):  C = A·Wᵀ + bias + LayerNorm(Rpre)[m, n], bf16, large-M kernel only
+ * (ag_gemm_resid_ln_supported).  Rpre [M, N] (row stride ldr) holds the PRE-LayerNorm rows the previous GEMM wrote, d_r_stats
+ * [ceil(N/256), M, 2] their slab statistics (that GEMM's d_stats_out), ln_g / ln_b [N] the LayerNorm's parameters: the epilogue adds
+ * (Rpre - mean[m]) * rstd[m] * ln_g[n] + ln_b[n] in fp32.  d_stats_out [ceil(N/256), M, 2] (required) receives the statistics of the
+ * rows written — which are again pre-LN rows: their LayerNorm is folded into the next GEMMs (ag_gemm's d_ln_stats) and into the next
+ * residual (this call).  Together: a post-LN block chain in which no LayerNorm output is ever written or read. */
+int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                     const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps,
+                     int M, int N, int K, float* d_stats_out, void* stream);
+int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr);
 /* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
  * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
  * kernel, bf16:   post_ln = 0 (ViT, models/vanilla_vit.py:373-376):  out = x + fc2(gelu(fc1(LN(x))))     (ln_g NULL: no LN)
@@ -228,8 +239,12 @@ typedef struct ag_layer_weights {
     const float* ln1_b;
     const float* ln2_g;  /* ViT layernorm_after  / BERT output.LayerNorm                     */
     const float* ln2_b;
-    /* optional (ViT, bf16): LayerNorm-folded projections — weights pre-scaled by gamma, bias' = b + W·beta,
-     * colsum[n] = sum_k W'[n,k].  NULL = run the LayerNorm kernel.                                         */
+    /* optional (bf16): LayerNorm-folded projections — weights pre-scaled by gamma, bias' = b + W·beta,
+     * colsum[n] = sum_k W'[n,k].  NULL = run the LayerNorm kernel.  Which LayerNorm feeds the projection:
+     *   ViT (pre-LN):   qkv <- this layer's layernorm_before (ln1), fc1 <- this layer's layernorm_after (ln2);
+     *   BERT (post-LN): qkv <- the PREVIOUS layer's output.LayerNorm (ln2 of layer l-1; unused in layer 0),
+     *                   fc1 <- this layer's attention.output.LayerNorm (ln1).  Used by the token-pruned forward, whose
+     *                   packed layers then keep only pre-LN rows + row statistics (ag_gemm_resid_ln).              */
     const void* w_qkv_ln; const float* b_qkv_ln; const float* s_qkv_ln;
     const void* w_fc1_ln; const float* b_fc1_ln; const float* s_fc1_ln;
 } ag_layer_weights;

@@ -234,3 +234,76 @@ def test_ring_auto_nontemporal_output(cuda_device):
     rows = np.unique(np.concatenate([np.arange(0, 300), np.arange(m - 300, m), g.integers(0, m, 600)]))
     ref = a[rows].astype(np.float64) @ w.astype(np.float64).T + b
     np.testing.assert_allclose(out[torch.from_numpy(rows).to(cuda_device)].float().cpu().numpy(), ref, **TOL)
+
+
+@pytest.mark.parametrize("m,n,k", [(1061, 768, 768), (1157, 768, 3072), (1300, 1024, 4096), (1030, 264, 160)])
+def test_ring_residual_is_layernorm_of_stored_rows(cuda_device, m, n, k):
+    """VAR = 3 (ag_gemm_resid_ln; BERT post-LN chain): out = A W^T + b + LayerNorm(Rpre), the LayerNorm recomputed in the epilogue
+    from the stored pre-LN rows and their slab statistics (eps 1e-12 as BERT), plus the statistics of the rows written."""
+    from autognothi_amd import _lib as L, ops
+    g, a, w, b, ref = _case(m, n, k, 5 * m + n)
+    dev = cuda_device
+    assert L.lib().ag_gemm_resid_ln_supported(m, n, k, k, n, n) == 1
+    r = _r((g.standard_normal((m, n)) * 1.7 + 0.3).astype(np.float32))
+    gamma = (1 + 0.2 * g.standard_normal(n)).astype(np.float32)
+    beta = (0.2 * g.standard_normal(n)).astype(np.float32)
+    R = _dev(r, dev)
+    r_st = ops.row_stats(R)
+    out, st = ops.gemm_resid_ln(_dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), R, r_st, torch.from_numpy(gamma).to(dev),
+                                torch.from_numpy(beta).to(dev), 1e-12)
+    ln = otr.layer_norm(r, {"ln.weight": gamma, "ln.bias": beta}, "ln", 1e-12).astype(np.float64)
+    o = out.float().cpu().numpy()
+    np.testing.assert_allclose(o, ref + ln, **TOL)
+    got = ops.reduce_row_stats(st, m, n).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], o.astype(np.float64).sum(1), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(got[:, 1], (o.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    out2, st2 = ops.gemm_resid_ln(_dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), R, r_st, torch.from_numpy(gamma).to(dev),
+                                  torch.from_numpy(beta).to(dev), 1e-12)
+    assert torch.equal(out2, out) and torch.equal(st2, st)
+
+
+def test_ring_post_ln_chain_without_layernorm_passes(cuda_device):
+    """two BERT sub-blocks chained as encoder.cpp chains them — h1 = ctx Wo^T + bo + x (statistics), inter = gelu(LN1(h1) W1^T + b1)
+    folded, h2 = inter W2^T + b2 + LN1(h1) recomputed (statistics), q = LN2(h2) Wq^T + bq folded — against the same chain with
+    the LayerNorms materialised in float64; with a data-dependent row count (ag_dynamic_rows) on top."""
+    from autognothi_amd import _lib as L, ops
+    m, h, i = 1411, 768, 3072
+    g = np.random.default_rng(123)
+    dev = cuda_device
+    f = lambda *s_: g.standard_normal(s_).astype(np.float32)   # noqa: E731
+    ctx, x = _r(f(m, h)), _r(f(m, h) * 1.5)
+    wo, w1, w2, wq = _r(f(h, h) / np.sqrt(h)), f(i, h) / np.sqrt(h), _r(f(h, i) / np.sqrt(i)), f(h, h) / np.sqrt(h)
+    bo, b1, b2, bq = f(h), f(i), f(h), f(h)
+    g1, be1, g2, be2 = 1 + 0.1 * f(h), 0.1 * f(h), 1 + 0.1 * f(h), 0.1 * f(h)
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)   # noqa: E731
+
+    def fold(w_, b_, gam, bet):
+        wf = torch.from_numpy(w_ * gam[None, :]).to(dev).to(torch.bfloat16)
+        return wf, t((b_ + w_ @ bet).astype(np.float32)), wf.float().sum(1).contiguous()
+
+    def chain(rows_dev=None):
+        import contextlib
+        cm = ops.dynamic_rows(rows_dev) if rows_dev is not None else contextlib.nullcontext()
+        with cm:
+            st1 = ops.new_row_stats(m, h, dev)
+            h1 = ops.gemm(_dev(ctx, dev), _dev(wo, dev), t(bo), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(x, dev), stats_out=st1)
+            w1f, b1f, s1f = fold(w1, b1, g1, be1)
+            inter = ops.gemm(h1, w1f, b1f, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st1, ln_colsum=s1f, ln_eps=1e-12)
+            h2, st2 = ops.gemm_resid_ln(inter, _dev(w2, dev), t(b2), h1, st1, t(g1), t(be1), 1e-12)
+            wqf, bqf, sqf = fold(wq, bq, g2, be2)
+            q = ops.gemm(h2, wqf, bqf, L.AG_EPI_BIAS, BF16, ln_stats=st2, ln_colsum=sqf, ln_eps=1e-12)
+        return h1, inter, h2, q
+
+    h1, inter, h2, q = chain()
+    h1n, intern, h2n = [v.float().cpu().numpy() for v in (h1, inter, h2)]
+    lnp = lambda v, gam, bet: otr.layer_norm(v, {"ln.weight": gam, "ln.bias": bet}, "ln", 1e-12).astype(np.float64)   # noqa: E731
+    np.testing.assert_allclose(h1n, ctx.astype(np.float64) @ wo.astype(np.float64).T + bo + x, **TOL)
+    np.testing.assert_allclose(intern, otr.gelu((lnp(h1n, g1, be1) @ w1.astype(np.float64).T + b1).astype(np.float32)), rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(h2n, intern.astype(np.float64) @ w2.astype(np.float64).T + b2 + lnp(h1n, g1, be1), **TOL)
+    np.testing.assert_allclose(q.float().cpu().numpy(), lnp(h2n, g2, be2) @ wq.astype(np.float64).T + bq, rtol=2e-2, atol=3e-2)
+    # the same launches sized for m rows but told (on the device) that only 1037 exist: rows [0, 1037) identical, the rest untouched
+    n_live = 1037
+    cnt = torch.tensor([n_live], dtype=torch.int32, device=dev)
+    d1, di, d2, dq = chain(cnt)
+    for full, part in ((h1, d1), (inter, di), (h2, d2), (q, dq)):
+        assert torch.equal(full[:n_live], part[:n_live])
