@@ -25,7 +25,29 @@ constexpr int HALF_OP_BYTES = BT * HROWB;       // 16 KiB per operand per half-s
 constexpr int SLOT_BYTES = 2 * HALF_OP_BYTES;   // 32 KiB
 constexpr int NSLOT = 4;
 constexpr int NT = 512;
-constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + BT * 8;   // ring + one (mean, rstd) pair per tile row (LayerNorm-fold consumer)
+// LDS tail behind the ring: what a tile's epilogue needs from memory besides the residual, fetched while the ring fills for the
+// first time (kernel start) instead of at the start of the epilogue, where the matrix cores are idle and an L2 round trip is paid
+// in full: one (mean, rstd) pair per tile row (LayerNorm-fold consumer / residual-LayerNorm variant) and three per-column
+// constants (bias | folded column sums or residual-LN gamma | residual-LN beta)
+constexpr int TAIL_STAT = 0, TAIL_C0 = BT * 8, TAIL_C1 = TAIL_C0 + BT * 4, TAIL_C2 = TAIL_C1 + BT * 4, TAIL_BYTES = TAIL_C2 + BT * 4;
+constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + TAIL_BYTES;
+
+// loads the compiler does not see (no s_waitcnt of its own on them: its vmcnt bookkeeping does not know the LDS-DMA loads
+// issued after these, so a wait of its making would drain the whole prologue): waited for by the counted wait that the
+// prologue needs anyway, and tied to it with gload_landed()
+__device__ __forceinline__ float gload_f32_async(const float* ptr) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v_t gload_f32x2_async(const float* ptr) {
+    f32x2v_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gload_landed(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void gload_landed(f32x2v_t& v) { asm volatile("" : "+v"(v)); }
 
 struct BigArgs {
     const char* A; long lda_b;
@@ -128,68 +150,30 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     constexpr int STAT_OFF = 8192;  // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its 16 KB
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
 
-    // ---- row constants (LayerNorm fold) ----
-    // Each of the tile's 256 rows is finished ONCE per workgroup: wave (wm, wn) takes rows [32 wn, 32 wn + 32) of its half,
-    // lanes 0..31 add the row's S slab partials in slab order, turn them into (mean, rstd) and park the pair in the LDS
-    // tail behind the ring; the barrier below (which the epilogue needs anyway: the staging buffers live in the ring)
-    // publishes them, and the row loop reads its pair back with one ds_read_b64.  The loads are requested before the
-    // column constants so that both batches are in flight together.
-    float2* const stat_lds = reinterpret_cast<float2*>(const_cast<char*>(smem_base) + NSLOT * SLOT_BYTES);
+    // ---- row and column constants: parked in the LDS tail by the kernel's prologue (tile_constants_*) ----
+    const char* const tail = smem_base + NSLOT * SLOT_BYTES;
+    const float2* const stat_lds = reinterpret_cast<const float2*>(tail + TAIL_STAT);
     const int wave_id = (int)((stg - smem_base) >> 14);
-    float2 racc = make_float2(0.f, 0.f);
     constexpr bool ROWST = LNF || RLN;   // this tile's rows need (mean, rstd): of the A rows (fold) or of the residual rows
-    if (ROWST && lane < 32) {
-        int m = mw0 + (wave_id & 3) * 32 + lane;
-        m = m < p.M ? m : p.M - 1;
-        const float* sp = p.ln_stats + 2 * (long)m;
-        // up to four slabs (H <= 1024: every shipped width) requested together, added in slab order
-        float2 v[4];
+    float4 bv[4], sv[4];
+    float4 gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
 #pragma unroll
-        for (int s_i = 0; s_i < 4; ++s_i) v[s_i] = *reinterpret_cast<const float2*>(sp + (s_i < p.ln_nslab ? s_i : 0) * p.stats_slab);
-        racc = v[0];
-#pragma unroll
-        for (int s_i = 1; s_i < 4; ++s_i) {
-            racc.x += s_i < p.ln_nslab ? v[s_i].x : 0.f; racc.y += s_i < p.ln_nslab ? v[s_i].y : 0.f;
-        }
-        for (int s_i = 4; s_i < p.ln_nslab; ++s_i) {      // wider rows: one more round trip per slab
-            const float2 w = *reinterpret_cast<const float2*>(sp + s_i * p.stats_slab);
-            racc.x += w.x; racc.y += w.y;
+    for (int sn = 0; sn < 4; ++sn) {
+        const int cl = (wave_id & 3) * 64 + sn * 16 + fq * 4;          // tile-local column of this lane's four outputs
+        bv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C0 + cl * 4);
+        sv[sn] = LNF ? *reinterpret_cast<const float4*>(tail + TAIL_C1 + cl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RLN) {
+            gv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C1 + cl * 4);
+            btv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C2 + cl * 4);
         }
     }
-    // ---- column constants ----
-    float4 bv[4], sv[4];
     int ncl[4];
 #pragma unroll
     for (int sn = 0; sn < 4; ++sn) {
         const int n = nw0 + sn * 16 + fq * 4;
         ncl[sn] = n < p.N ? n : p.N - 4;
-        bv[sn] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sv[sn] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (p.bias) {
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) bv[sn] = *reinterpret_cast<const float4*>(p.bias + ncl[sn]);
-    }
-    if (LNF) {
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) sv[sn] = *reinterpret_cast<const float4*>(p.ln_s + ncl[sn]);
-    }
-    float4 gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
-    if (RLN) {
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-            gv[sn] = *reinterpret_cast<const float4*>(p.rln_g + ncl[sn]);
-            btv[sn] = *reinterpret_cast<const float4*>(p.rln_b + ncl[sn]);
-        }
-    }
-    if (ROWST) {
-        if (lane < 32) {
-            const float mean = racc.x * p.ln_inv_h;
-            const float rstd = rsqrtf(fmaxf(racc.y * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
-            stat_lds[(wave_id >> 2) * 128 + (wave_id & 3) * 32 + lane] = make_float2(mean, rstd);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!OUT_F32) asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring (the staging buffers reuse it)
     // residual row of output row m: ((m / T) / share) * T + (m % T); walked incrementally (m advances by 16)
     int r_t = 0, r_seq_rem = 0;
@@ -392,6 +376,29 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
         glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
                      ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
     };
+    // ---- tile constants: requested BEFORE the ring's first fill (so that they are the oldest loads in flight) and parked in the
+    // LDS tail once the prologue's counted wait has let them land; the epilogue then needs nothing from memory but the residual
+    constexpr bool ROWST = (VAR == 1 || VAR == 3);
+    float c_a = 0.f, c_b = 0.f;
+    f32x2v_t c_st[4] = {f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}};
+    {
+        int n = n0 + (tid & 255);
+        n = n < p.N ? n : p.N - 1;
+        if (tid < 256) {                                   // (wave-uniform: waves 0-3 / 4-7)
+            if (p.bias) c_a = gload_f32_async(p.bias + n);
+            if (VAR == 3) c_b = gload_f32_async(p.rln_b + n);
+        } else {
+            if (VAR == 1) c_a = gload_f32_async(p.ln_s + n);
+            if (VAR == 3) c_a = gload_f32_async(p.rln_g + n);
+        }
+        if (ROWST && lane < 32) {   // wave (wm, wn) finishes rows [32 wn, 32 wn + 32) of its half: up to four slabs (H <= 1024) at once
+            int m = m0 + wm * 128 + wn * 32 + lane;
+            m = m < p.M ? m : p.M - 1;
+            const float* sp = p.ln_stats + 2 * (long)m;
+#pragma unroll
+            for (int s_i = 0; s_i < 4; ++s_i) c_st[s_i] = gload_f32x2_async(sp + (s_i < p.ln_nslab ? s_i : 0) * p.stats_slab);
+        }
+    }
     // prologue: half-steps 0..3 into slots 0..3 (4 pieces per wave per half-step)
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j)
@@ -416,6 +423,38 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
     };
     AG_MARK(121)
     wait_ahead(min(nh - 1, 3));                     // slot 0 (this wave's pieces) before barrier #0
+    {   // everything older than slot 0 has landed too: the tile constants.  Into the LDS tail (read in the epilogue, many barriers on)
+        gload_landed(c_a); gload_landed(c_b);
+        char* const tail = smem + NSLOT * SLOT_BYTES;
+        if (tid < 256) {
+            *reinterpret_cast<float*>(tail + TAIL_C0 + (tid & 255) * 4) = c_a;
+            if (VAR == 3) *reinterpret_cast<float*>(tail + TAIL_C2 + (tid & 255) * 4) = c_b;
+        } else if (VAR == 1 || VAR == 3) {
+            *reinterpret_cast<float*>(tail + TAIL_C1 + (tid & 255) * 4) = c_a;
+        }
+        if (ROWST) {
+#pragma unroll
+            for (int s_i = 0; s_i < 4; ++s_i) gload_landed(c_st[s_i]);
+            if (lane < 32) {
+                float sx = c_st[0].x, sq = c_st[0].y;   // slabs added in slab order: bit-reproducible
+#pragma unroll
+                for (int s_i = 1; s_i < 4; ++s_i) {
+                    sx += s_i < p.ln_nslab ? c_st[s_i].x : 0.f; sq += s_i < p.ln_nslab ? c_st[s_i].y : 0.f;
+                }
+                if (p.ln_nslab > 4) {                   // wider rows (H > 1024: none shipped): plain loads, one round trip per slab
+                    int m = m0 + wm * 128 + wn * 32 + lane;
+                    m = m < p.M ? m : p.M - 1;
+                    for (int s_i = 4; s_i < p.ln_nslab; ++s_i) {
+                        const float2 w = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m + s_i * p.stats_slab);
+                        sx += w.x; sq += w.y;
+                    }
+                }
+                const float mean = sx * p.ln_inv_h;
+                const float rstd = rsqrtf(fmaxf(sq * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
+                *reinterpret_cast<float2*>(tail + TAIL_STAT + (wm * 128 + wn * 32 + lane) * 8) = make_float2(mean, rstd);
+            }
+        }
+    }
     AG_MARK(122)
     if (grp == 1) asm volatile("s_barrier" ::: "memory");
     // this wave's LDS-DMA pieces: 2 of A, 2 of W per half-step
