@@ -78,6 +78,10 @@ SIGNATURES = {
     "ag_gelu_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
     "ag_tanh_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
     "ag_add_f32": (i32, [vp, vp, vp, i64, vp]),
+    "ag_dropout_add_f32": (i32, [vp, vp, vp, i64, f32, u32, vp]),
+    "ag_gelu_cast_transpose_f32_bf16": (i32, [vp, i32, i32, vp, vp, i64, vp]),
+    "ag_gelu_bwd_cast_transpose_f32_bf16": (i32, [vp, vp, i32, i32, vp, vp, vp, i64, vp]),
+    "ag_layernorm_bwd_add": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, vp]),
     "ag_dropout_f32": (i32, [vp, vp, i64, f32, u32, vp]),
     "ag_softmax_rows_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
     "ag_layernorm_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, vp, vp]),

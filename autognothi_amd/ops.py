@@ -478,6 +478,31 @@ def cast_transpose_bf16(src: Tensor, pad_cols_to: int = 1) -> Tuple[Tensor, Tens
     return plain, dst
 
 
+def gelu_cast_transpose_bf16(u: Tensor, pad_cols_to: int = 1) -> Tuple[Tensor, Tensor]:
+    """gelu(u) as ([R,C] bf16, [C,Rp] bf16) in one pass over u (the fp32 GELU output is never written)."""
+    s = _f32c(u)
+    r, c = s.shape
+    rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    plain = torch.empty((r, c), dtype=torch.bfloat16, device=s.device)
+    dst = torch.empty((c, rp), dtype=torch.bfloat16, device=s.device)
+    with L.on(s.device):
+        L.check(L.lib().ag_gelu_cast_transpose_f32_bf16(L.ptr(s), r, c, L.ptr(plain), L.ptr(dst), rp, L.stream()))
+    return plain, dst
+
+
+def gelu_bwd_cast_transpose_bf16(u: Tensor, dy: Tensor, pad_cols_to: int = 1, want_f32: bool = True):
+    """du = dy * gelu'(u) -> (du fp32 or None, [R,C] bf16, [C,Rp] bf16) in one pass."""
+    u, dy = _f32c(u), _f32c(dy)
+    r, c = dy.shape
+    rp = (r + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    du = torch.empty_like(dy) if want_f32 else None
+    plain = torch.empty((r, c), dtype=torch.bfloat16, device=dy.device)
+    dst = torch.empty((c, rp), dtype=torch.bfloat16, device=dy.device)
+    with L.on(dy.device):
+        L.check(L.lib().ag_gelu_bwd_cast_transpose_f32_bf16(L.ptr(u), L.ptr(dy), r, c, L.ptr(du), L.ptr(plain), L.ptr(dst), rp, L.stream()))
+    return du, plain, dst
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     x = _f32c(x)
     m, n = x.shape
@@ -524,6 +549,15 @@ def dropout(x: Tensor, p: float, seed: int) -> Tensor:
     return y
 
 
+def dropout_add(x: Tensor, resid: Tensor, p: float, seed: int) -> Tensor:
+    """resid + dropout(x) in one pass (p = 0: the plain sum)."""
+    x, resid = _f32c(x), _f32c(resid)
+    y = torch.empty_like(x)
+    with L.on(x.device):
+        L.check(L.lib().ag_dropout_add_f32(L.ptr(x), L.ptr(resid), L.ptr(y), x.numel(), float(max(p, 0.0)), seed & 0xFFFFFFFF, L.stream()))
+    return y
+
+
 def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
     y, dy = _f32c(y), _f32c(dy)
     dx = torch.empty_like(y)
@@ -533,16 +567,17 @@ def softmax_rows_bwd(y: Tensor, dy: Tensor) -> Tensor:
 
 
 def layernorm_bwd(x: Tensor, gamma: Optional[Tensor], dy: Tensor, eps: float, dgamma: Optional[Tensor] = None,
-                  dbeta: Optional[Tensor] = None, accumulate: bool = True) -> Tensor:
-    """x, dy [rows, H] fp32 -> dx; dgamma / dbeta ([H]) accumulated in place when given."""
+                  dbeta: Optional[Tensor] = None, accumulate: bool = True, add: Optional[Tensor] = None) -> Tensor:
+    """x, dy [rows, H] fp32 -> dx (+ add: the gradient of the residual branch); dgamma / dbeta ([H]) accumulated in place when given."""
     x, dy = _f32c(x), _f32c(dy)
+    add = _f32c(add) if add is not None else None
     h = x.shape[-1]
     rows = x.numel() // h
     dx = torch.empty_like(x)
     scratch = torch.empty(256 * 2 * h, dtype=torch.float32, device=x.device)
     with L.on(x.device):
-        L.check(L.lib().ag_layernorm_bwd(L.ptr(x), L.ptr(gamma), L.ptr(dy), rows, h, eps, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
-                                         1 if accumulate else 0, L.ptr(scratch), L.stream()))
+        L.check(L.lib().ag_layernorm_bwd_add(L.ptr(x), L.ptr(gamma), L.ptr(dy), L.ptr(add), rows, h, eps, L.ptr(dx), L.ptr(dgamma),
+                                             L.ptr(dbeta), 1 if accumulate else 0, L.ptr(scratch), L.stream()))
     return dx
 
 

@@ -181,7 +181,25 @@ class Lin:
             self.x = x
         return _mm(x, w, b, epilogue, x.shape[0], None)
 
-    def backward(self, dy: Tensor, need_dx: bool = True) -> Optional[Tensor]:
+    def forward_gelu(self, u: Tensor) -> Tensor:
+        """forward(gelu(u)).  Mixed mode, trainable: GELU is applied inside the pass that makes the two bf16 operand forms, the
+        fp32 GELU output never exists (the backward recomputes gelu' from u: Block keeps u)."""
+        if MIXED_BF16 and self.trainable() and u.shape[-1] % 8 == 0:
+            _, b = self._w()
+            xb, self.xt = ops.gelu_cast_transpose_bf16(u, pad_cols_to=PAD)
+            return ops.gemm(xb, self._w_pair()[0], b, L.AG_EPI_BIAS_F32, L.AG_BF16, m=u.shape[0])
+        return self.forward(ops.gelu(u))
+
+    def backward_gelu(self, u: Tensor, dg: Tensor, need_dx: bool = True) -> Optional[Tensor]:
+        """backward(dg * gelu'(u)) for this Linear's OUTPUT pre-activation u (fc1): mixed mode fuses gelu' into the operand pass."""
+        w, _ = self._w()
+        n, k = w.shape
+        if MIXED_BF16 and self.trainable() and n % PAD == 0 and k % 8 == 0:
+            du, dyb, dyt = ops.gelu_bwd_cast_transpose_bf16(u, dg, pad_cols_to=PAD)
+            return self.backward(du, need_dx, pre=(dyb, dyt))
+        return self.backward(ops.gelu_bwd(u, dg), need_dx)
+
+    def backward(self, dy: Tensor, need_dx: bool = True, pre: Optional[Tuple[Tensor, Tensor]] = None) -> Optional[Tensor]:
         w, _ = self._w()
         n, k = w.shape
         m = dy.shape[0]
@@ -189,7 +207,9 @@ class Lin:
         train = self.trainable()
         if MIXED_BF16 and n % PAD == 0 and k % 8 == 0:
             # dy and dy^T as bf16 from one launch; dX = dY . W against W^T [K, N], dW = dY^T . X against X^T [K, Mp]
-            if train:
+            if pre is not None:
+                dyb, dyt = pre
+            elif train:
                 dyb, dyt = ops.cast_transpose_bf16(dy, pad_cols_to=PAD)
             else:
                 dyb, dyt = ops.cast(dy, L.AG_BF16), None
@@ -249,16 +269,18 @@ class Norm:
                              want_store=False, want_f32=True)
         return y
 
-    def backward(self, dy: Tensor) -> Tensor:
+    def backward(self, dy: Tensor, add: Optional[Tensor] = None) -> Tensor:
+        """-> dx (+ ``add``: a gradient that joins over the residual branch, summed in the same pass)."""
         if self.identity:
-            return dy
+            return dy if add is None else ops.add(dy, add)
         train = self.mod.weight.requires_grad
         fresh = train and self.mod.weight.grad is None and self.mod.bias.grad is None
         if fresh:   # first contribution of the step: the kernel stores instead of accumulating (no zero fill)
             self.mod.weight.grad = torch.empty_like(self.mod.weight, dtype=torch.float32)
             self.mod.bias.grad = torch.empty_like(self.mod.bias, dtype=torch.float32)
         dx = ops.layernorm_bwd(self.x, self.mod.weight.detach().float(), dy, self.eps,
-                               _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=not fresh)
+                               _grad(self.mod.weight) if train else None, _grad(self.mod.bias) if train else None, accumulate=not fresh,
+                               add=add)
         self.x = None
         if train:
             _final(self.mod.weight, self.mod.bias)
@@ -287,13 +309,10 @@ class Block:
         u1 = self.n1.forward(h) if vit else h
         qkv = self.qkv.forward(u1)
         ctx = ops.masked_attention_train(qkv, bits, rows, t, hdim, self.heads, self.kind, pa, s_att, mixed=MIXED_BF16).view(rows * t, hdim)
-        ao = ops.dropout(self.o.forward(ctx), ph, s_o)
-        hx = ops.add(h, ao)
+        hx = ops.dropout_add(self.o.forward(ctx), h, ph, s_o)         # h + dropout(dense(ctx)) in one pass
         u2 = self.n2.forward(hx) if vit else self.n1.forward(hx)
         f1 = self.fc1.forward(u2)
-        g = ops.gelu(f1)
-        f2 = ops.dropout(self.fc2.forward(g), ph, s_f)
-        out = ops.add(hx if vit else u2, f2)
+        out = ops.dropout_add(self.fc2.forward_gelu(f1), hx if vit else u2, ph, s_f)
         if not vit:
             out = self.n2.forward(out)
         self.saved = (qkv, ctx, f1, bits, rows, t, hdim, ph, pa, s_att, s_o, s_f)
@@ -303,17 +322,16 @@ class Block:
         qkv, ctx, f1, bits, rows, t, hdim, ph, pa, s_att, s_o, s_f = self.saved
         vit = self.kind == L.AG_MASK_VIT_MUL
         if vit:
-            dhx = dout
-            du2 = self.fc1.backward(ops.gelu_bwd(f1, self.fc2.backward(ops.dropout(dout, ph, s_f))))
-            dhx = ops.add(dhx, self.n2.backward(du2))
+            du2 = self.fc1.backward_gelu(f1, self.fc2.backward(ops.dropout(dout, ph, s_f)))
+            dhx = self.n2.backward(du2, add=dout)              # + the gradient over the residual branch, in the same pass
             dctx = self.o.backward(ops.dropout(dhx, ph, s_o))
             dqkv = ops.masked_attention_bwd(qkv.view(rows, t, 3 * hdim), bits, ctx.view(rows, t, hdim), dctx.view(rows, t, hdim),
                                             rows, t, hdim, self.heads, self.kind, pa, s_att, mixed=MIXED_BF16).view(rows * t, 3 * hdim)
             du1 = self.qkv.backward(dqkv)
-            dh = ops.add(dhx, self.n1.backward(du1))
+            dh = self.n1.backward(du1, add=dhx)
         else:
             dsum = self.n2.backward(dout)                       # d(f2 + a)
-            da = self.fc1.backward(ops.gelu_bwd(f1, self.fc2.backward(ops.dropout(dsum, ph, s_f))))
+            da = self.fc1.backward_gelu(f1, self.fc2.backward(ops.dropout(dsum, ph, s_f)))
             da = ops.add(da, dsum)
             dpre = self.n1.backward(da)                         # d(ao + h)
             dctx = self.o.backward(ops.dropout(dpre, ph, s_o))

@@ -295,6 +295,12 @@ int ag_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, v
 /* Both bf16 operand forms of an fp32 matrix in one pass: d_plain [rows, cols] (dense) and d_dst_t [cols, ldd] (as above). */
 int ag_cast_transpose_f32_bf16(const float* d_src, int rows, int cols, int64_t lds, void* d_plain, void* d_dst_t, int64_t ldd,
                                void* stream);
+/* The same pass with the exact-erf GELU applied on the way (mixed-precision training, fc1 -> fc2): d_plain / d_dst_t hold gelu(u);
+ * the fp32 GELU output is never written (the backward recomputes from u).  cols % 4 == 0, ldd % 4 == 0. */
+int ag_gelu_cast_transpose_f32_bf16(const float* d_u, int rows, int cols, void* d_plain, void* d_dst_t, int64_t ldd, void* stream);
+/* ... and its backward: du = dy * gelu'(u) as both bf16 operand forms, and (d_du != NULL) in fp32 for the bias sums. */
+int ag_gelu_bwd_cast_transpose_f32_bf16(const float* d_u, const float* d_dy, int rows, int cols, float* d_du, void* d_plain,
+                                        void* d_dst_t, int64_t ldd, void* stream);
 /* out[n] (+)= sum_m x[m, n]  (bias gradients). */
 int ag_colsum_f32(const float* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, void* stream);
 /* exact-erf GELU (nn.GELU default) and its derivative: du = dy * gelu'(u). */
@@ -306,12 +312,17 @@ int ag_add_f32(const float* d_a, const float* d_b, float* d_y, int64_t n, void* 
 /* inverted dropout with a counter-based keep decision hash(seed, index): y = keep ? x/(1-p) : 0.
  * Calling it on dy with the same (p, seed) is the backward (nn.Dropout, p = hidden_dropout_prob). */
 int ag_dropout_f32(const float* d_x, float* d_y, int64_t n, float p, uint32_t seed, void* stream);
+/* y = resid + dropout(x)  (models/vanilla_vit.py:372,:512-513 / vanilla_bert.py:558-559: hidden = residual + dropout(dense)). */
+int ag_dropout_add_f32(const float* d_x, const float* d_resid, float* d_y, int64_t n, float p, uint32_t seed, void* stream);
 /* dx = y * (dy - sum_c y*dy)  for y = softmax(x) rows. */
 int ag_softmax_rows_bwd(const float* d_y, const float* d_dy, float* d_dx, int rows, int C, void* stream);
 /* LayerNorm backward: dx [rows,H]; dgamma/dbeta [H] (= or += when accumulate); gamma may be NULL (ones).
  * d_scratch: >= 256*2*H floats. */
 int ag_layernorm_bwd(const float* d_x, const float* d_gamma, const float* d_dy, int rows, int H, float eps,
                      float* d_dx, float* d_dgamma, float* d_dbeta, int accumulate, float* d_scratch, void* stream);
+/* ... with an addend: dx = d_add + LayerNorm backward (the gradient arriving over the residual branch; d_add may be NULL). */
+int ag_layernorm_bwd_add(const float* d_x, const float* d_gamma, const float* d_dy, const float* d_add, int rows, int H, float eps,
+                         float* d_dx, float* d_dgamma, float* d_dbeta, int accumulate, float* d_scratch, void* stream);
 /* fp32 masked attention forward WITH attention-probability dropout (training); p_drop = 0 is the plain
  * forward.  Same layout as ag_masked_attention (AG_F32). */
 int ag_masked_attention_train(const float* d_qkv, const uint32_t* d_mask_bits, float* d_ctx, int R, int T, int H,

@@ -374,3 +374,57 @@ def test_fused_optimizer_leaves_no_stale_weight_cache(cuda_device, tag, mixed):
         assert float((inf_a - phi_start).abs().max()) > 1e-4          # (and the three steps did move the explainer)
     finally:
         T.MIXED_BF16 = False
+
+
+@pytest.mark.parametrize("r,c", [(1576, 768), (1576, 3072), (1000, 100), (37, 8), (64, 64), (130, 2304), (5, 10)])
+def test_operand_form_kernels(cuda_device, r, c):
+    """the passes that make a mixed-precision Linear's bf16 operand forms ([R,C] and the zero-padded transpose [C,Rp]) — plain,
+    with GELU applied on the way (fc2's operand) and with GELU' (fc1's incoming gradient, + its fp32 copy) — against torch;
+    64x64 vector kernel for widths that are multiples of 4, the 32x32 scalar one otherwise (c = 10: num_labels)."""
+    from autognothi_amd import ops
+    g = torch.Generator().manual_seed(r * 7 + c)
+    x = torch.randn((r, c), generator=g) * 1.5
+    dy = torch.randn((r, c), generator=g)
+    xd, dyd = x.to(cuda_device), dy.to(cuda_device)
+    rp = (r + 31) // 32 * 32
+
+    def check(plain, tr, want):
+        wb = want.to(torch.bfloat16)
+        assert plain.shape == (r, c) and tr.shape == (c, rp)
+        assert torch.equal(plain.cpu(), wb)
+        assert torch.equal(tr[:, :r].cpu(), wb.t())
+        assert not bool(tr[:, r:].any())                      # the padding is written (zeros): the GEMM reads it
+
+    check(*ops.cast_transpose_bf16(xd, pad_cols_to=32), x)
+    assert torch.equal(ops.transpose_bf16(xd, pad_cols_to=32)[:, :r].cpu(), x.to(torch.bfloat16).t())
+    if c % 4 == 0:
+        gl = torch.nn.functional.gelu(x.double()).float()
+        p_, t_ = ops.gelu_cast_transpose_bf16(xd, pad_cols_to=32)
+        # erff / expf differ from torch's by an ulp or two of fp32: compare in fp32 with a bf16-ulp allowance at rounding ties
+        np.testing.assert_allclose(p_.float().cpu().numpy(), gl.numpy(), rtol=8e-3, atol=1e-6)
+        assert torch.equal(t_[:, :r], p_.t()) and not bool(t_[:, r:].any())
+        xg = x.double().requires_grad_(True)
+        torch.nn.functional.gelu(xg).backward(dy.double())
+        du, p2, t2 = ops.gelu_bwd_cast_transpose_bf16(xd, dyd, pad_cols_to=32)
+        np.testing.assert_allclose(du.cpu().numpy(), xg.grad.float().numpy(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(p2, du.to(torch.bfloat16)) and torch.equal(t2[:, :r], p2.t()) and not bool(t2[:, r:].any())
+        assert torch.equal(du, ops.gelu_bwd(xd, dyd))          # the fused form is the stand-alone kernel's arithmetic
+
+
+def test_fused_residual_kernels(cuda_device):
+    """resid + dropout(x) in one pass == the two kernels it replaces (same keep decisions), p = 0 == plain add; LayerNorm backward
+    with the residual-branch gradient added in the same pass == layernorm_bwd + add."""
+    from autognothi_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x, res, dy = [torch.randn((777, 768), generator=g).to(cuda_device) for _ in range(3)]
+    for p in (0.0, 0.1, 0.5):
+        want = ops.add(res, ops.dropout(x, p, 1234))
+        assert torch.equal(ops.dropout_add(x, res, p, 1234), want)
+    gamma = (1 + 0.1 * torch.randn(768, generator=g)).to(cuda_device)
+    dg1, db1 = torch.zeros(768, device=cuda_device), torch.zeros(768, device=cuda_device)
+    dg2, db2 = torch.zeros(768, device=cuda_device), torch.zeros(768, device=cuda_device)
+    a = ops.add(ops.layernorm_bwd(x, gamma, dy, 1e-12, dg1, db1), res)
+    b = ops.layernorm_bwd(x, gamma, dy, 1e-12, dg2, db2, add=res)
+    torch.testing.assert_close(b, a, rtol=0, atol=0)
+    torch.testing.assert_close(dg2, dg1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db2, db1, rtol=1e-5, atol=1e-5)
