@@ -259,15 +259,17 @@ template <typename T, int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
     // 128^2 tiles unless they would leave most of the 256 CUs (2 workgroups each) without work: the training steps run
     // on a few images (M = B*T ~ 1.5 k rows) and their dW GEMMs have N x K outputs of a few dozen 128^2 tiles.
-    // Ring depth (tools/gemm_small.py, L2-warm): two slots of 16 / 32 KiB leave room for more workgroups per CU and win on
-    // short K; 64^2 tiles with K >= 4 KiB per row (fc2 and its dX: 48 slices) gain 12-27 % from four slots.  The 8-slot
-    // variant (one workgroup per CU) lost everywhere and is gone.  AG_GEMM_NST = 2 / 4 overrides (dev knob, read once).
+    // Ring depth.  64^2 tiles: four slots of 16 KiB.  Back to back on L2-warm operands (tools/gemm_small.py) two slots — more
+    // workgroups per CU — win by 5-10 % on short K and lose 12-27 % on K >= 2048; inside the training step, where every operand was
+    // written by the previous kernel, four slots win for every K (step: ViT-base 18.57 -> 18.03 ms, duo BERT-base 11.44 -> 10.87 ms
+    // against two slots everywhere).  The 8-slot variant (one workgroup per CU) lost everywhere and is gone; 128^2 tiles keep two
+    // slots of 32 KiB (two workgroups per CU).  AG_GEMM_NST = 2 / 4 overrides (dev knob, read once).
     const long tiles128 = (long)ceil_div(a.M, 128) * ceil_div(a.N, 128);
     static const int bt_env = getenv("AG_GEMM_BT") ? atoi(getenv("AG_GEMM_BT")) : 0;
     static const int nst_env = getenv("AG_GEMM_NST") ? atoi(getenv("AG_GEMM_NST")) : 0;
     if (bt_env == 64 || (bt_env == 0 && tiles128 < 384)) {
-        if (nst_env == 4 || (nst_env == 0 && a.kbytes >= 4096)) return launch_bt<T, EPI, 64, 4>(a, s);
-        return launch_bt<T, EPI, 64, 2>(a, s);
+        if (nst_env == 2) return launch_bt<T, EPI, 64, 2>(a, s);
+        return launch_bt<T, EPI, 64, 4>(a, s);
     }
     return launch_bt<T, EPI, 128, 2>(a, s);
 }
