@@ -179,3 +179,66 @@ def test_duo_pipeline_runs_from_checkpoints(cuda_device, tmp_path):
                                       train_explainer=_train_cfg()), tmp_path, loader)
     train_duo_explainer(env2, dev)
     assert any("skip" in ln for ln in env2.lines)
+
+
+def test_train_all_stage_machine_and_classifier_training(cuda_device, tmp_path):
+    """train_all(env, device) (scripts/train_all.py:16): from a classifier {0} checkpoint through surrogate and explainer training to
+    a coherent final {0}; resumable (a second call finds stage 7); stage 0 without base parameters says what it needs.  And
+    train_classifier(env, device, set_model_mode) (scripts/train_classifier.py:15) as scripts/pretrain_classifier.py drives it:
+    only the unfrozen head moves."""
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import resources as rs
+    from autognothi_amd.scripts.train_all import detect_stage, train_all
+    from autognothi_amd.scripts.train_classifier import train_classifier
+    from autognothi_amd.utils import synth
+    from autognothi_amd.utils.nnmodel import freeze_model_parameters
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    recipe, dev = c["recipe"], cuda_device
+    prm = dict(c["meta"]["params"], num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg = recipe.t_config(**prm)
+    n = 6
+    imgs = torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=9))
+    loader = _Loader([imgs[i] for i in range(n)], [i % prm["num_labels"] for i in range(n)])
+    config = types.SimpleNamespace(
+        seed=3407, net=types.SimpleNamespace(kind="vanilla_vit", params=prm), dataset=None,
+        train_classifier=_train_cfg(epochs=0), train_surrogate=_train_cfg(epochs=1),
+        train_explainer=_train_cfg(epochs=1, n_mask_samples=4, lambda_efficiency=0.0, lambda_norm=0.0))
+    env = _Env(config, tmp_path, loader)
+    assert detect_stage(env) == 0
+    with pytest.raises(NotImplementedError, match="base_params"):
+        train_all(env, dev)
+    cls = recipe.t_classifier(cfg)
+    synth.load_synth_weights(cls, seed=3)
+    rs.save_epoch_ckpt(tmp_path, "classifier", "_:%1==0", 0, 0, cls)
+    assert detect_stage(env) == 2                      # train_classifier.epochs == 0: the conversion is the trained classifier
+    train_all(env, dev)
+    assert detect_stage(env) == 7
+    assert rs.get_epoch_ckpts(tmp_path, "surrogate", 3) == [0, 1] and rs.get_epoch_ckpts(tmp_path, "explainer", 3) == [0, 1]
+    assert any("verified final model is coherent" in ln for ln in env.lines)
+    # the surrogate {0} is the classifier's parameters under the surrogate's keys (conv_classifier_surrogate)
+    s0 = torch.load(rs.ckpt_path(tmp_path, "surrogate", 0), weights_only=False)
+    assert all(torch.equal(s0[k], v) for k, v in cls.state_dict().items())
+    n_lines = len(env.lines)
+    train_all(env, dev)                                # nothing left to do
+    assert env.lines[n_lines:] == ["[[[ current stage: 7 / 7 ]]]", "[[[ all stages ok ]]]"]
+
+    # ---- classifier training with the head unfrozen (pretrain_classifier.py:27-48 passes such a set_model_mode) ----
+    path2 = tmp_path / "cls"
+    path2.mkdir()
+    rs.save_epoch_ckpt(path2, "classifier", "_:%1==0", 2, 0, cls)
+    config2 = types.SimpleNamespace(seed=3407, net=config.net, dataset=None, train_classifier=_train_cfg(epochs=2, lr=1e-2))
+    env2 = _Env(config2, path2, loader)
+    with pytest.raises(RuntimeError, match="requires grad"):
+        train_classifier(env2, dev)                    # vanilla classifiers freeze themselves in train()
+
+    def unfreeze_head(net, _train):
+        freeze_model_parameters(net, "classifier", requires_grad=True)
+    train_classifier(env2, dev, set_model_mode=unfreeze_head)
+    assert [e["epoch"] for e in env2.entries] == [1, 2]
+    assert all(np.isfinite(e[k]) for e in env2.entries for k in ("train_cls_loss", "train_cls_acc", "test_cls_loss", "test_cls_acc"))
+    assert env2.entries[1]["train_cls_loss"] < env2.entries[0]["train_cls_loss"]
+    after = torch.load(rs.ckpt_path(path2, "classifier", 2), weights_only=False)
+    before = cls.state_dict()
+    moved = {k for k in before if not torch.equal(before[k], after[k])}
+    assert moved == {"classifier.weight", "classifier.bias"}, moved
