@@ -223,6 +223,15 @@ def test_train_all_stage_machine_and_classifier_training(cuda_device, tmp_path):
     train_all(env, dev)                                # nothing left to do
     assert env.lines[n_lines:] == ["[[[ current stage: 7 / 7 ]]]", "[[[ all stages ok ]]]"]
 
+    # ---- measure_train_resources(env, device, d_loader) (scripts/measure_train_resources.py:62): the reference's two batch bodies
+    # on the autograd bridge, per-sample seconds and MB
+    from autognothi_amd.scripts.measure_train_resources import measure_train_resources
+    config.eval_train_resources = types.SimpleNamespace(batch_size=2, max_samples=4)
+    rep = measure_train_resources(env, dev, loader)
+    assert len(rep.srg_tm.all) == 2 and len(rep.exp_tm.all) == 2                       # 2 batches of 2 reach max_samples = 4
+    assert all(t > 0 for t in rep.srg_tm.all + rep.exp_tm.all) and rep.init_mem > 0
+    assert min(rep.exp_mem.all) > min(rep.srg_mem.all) > 0                             # the explainer step holds more activations
+
     # ---- classifier training with the head unfrozen (pretrain_classifier.py:27-48 passes such a set_model_mode) ----
     path2 = tmp_path / "cls"
     path2.mkdir()
