@@ -330,7 +330,8 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     AG_REQUIRE(!d_ln_stats || d_ln_colsum, "ag_gemm: ln_stats given without ln_colsum");
     // the LTT ladder's map (a 768-wide stream into a 96-wide one, + GELU + additive residual): HBM-bound, weights stay in LDS
     static const bool map_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
-    if (dtype == AG_BF16 && !map_off && rows_per_seq <= 1 && resid_share <= 1 &&
+    // (resid_share <= 1: the residual row of output row m is row m whatever rows_per_seq says)
+    if (dtype == AG_BF16 && !map_off && resid_share <= 1 &&
         ag_side_map_eligible(M, N, K, lda, ldc, ldr, epilogue, epilogue == AG_EPI_BIAS_GELU_ADD))
         return ag_side_map(d_A, lda, d_W, d_bias, epilogue == AG_EPI_BIAS_GELU_ADD ? d_R : nullptr, ldr, d_C, ldc, M, N, K, 1, s);
     if (big)
