@@ -373,9 +373,27 @@ extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const voi
     static const bool side_off = getenv("AG_SIDE_MLP") && atoi(getenv("AG_SIDE_MLP")) == 0;
     const bool side_mlp = !side_off && ag_side_mlp_supported(H, I, dt);
     const bool side_lin = !side_off && ag_side_linear_supported(H, 3 * H, 0, dt) && ag_side_linear_supported(H, H, 1, dt);
+    // wide layers (the LTT backbone, one layer per call): the attention-output LayerNorm is never written — out-proj emits the
+    // statistics of the pre-LN rows, fc1 folds LN1 into its epilogue, fc2 recomputes LN1(h1) as its residual (ag_gemm_resid_ln);
+    // the layer's OUTPUT LayerNorm stays a kernel: the caller's taps and the next call read its result
+    static const bool fold_off = getenv("AG_BERT_LN_FOLD") && atoi(getenv("AG_BERT_LN_FOLD")) == 0;
+    const bool fold_ok = !fold_off && !side_lin && dt == AG_BF16 && ag_gemm_supports_ln_fold(N, I, H, H, I, 0, AG_EPI_BIAS_GELU, dt) &&
+                         ag_gemm_supports_ln_fold(N, H, H, H, H, H, AG_EPI_BIAS_RESID, dt) && ag_gemm_resid_ln_supported(N, H, I, I, H, H);
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         AG_REQUIRE(w.ln2_g, "ag_bert_layers_forward_packed: BERT output.LayerNorm missing in layer %d", l);
+        if (fold_ok && w.ln1_g && w.w_fc1_ln) {
+            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+            TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
+            TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, stream));
+            TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, ws.st1, w.s_fc1_ln, d->ln_eps,
+                        nullptr, stream));
+            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, ws.ha, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, stream));
+            char* dst_f = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
+            TRY(ag_layernorm(ws.ha, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst_f, nullptr, dt, stream));
+            x = dst_f;
+            continue;
+        }
         const char* a = ws.hx;
         if (side_lin) {   // narrow layers (LTT ladder): QKV, and out-proj + residual + LayerNorm, as one kernel each
             TRY(ag_side_linear(x, H, N, H, 3 * H, w.w_qkv, w.b_qkv, nullptr, nullptr, nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, stream));

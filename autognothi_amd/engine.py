@@ -191,8 +191,8 @@ class PackedEncoder:
                 keep += [w, b]
                 setattr(lw, cw, w.data_ptr())
                 setattr(lw, cb, b.data_ptr())
-            # (BERT: only the token-pruned forward reads the folded forms; they are packed when it can run: >= 3 layers)
-            if dtype == L.AG_BF16 and FOLD_LAYERNORM and (self.kind == L.AG_MASK_VIT_MUL or (PRUNE_BERT_TOKENS and len(self.layers) >= 3)):
+            # (BERT: only the token-pruned forwards — ag_bert_encoder_forward_pruned, ag_bert_layers_forward_packed — read the folded forms)
+            if dtype == L.AG_BF16 and FOLD_LAYERNORM and (self.kind == L.AG_MASK_VIT_MUL or PRUNE_BERT_TOKENS):
                 for name, cw, cb, cs in (("qkv_ln", "w_qkv_ln", "b_qkv_ln", "s_qkv_ln"), ("fc1_ln", "w_fc1_ln", "b_fc1_ln", "s_fc1_ln")):
                     if name in self.lin[i]:
                         w, b, s_ = self.lin[i][name].get(dtype)
