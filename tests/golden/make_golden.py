@@ -540,7 +540,34 @@ def gen_state_keys():
     print("wrote state_keys.json")
 
 
+def gen_hparams():
+    """experiment configs in the reference's on-disk format (data files of experiments/, validated here by the reference's own
+    pydantic ExpConfig) + what its get_recipe makes of them: the fixtures of tests/test_host_env.py"""
+    import shutil
+    _stub_modules()
+    from reference.scripts.resources import get_recipe
+    from reference.scripts.types import ExpConfig
+    os.makedirs(os.path.join(HERE, "hparams"), exist_ok=True)
+    meta = {}
+    for exp in ("vit_base_imagenette_vanilla", "bert_base_tayp_ltt", "bert_base_tayp_duo_vanilla"):
+        src = f"/root/reference/experiments/{exp}/.hparams.json"
+        shutil.copy(src, os.path.join(HERE, "hparams", f"{exp}.hparams.json"))
+        with open(src) as f:
+            cfg = ExpConfig.model_validate(json.load(f))
+        recipe, m_cfg = get_recipe(cfg)
+        meta[exp] = {"kind": cfg.net.kind, "n_players": int(recipe.n_players(m_cfg)), "config_class": type(m_cfg).__name__,
+                     "train_explainer": {"epochs": cfg.train_explainer.epochs, "n_mask_samples": cfg.train_explainer.n_mask_samples,
+                                         "batch_size": cfg.train_explainer.batch_size},
+                     "progressive": {"surrogate": cfg.train_surrogate.EXPERIMENTAL_progressive_training,
+                                     "explainer": cfg.train_explainer.EXPERIMENTAL_progressive_training}}
+    with open(os.path.join(HERE, "hparams", "expected.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "hparams":
+        gen_hparams()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "state_keys":
         gen_state_keys()
         sys.exit(0)

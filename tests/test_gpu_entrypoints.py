@@ -251,3 +251,42 @@ def test_train_all_stage_machine_and_classifier_training(cuda_device, tmp_path):
     before = cls.state_dict()
     moved = {k for k in before if not torch.equal(before[k], after[k])}
     assert moved == {"classifier.weight", "classifier.bias"}, moved
+
+
+def test_model_directory_in_the_reference_format_runs_train_all(cuda_device, tmp_path):
+    """a model directory as the reference lays it out — .hparams.json (one of its own experiment configs, shrunk to ViT-tiny /
+    2 layers / 1 epoch), classifier-epoch-0.ckpt — driven through scripts.env.ExpEnv + train_all: checkpoints, .log.txt with the
+    METRICS lines, the config file rewritten by flush_cfg, stage 7 at the end."""
+    import json
+    import os
+    from autognothi_amd import engine
+    from autognothi_amd.scripts import resources as rs
+    from autognothi_amd.scripts.env import ExpEnv
+    from autognothi_amd.scripts.train_all import detect_stage, train_all
+    from autognothi_amd.utils import synth
+    engine.set_precision("fp32")
+    c = build_case("vit_tiny_c1")
+    recipe, dev = c["recipe"], cuda_device
+    prm = dict(c["meta"]["params"], num_hidden_layers=2)
+    hp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hparams", "vit_base_imagenette_vanilla.hparams.json")))
+    hp["net"]["params"] = prm
+    for sec, ep in (("train_classifier", 0), ("train_surrogate", 1), ("train_explainer", 1)):
+        hp[sec].update(epochs=ep, batch_size=2, lr=1e-3)
+    hp["train_explainer"]["n_mask_samples"] = 4
+    with open(tmp_path / ".hparams.json", "w") as f:
+        json.dump(hp, f, indent=2)
+    cls = recipe.t_classifier(recipe.t_config(**prm))
+    synth.load_synth_weights(cls, seed=3)
+    rs.save_epoch_ckpt(tmp_path, "classifier", "_:%1==0", 0, 0, cls)
+    n = 4
+    imgs = torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=9))
+    loader = _Loader([imgs[i] for i in range(n)], [i % prm["num_labels"] for i in range(n)])
+    with ExpEnv(tmp_path, d_loader=loader, echo=False) as env:
+        train_all(env, dev)
+        assert detect_stage(env) == 7
+    log = open(tmp_path / ".log.txt").read()
+    assert "[[[ all stages ok ]]]" in log and "verified final model is coherent" in log
+    assert log.count("METRICS: ") == 2 and "'train_kld_loss'" in log and "'train_reg_loss'" in log
+    assert sorted(p.name for p in tmp_path.glob("*.ckpt")) == ["classifier-epoch-0.ckpt", "explainer-epoch-0.ckpt", "explainer-epoch-1.ckpt",
+                                                              "final-epoch-0.ckpt", "surrogate-epoch-0.ckpt", "surrogate-epoch-1.ckpt"]
+    assert json.load(open(tmp_path / ".hparams.json"))["net"]["params"] == prm          # flush_cfg kept the file intact
