@@ -85,12 +85,35 @@ def stat_perf(model: nn.Module, tm: List[float], flops: float) -> ModelPerforman
         params_trainable=sum(p.numel() for p in model.parameters() if p.requires_grad) / 1e6)
 
 
-def measure_performance(env: Any, device: torch.device, m_recipe: ModelRecipe, n_players: int,
-                        make_items: Callable[[], Iterable[Tuple[Any, Any]]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
-                        null_xs: Tensor, loops: int, m_classifier=None, m_surrogate=None, m_explainer=None, m_final=None
-                        ) -> MeasurePerformanceReport:
-    """reference measure_performance (:38-103) on already-loaded models (checkpoint loading is outside this build's
-    scope); any of the four may be None (its entry is None, as for a recipe whose allow_performance_* flag is off)."""
+def measure_performance(env: Any, device: torch.device, d_loader: Any) -> MeasurePerformanceReport:
+    """reference measure_performance(env, device, d_loader) (:36-103): newest classifier / surrogate / explainer / final checkpoints
+    of ``env.model_path``, one sample per inference (batch_size 1, as there), ``config.eval_performance.loops`` passes over the test
+    split.  ``env`` duck-typed as in scripts/train_explainer.train_explainer; ``d_loader`` None falls back to ``env.d_loader``."""
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env
+    env.log("loading models...")
+    config = env.config
+    m_recipe, m_config = get_recipe(config)
+    if d_loader is None:
+        env.log("loading dataset...")
+        d_loader = load_cfg_dataset(env, getattr(config.eval_performance, "dataset", None) or getattr(config, "dataset", None))
+    m_misc = m_recipe.load_misc(env.model_path, m_config)
+    meas = m_recipe.measurements
+    models = {}
+    for sec, need in (("classifier", meas.allow_performance_cls), ("surrogate", meas.allow_performance_srg_exp),
+                      ("explainer", meas.allow_performance_srg_exp), ("final", meas.allow_performance_fin)):
+        models[sec] = load_epoch_model_env(env, m_recipe, sec, device=device)[1] if need else None
+    return measure_performance_loaded(env, device, m_recipe, m_recipe.n_players(m_config), lambda: d_loader.test(1),
+                                      m_recipe.gen_input(m_config, m_misc, device), m_recipe.gen_null(m_config, m_misc, device),
+                                      config.eval_performance.loops, m_classifier=models["classifier"], m_surrogate=models["surrogate"],
+                                      m_explainer=models["explainer"], m_final=models["final"])
+
+
+def measure_performance_loaded(env: Any, device: torch.device, m_recipe: ModelRecipe, n_players: int,
+                               make_items: Callable[[], Iterable[Tuple[Any, Any]]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
+                               null_xs: Tensor, loops: int, m_classifier=None, m_surrogate=None, m_explainer=None, m_final=None
+                               ) -> MeasurePerformanceReport:
+    """reference measure_performance (:38-103) on already-loaded models; any of the four may be None (its entry is None, as for a
+    recipe whose allow_performance_* flag is off)."""
     env = env or Log()
     meas = m_recipe.measurements
     rep = {"classifier": None, "surrogate": None, "explainer": None, "final": None}

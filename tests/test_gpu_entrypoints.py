@@ -290,3 +290,19 @@ def test_model_directory_in_the_reference_format_runs_train_all(cuda_device, tmp
     assert sorted(p.name for p in tmp_path.glob("*.ckpt")) == ["classifier-epoch-0.ckpt", "explainer-epoch-0.ckpt", "explainer-epoch-1.ckpt",
                                                               "final-epoch-0.ckpt", "surrogate-epoch-0.ckpt", "surrogate-epoch-1.ckpt"]
     assert json.load(open(tmp_path / ".hparams.json"))["net"]["params"] == prm          # flush_cfg kept the file intact
+
+    # ---- measure_all (scripts/measure_all.py:24): every report once, kept under .reports/ in the reference's file layout ----
+    from autognothi_amd.scripts.measure_all import measure_all
+    with ExpEnv(tmp_path, d_loader=loader, echo=False) as env:
+        done = measure_all(env, dev, True, True, True, True, True, False, False)
+        assert sorted(done) == ["accuracy", "cls_acc", "faithfulness", "performance", "train_resources"]
+        again = measure_all(env, dev, True, True, True, True, True, False, False)      # loaded from the files, not re-measured
+        assert again == done
+    reports = sorted(p.name for p in (tmp_path / ".reports").glob("*.json"))
+    assert reports == ["accuracy.json", "cls_acc.json", "faithfulness.json", "performance.json", "train_resources.json"]
+    acc = json.load(open(tmp_path / ".reports" / "accuracy.json"))
+    assert acc["masked_players"][0] == 0 and acc["masked_players"][-1] == c["P"] and len(acc["accuracy"]) == hp["eval_accuracy"]["resolution"]
+    perf = json.load(open(tmp_path / ".reports" / "performance.json"))
+    assert all(perf[k]["params_all"] > 0 and perf[k]["time_avg"] > 0 for k in ("classifier", "surrogate", "explainer", "final"))
+    fth = json.load(open(tmp_path / ".reports" / "faithfulness.json"))
+    assert len(fth["insertion"]["avg"]) == hp["eval_faithfulness"]["resolution"] and all(isinstance(k, str) for k in fth["insertion"]["avg"])

@@ -148,7 +148,7 @@ def test_performance_report(cuda_device):
     xs = torch.from_numpy(c["xs"][:1]).to(dev)
     null = torch.from_numpy(c["null"]).to(dev)
     gen = lambda a, b: (xs, torch.zeros(1, dtype=torch.long, device=dev))  # noqa: E731
-    rep = mp.measure_performance(None, dev, recipe, c["P"], lambda: [(None, None)] * 2, gen, null, loops=2,
+    rep = mp.measure_performance_loaded(None, dev, recipe, c["P"], lambda: [(None, None)] * 2, gen, null, loops=2,
                                  m_classifier=cls, m_surrogate=srg, m_explainer=exp)
     assert rep.final is None and len(rep.classifier.time) == 4 and rep.classifier.time_avg > 0
     n_params = sum(p.numel() for p in cls.parameters()) / 1e6
