@@ -304,5 +304,19 @@ def test_model_directory_in_the_reference_format_runs_train_all(cuda_device, tmp
     assert acc["masked_players"][0] == 0 and acc["masked_players"][-1] == c["P"] and len(acc["accuracy"]) == hp["eval_accuracy"]["resolution"]
     perf = json.load(open(tmp_path / ".reports" / "performance.json"))
     assert all(perf[k]["params_all"] > 0 and perf[k]["time_avg"] > 0 for k in ("classifier", "surrogate", "explainer", "final"))
+    # estimate_train_time (scripts/estimate_train_time.py:13) from the cached train_resources report; pretrain_classifier
+    # (scripts/pretrain_classifier.py:17): whole classifier unfrozen, exported as model.json + model.ckpt
+    from autognothi_amd.scripts.pretrain_classifier import estimate_train_time, fmt_tm, pretrain_classifier
+    with ExpEnv(tmp_path, d_loader=loader, echo=False) as env:
+        t_s, t_e = estimate_train_time(env, dev)
+        tr = json.load(open(tmp_path / ".reports" / "train_resources.json"))
+        assert abs(t_s - (tr["init_tm"] + tr["srg_tm"]["avg"] * hp["dataset"]["train_size"])) < 1e-9 and t_e > 0
+        assert fmt_tm(59.0) == "     00m" and fmt_tm(3 * 3600 + 61) == "  3h 01m"
+        env.config.train_classifier.epochs = 1
+        dest = pretrain_classifier(env, dev, dest_root=tmp_path / "params")
+    assert json.load(open(dest / "model.json")) == prm
+    exported = torch.load(dest / "model.ckpt", weights_only=False)
+    assert list(exported) == list(cls.state_dict()) and any(not torch.equal(exported[k], v) for k, v in cls.state_dict().items())
+    assert (tmp_path / "classifier-epoch-1.ckpt").exists()
     fth = json.load(open(tmp_path / ".reports" / "faithfulness.json"))
     assert len(fth["insertion"]["avg"]) == hp["eval_faithfulness"]["resolution"] and all(isinstance(k, str) for k in fth["insertion"]["avg"])
