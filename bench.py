@@ -444,6 +444,34 @@ def main():
         secondary["token_pruning_off"] = {"value": round(v_np, 1), "unit": "masked-forwards/s", "exec_tflops": round(v_np / world * f_np / 1e12, 1),
                                           "exec_frac_of_peak": round(v_np / world * f_np / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
+    # ---- calibration, not a product path: the vendor library (torch.matmul -> hipBLASLt) on the same four encoder GEMM shapes,
+    # bf16 in / bf16 out, NO bias / GELU / residual / LayerNorm-fold epilogue, against this library's kernels WITH theirs
+    if not args.no_secondary and args.precision == "bf16" and rank == 0:
+        hidden, inter = params["hidden_size"], params["intermediate_size"]
+        m_rows = R * T
+        cal = {}
+        for name, n_, k_, label in (("qkv", 3 * hidden, hidden, "gemm<bias>"), ("fc1", inter, hidden, "gemm<bias+gelu>"),
+                                    ("fc2", hidden, inter, "gemm<bias+residual>")):
+            a_ = torch.randn((m_rows, k_), device=dev, dtype=torch.bfloat16)
+            w_ = torch.randn((n_, k_), device=dev, dtype=torch.bfloat16) * (k_ ** -0.5)
+            o_ = torch.empty((m_rows, n_), device=dev, dtype=torch.bfloat16)
+            for _ in range(3):
+                torch.matmul(a_, w_.t(), out=o_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                torch.matmul(a_, w_.t(), out=o_)
+            e1.record()
+            torch.cuda.synchronize()
+            us_ = e0.elapsed_time(e1) / 10 * 1e3
+            cal[name] = {"M": m_rows, "N": n_, "K": k_, "vendor_us": round(us_, 1), "vendor_tflops": round(2.0 * m_rows * n_ * k_ / us_ / 1e6, 1),
+                         "this_library_class": label}
+            del a_, w_, o_
+        secondary["vendor_gemm_calibration"] = {"what": "torch.matmul (hipBLASLt), same shapes, plain bf16 GEMM without any epilogue; compare with "
+                                                        "roofline.kernels[<class>].tflops (which include bias / GELU / residual / LayerNorm folding / "
+                                                        "row statistics); fc2's class average also contains the K = hidden out-projection",
+                                                "shapes": cal}
+
     # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +
     # surrogate + explainer forwards on all-ones masks -> phi [B, C, P]); untimed by the contract's K steps.
     attrs_per_s = None
