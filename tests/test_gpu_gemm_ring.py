@@ -307,3 +307,54 @@ def test_ring_post_ln_chain_without_layernorm_passes(cuda_device):
     d1, di, d2, dq = chain(cnt)
     for full, part in ((h1, d1), (inter, di), (h2, d2), (q, dq)):
         assert torch.equal(full[:n_live], part[:n_live])
+
+
+def _random_shapes(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        m = int(g.integers(1024, 2900))
+        nn = int(g.integers(32, 390)) * 8           # 256 .. 3112, multiples of 8 (ragged last column tile most of the time)
+        k = int(g.integers(4, 129)) * 32            # 128 .. 4096
+        out.append((m, nn, k))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", _random_shapes(10, 20261003))
+def test_ring_random_shapes_all_variants(cuda_device, m, n, k):
+    """seeded random (M, N, K): every ring-kernel variant that the encoder chains — plain bias, bias + GELU, residual with
+    statistics, folded consumer fed by those statistics, residual-LayerNorm producer — against float64, plus the statistics."""
+    from autognothi_amd import _lib as L, ops
+    g, a, w, b, ref = _case(m, n, k, m * 131 + n * 7 + k)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
+    np.testing.assert_allclose(out, ref, **TOL)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16).float().cpu().numpy()
+    np.testing.assert_allclose(out, otr.gelu(ref.astype(np.float32)), rtol=2e-2, atol=3e-2)
+    # producer (residual + statistics), then a consumer that folds LN(out) over K' = n into a small projection
+    r = _r((g.standard_normal((m, n)) * 1.3).astype(np.float32))
+    st = ops.new_row_stats(m, n, dev)
+    h = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev), stats_out=st)
+    hn = h.float().cpu().numpy()
+    np.testing.assert_allclose(hn, ref + r, **TOL)
+    got = ops.reduce_row_stats(st, m, n).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], hn.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
+    np.testing.assert_allclose(got[:, 1], (hn.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    gamma = (1 + 0.1 * g.standard_normal(n)).astype(np.float32)
+    beta = (0.1 * g.standard_normal(n)).astype(np.float32)
+    ln = otr.layer_norm(hn, {"ln.weight": gamma, "ln.bias": beta}, "ln", 1e-12).astype(np.float64)
+    if n % 32 == 0:            # (K' of the consumer must be a multiple of 32)
+        n2 = 264
+        w2 = (g.standard_normal((n2, n)) / np.sqrt(n)).astype(np.float32)
+        b2 = g.standard_normal(n2).astype(np.float32)
+        wf = torch.from_numpy(w2 * gamma[None, :]).to(dev).to(torch.bfloat16)
+        bf = torch.from_numpy((b2 + w2 @ beta).astype(np.float32)).to(dev)
+        q = ops.gemm(h, wf, bf, L.AG_EPI_BIAS, BF16, ln_stats=st, ln_colsum=wf.float().sum(1).contiguous(), ln_eps=1e-12)
+        np.testing.assert_allclose(q.float().cpu().numpy(), ln @ w2.astype(np.float64).T + b2, rtol=2e-2, atol=4e-2)
+    # residual-LayerNorm producer on the same pre-LN rows: A2 [m, k] W2 [n, k]
+    h2, st2 = ops.gemm_resid_ln(A, W, B, h, st, torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev), 1e-12)
+    h2n = h2.float().cpu().numpy()
+    np.testing.assert_allclose(h2n, ref + ln, **TOL)
+    got2 = ops.reduce_row_stats(st2, m, n).cpu().numpy()
+    np.testing.assert_allclose(got2[:, 0], h2n.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
