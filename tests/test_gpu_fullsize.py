@@ -153,3 +153,45 @@ def test_bf16_forward_is_bit_reproducible(cuda_device, workload):
     first = _probs(recipe, m, xs, masks)
     for _ in range(3):
         np.testing.assert_array_equal(_probs(recipe, m, xs, masks), first)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_bert_full_sequence_length_512(cuda_device, precision):
+    """the reference's BERT experiments run at max_position_embeddings = 512 (experiments/bert_base_tayp_*/.hparams.json; BASELINE
+    config 3 shortens it to 128): the same path at T = 512, P = 511 — packed (token-pruned, LayerNorm-free in bf16) against
+    un-pruned, masks from the device sampler at P = 511, an all-visible mask against the single unmasked forward."""
+    import bench
+    from autognothi_amd import engine, ops
+    from autognothi_amd.recipes import get_recipe
+    from autognothi_amd.utils import synth
+    kind, params, _ = bench.WORKLOADS["bert_base"]
+    params = dict(params, max_position_embeddings=512, num_hidden_layers=4)
+    recipe = get_recipe(kind)
+    cfg = recipe.t_config(**params)
+    engine.set_precision(precision)
+    try:
+        m = recipe.t_surrogate(cfg)
+        synth.load_synth_weights(m, seed=0)
+        m = m.to(cuda_device).eval()
+        b, k, p = 3, 8, recipe.n_players(cfg)
+        assert p == 511
+        xs = torch.from_numpy(synth.synth_token_ids(b, 512, params["vocab_size"], seed=4)).to(cuda_device)
+        masks, _ = ops.mask_shapley_new(ops.DeviceMT19937(cuda_device, 77), b * k, p, want_i64=True, want_bits=False)
+        keep = engine.PRUNE_BERT_TOKENS
+        try:
+            engine.PRUNE_BERT_TOKENS = True
+            a = _probs(recipe, m, xs, masks)
+            engine.PRUNE_BERT_TOKENS = False
+            u = _probs(recipe, m, xs, masks)
+        finally:
+            engine.PRUNE_BERT_TOKENS = keep
+        tol = 2e-5 if precision == "fp32" else TOL
+        np.testing.assert_allclose(a, u, rtol=0, atol=tol)
+        np.testing.assert_allclose(a.sum(-1), 1.0, atol=1e-3)
+        assert float(np.abs(a.reshape(b, k, -1) - a.reshape(b, k, -1)[:, :1]).max()) > 1e-3      # masks matter
+        ones = torch.ones((b * k, p), dtype=torch.int64, device=cuda_device)
+        many = _probs(recipe, m, xs, ones).reshape(b, k, -1)
+        single = _probs(recipe, m, xs, ones[:b])
+        np.testing.assert_allclose(many, np.repeat(single[:, None], k, axis=1), rtol=0, atol=tol)
+    finally:
+        engine.set_precision("bf16")
