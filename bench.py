@@ -69,11 +69,14 @@ WORKLOADS["ltt_bert_base"] = ("ltt_bert", dict({k: v for k, v in WORKLOADS["bert
                                                 explainer_normalize=True, **_LTT), 32)
 # BASELINE config 5's recipes (same backbones; what differs is the training step: duo = one backbone for both objectives
 # + a cross-entropy term, froyo = frozen shared backbone, explainer head only)
+# the reference's BERT experiments as shipped (max_position_embeddings 512: experiments/bert_base_tayp_vanilla/.hparams.json; BASELINE
+# config 3 shortens the sequences to 128)
+WORKLOADS["bert_base_512"] = ("vanilla_bert", dict(WORKLOADS["bert_base"][1], max_position_embeddings=512), 32)
 WORKLOADS["duo_bert_base"] = ("duo_vanilla_bert", WORKLOADS["bert_base"][1], 32)
 WORKLOADS["froyo_vit_base"] = ("froyo_vit", WORKLOADS["vit_base"][1], 32)
 WORKLOAD_LABEL = {"vit_base": "vit_base_imagenette_vanilla", "vit_large": "vit_large_imagenette_vanilla",
                   "vit_tiny": "vit_tiny_imagenette_vanilla", "bert_base": "bert_base_tayp_vanilla seq_len=128",
-                  "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128",
+                  "bert_base_512": "bert_base_tayp_vanilla seq_len=512", "ltt_vit_base": "vit_base_imagenette + LTT ladder (h=96)", "ltt_bert_base": "bert_base_tayp_ltt seq_len=128",
                   "duo_bert_base": "bert_base_tayp_duo_vanilla seq_len=128", "froyo_vit_base": "vit_base_imagenette froyo"}
 
 EPI_NAMES = {0: "gemm<bias>", 1: "gemm<bias+gelu>", 2: "gemm<bias+residual>", 3: "gemm<bias,f32out>", 4: "gemm<bias+tanh>",
