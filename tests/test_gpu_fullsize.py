@@ -137,7 +137,8 @@ def test_chained_per_layer_forward_equals_one_call(cuda_device):
         chain[2] = i + 1 < len(singles)
         used.append(chain[1])
         h = enc.forward(h, rows, K if i == 0 else 1, bits, False, dtype, chain=chain)
-    assert used[0] is False and all(used[1:]), used      # every layer after the first consumed its predecessor's statistics
+    if engine.FOLD_LAYERNORM:             # (AG_LN_FOLD=0 runs the LayerNorm kernels instead: nothing to hand on)
+        assert used[0] is False and all(used[1:]), used      # every layer after the first consumed its predecessor's statistics
     got = h.float().cpu().numpy()
     np.testing.assert_array_equal(got, ref)       # same kernels, same statistics partials, same order: bit for bit
 
