@@ -46,18 +46,19 @@ SIGNATURES = {
     "ag_mask_shapley_new": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "ag_mask_shapley_new_rows": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "ag_mask_purely_uniform": (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    "ag_mask_purely_uniform_rows": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "ag_pack_mask": (i32, [vp, i32, i32, vp, vp]),
     "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
-    "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp]),
-    "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp]),
+    "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp]),
+    "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
     "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
-    "ag_gemm_resid_ln": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i32, vp, vp]),
+    "ag_gemm_resid_ln": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp]),
     "ag_gemm_resid_ln_supported": (i32, [i32, i32, i32, i64, i64, i64]),
     "ag_side_mlp_supported": (i32, [i32, i32, i32]),
-    "ag_side_mlp": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp]),
+    "ag_side_mlp": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp]),
     "ag_side_linear_supported": (i32, [i32, i32, i32, i32]),
-    "ag_side_linear": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, f32, vp, i64, vp]),
+    "ag_side_linear": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, f32, vp, i64, vp, vp]),
     "ag_row_stats_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
     "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
@@ -97,10 +98,10 @@ SIGNATURES = {
     "ag_encoder_forward": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp]),
     "ag_encoder_forward_chained": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, i32, vp, sz, vp, i32, i32, C.POINTER(i32), vp]),
     "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, vp, vp]),
-    "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp]),
-    "ag_dynamic_rows": (i32, [vp]),
+    "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp, vp]),
+    "ag_reload_knobs": (i32, []),
     "ag_seq_compact_plan": (i32, [vp, i32, i32, vp, vp, vp]),
-    "ag_gather_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
+    "ag_gather_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp]),
     "ag_masked_attention_varlen": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
 }
 

@@ -19,6 +19,12 @@ int ag_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" int ag_abi_version(void) { return AG_ABI_VERSION; }
+
+int g_ag_knob_epoch = 1;
+extern "C" int ag_reload_knobs(void) {
+    ++g_ag_knob_epoch;
+    return AG_OK;
+}
 extern "C" const char* ag_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int ag_device_info(int device, int* cu_count, char* arch, size_t arch_len) {
@@ -49,17 +55,10 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-thread_local const int* g_ag_dyn_rows = nullptr;
-
-extern "C" int ag_dynamic_rows(const int* d_rows) {
-    g_ag_dyn_rows = d_rows;
-    return AG_OK;
-}
-
-AgProfScope::AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, double rows_upper) : idx(-1), stream(s) {
+AgProfScope::AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, const int* d_rows, double rows_upper) : idx(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{kernel_class, flops, bytes, take_event(), take_event(), rows_upper > 0.0 ? g_ag_dyn_rows : nullptr, rows_upper};
+    ProfRec r{kernel_class, flops, bytes, take_event(), take_event(), d_rows, rows_upper};
     (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
     idx = (int)g_recs.size() - 1;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/autognothi_hip.h"
@@ -125,6 +126,26 @@ __device__ __forceinline__ float quad_rows_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Experiment / test knobs: an environment variable read ONCE (and again after ag_reload_knobs()), never on the launch path.
+extern int g_ag_knob_epoch;   // capi.cpp
+struct AgKnob {
+    const char* name;
+    int epoch;
+    bool set;
+    double val;
+    const char* str;
+    explicit AgKnob(const char* n) : name(n), epoch(0), set(false), val(0.0), str(nullptr) {}
+    void sync() {
+        if (epoch == g_ag_knob_epoch) return;
+        str = getenv(name);
+        set = str != nullptr;
+        val = str ? atof(str) : 0.0;
+        epoch = g_ag_knob_epoch;
+    }
+    double get(double dflt) { sync(); return set ? val : dflt; }
+    bool is_set() { sync(); return set; }
+};
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t dtype_size(int dtype) { return dtype == AG_BF16 ? 2 : 4; }
 
@@ -132,15 +153,14 @@ static inline size_t dtype_size(int dtype) { return dtype == AG_BF16 ? 2 : 4; }
 struct AgProfScope {
     int idx;
     hipStream_t stream;
-    // rows_upper > 0: flops / bytes were computed for rows_upper rows while the launch runs under ag_dynamic_rows(): the
-    // totals are scaled by (actual rows / rows_upper) when collected
-    AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, double rows_upper = 0.0);
+    // d_rows != NULL: flops / bytes were computed for rows_upper rows while the launch runs on *d_rows of them (a device-side
+    // row count): the totals are scaled by (actual rows / rows_upper) when collected
+    AgProfScope(int kernel_class, double flops, double bytes, hipStream_t s, const int* d_rows = nullptr, double rows_upper = 0.0);
     ~AgProfScope();
 };
 
-// ag_dynamic_rows(): device pointer to the actual row count of the following launches of this host thread (NULL = the
-// host-side count is exact).  Read by the launchers of ag_gemm / ag_layernorm / ag_gather_rows and handed to their kernels.
-extern thread_local const int* g_ag_dyn_rows;
+// d_rows (ABI 2: an explicit argument of ag_gemm / ag_gemm_resid_ln / ag_layernorm / ag_gather_rows / ag_side_*): device
+// pointer to the actual row count of the launch (NULL = the host-side count is exact).
 __device__ __forceinline__ int ag_dyn_clamp(int rows, const int* dyn) {
     if (dyn) { const int d = *dyn; rows = d < rows ? d : rows; }
     return rows;
@@ -149,10 +169,10 @@ __device__ __forceinline__ int ag_dyn_clamp(int rows, const int* dyn) {
 // side_mlp.hip: wide -> narrow Linear (+ GELU, + additive residual) with the weights resident in LDS
 bool ag_side_map_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, bool has_resid);
 int ag_side_map(const void* d_x, int64_t ldx, const void* d_w, const float* d_b, const void* d_resid, int64_t ldr, void* d_out,
-                int64_t ldo, int M, int N, int K, int gelu, hipStream_t s);
+                int64_t ldo, int M, int N, int K, int gelu, const int* d_rows, hipStream_t s);
 
 // gemm_big.hip
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                 const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
-                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s);
+                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, const int* d_rows, hipStream_t s);

@@ -331,7 +331,8 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ---- token pruning (BERT additive mask): pack the visible tokens of every row ---------------------------------
-// counts[r] = popcount(mask row r) (CLS bit included); cu = exclusive scan (cu[R] = total); one workgroup.
+// counts[r] = popcount(mask row r) with the CLS bit forced on and bits at or beyond T ignored, so that the packed row count
+// cu[R] lies in [R, R*T] by construction (nothing downstream has to validate a device-side count); cu = exclusive scan; one workgroup.
 __global__ __launch_bounds__(1024) void seq_scan_kernel(const uint32_t* __restrict__ mask, int R, int Tw, int T, int* __restrict__ cu) {
     __shared__ int part[1024];
     const uint32_t last = (T & 31) ? ((1u << (T & 31)) - 1u) : 0xFFFFFFFFu;   // bits at or beyond T do not count
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(const uint32_t* __restri
     const int r0 = tid * per, r1 = min(R, r0 + per);
     int sum = 0;
     for (int r = r0; r < r1; ++r)
-        for (int w = 0; w < Tw; ++w) sum += __popc(mask[(long)r * Tw + w] & (w == Tw - 1 ? last : 0xFFFFFFFFu));
+        for (int w = 0; w < Tw; ++w) sum += __popc((mask[(long)r * Tw + w] | (w == 0 ? 1u : 0u)) & (w == Tw - 1 ? last : 0xFFFFFFFFu));
     part[tid] = sum;
     __syncthreads();
     for (int off = 1; off < nt; off <<= 1) {   // Hillis-Steele inclusive scan of the per-thread sums
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(const uint32_t* __restri
     int run = tid ? part[tid - 1] : 0;
     for (int r = r0; r < r1; ++r) {
         cu[r] = run;
-        for (int w = 0; w < Tw; ++w) run += __popc(mask[(long)r * Tw + w] & (w == Tw - 1 ? last : 0xFFFFFFFFu));
+        for (int w = 0; w < Tw; ++w) run += __popc((mask[(long)r * Tw + w] | (w == 0 ? 1u : 0u)) & (w == Tw - 1 ? last : 0xFFFFFFFFu));
     }
     if (tid == nt - 1) cu[R] = part[nt - 1];
 }
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(256) void seq_index_kernel(const uint32_t* __restri
     int base = cu[row];
     for (int w0 = 0; w0 < Tw; w0 += 2) {           // 64 tokens per step: lane = token
         const int t = w0 * 32 + lane;
-        const uint32_t word = (w0 + (lane >> 5)) < Tw ? mask[(long)row * Tw + w0 + (lane >> 5)] : 0u;
+        uint32_t word = (w0 + (lane >> 5)) < Tw ? mask[(long)row * Tw + w0 + (lane >> 5)] : 0u;
+        if (w0 + (lane >> 5) == 0) word |= 1u;      // CLS is always visible (as in the scan): cu[R] is in [R, R*T] whatever the caller packed
         const bool on = t < T && ((word >> (lane & 31)) & 1u);
         const unsigned long long ball = __ballot(on);
         if (on) tok_src[base + __popcll(ball & ((1ull << lane) - 1ull))] = row * T + t;
@@ -398,7 +400,7 @@ extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype
 }
 
 extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
-                            float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream) {
+                            float eps, void* d_y_store, float* d_y_f32, int dtype, const int* d_rows, void* stream) {
     if (rows == 0) return AG_OK;
     AG_REQUIRE(d_x && d_gamma && d_beta && (d_y_store || d_y_f32), "ag_layernorm: null pointer");
     AG_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_MAXV && ldx % 4 == 0, "ag_layernorm: H=%d unsupported (multiple of 4, <= %d)", H, 64 * 4 * LN_MAXV);
@@ -406,9 +408,9 @@ extern "C" int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows,
     const int blocks = ceil_div(rows, 4);
     hipStream_t s = (hipStream_t)stream;
     AG_REQUIRE(x_dtype == AG_F32 || x_dtype == AG_BF16, "ag_layernorm: bad x_dtype %d", x_dtype);
-    const int* dyn = g_ag_dyn_rows;
+    const int* dyn = d_rows;
     AgProfScope prof(AG_PROF_LAYERNORM, 0.0, (double)rows * H * ((double)dtype_size(x_dtype) + (d_y_store ? (double)dtype_size(dtype) : 0.0) + (d_y_f32 ? 4.0 : 0.0)), s,
-                     dyn ? (double)rows : 0.0);
+                     dyn, (double)rows);
     if (dtype != AG_BF16 && dtype != AG_F32) return ag_fail(AG_ERR_INVALID, "ag_layernorm: bad dtype %d", dtype);
     const bool narrow = H <= 128;                      // 8 lanes per row, 32 rows per block
     const int nblk = narrow ? ceil_div(rows, 32) : blocks;
@@ -502,7 +504,7 @@ extern "C" int ag_seq_compact_plan(const uint32_t* d_mask_bits, int R, int T, in
 }
 
 extern "C" int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_index, void* d_dst, int64_t ld_dst, int n, int H,
-                              int dtype, void* stream) {
+                              int dtype, const int* d_rows, void* stream) {
     AG_REQUIRE(d_src && d_index && d_dst && n >= 0 && H >= 1, "ag_gather_rows: bad arguments");
     AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_gather_rows: bad dtype %d", dtype);
     const size_t es = dtype_size(dtype);
@@ -511,7 +513,7 @@ extern "C" int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_in
     const long total = (long)n * ((H * es) >> 4);
     const int grid = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)d_src, (long)(ld_src * es), d_index,
-                       (char*)d_dst, (long)(ld_dst * es), n, (int)(H * es), g_ag_dyn_rows);
+                       (char*)d_dst, (long)(ld_dst * es), n, (int)(H * es), d_rows);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -92,6 +92,7 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
     int in_share = share;                  // how many rows share one h_in sequence
     bool st1_ready = chain_stats && stats_in_ready && share == 1;   // ws.st1 holds the row statistics of h_in (written by the previous fc2)
     hipStream_t hs = (hipStream_t)stream;
+    const int* const dyn = nullptr;        // every row count of this entry is exact on the host
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         const bool last_cls = cls_only_last && (l == d->n_layers - 1);
@@ -116,19 +117,19 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         if (fold1) {
             if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
             TRY(ag_gemm(h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
-                        ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, stream));
+                        ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, dyn, stream));
         } else if (side_qkv) {
             // narrow layer (LTT ladder): (LN1 +) QKV in one register-resident kernel
             TRY(ag_side_linear(h_in, H, Min, H, 3 * H, w.w_qkv, w.b_qkv, vit ? w.ln1_g : nullptr, vit ? w.ln1_b : nullptr,
-                               nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, stream));
+                               nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, dyn, stream));
         } else {
             const char* att_in = h_in;
             if (vit && w.ln1_g) {
-                TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+                TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
                 att_in = ws.xs;
             }
             TRY(ag_gemm(att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
-                        nullptr, nullptr, 0.f, nullptr, stream));
+                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
         }
         st1_ready = false;
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
@@ -140,28 +141,28 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         if (side_o) {
             const bool post = !vit && w.ln1_g;
             TRY(ag_side_linear(ws.ctx, H, Mo, H, H, w.w_o, w.b_o, nullptr, nullptr, h_in, H, post ? w.ln1_g : nullptr,
-                               post ? w.ln1_b : nullptr, d->ln_eps, post ? ws.ha : ws.hx, H, stream));
+                               post ? w.ln1_b : nullptr, d->ln_eps, post ? ws.ha : ws.hx, H, dyn, stream));
             ln1_done = post;
         } else {
         TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
-                    nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, stream));
+                    nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, dyn, stream));
         }
         if (vit) {
             if (side_mlp && !fold2) {
                 // narrow layer (LTT ladder): LN2 + fc1 + GELU + fc2 + residual in one register-resident kernel
-                TRY(ag_side_mlp(ws.hx, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 0, d_h, ld_tok, stream));
+                TRY(ag_side_mlp(ws.hx, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 0, d_h, ld_tok, dyn, stream));
             } else {
             if (fold2) {
                 TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                            ws.st2, w.s_fc1_ln, d->ln_eps, nullptr, stream));
+                            ws.st2, w.s_fc1_ln, d->ln_eps, nullptr, dyn, stream));
             } else {
-                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, stream));
+                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
                 TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                            nullptr, nullptr, 0.f, nullptr, stream));
+                            nullptr, nullptr, 0.f, nullptr, dyn, stream));
             }
             // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
-                        nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, stream));
+                        nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, dyn, stream));
             }
             st1_ready = next_fold1;
             if (chain_out && stats_written) *stats_written = next_fold1 ? 1 : 0;
@@ -170,13 +171,13 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
             if (ln1_done) {
                 a = ws.ha;
             } else if (w.ln1_g) {
-                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+                TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, dyn, stream));
                 a = ws.ha;
             }
             AG_REQUIRE(w.ln2_g, "ag_encoder_forward: BERT output.LayerNorm missing in layer %d", l);
             if (side_mlp) {   // narrow layer (LTT ladder): fc1 + GELU + fc2 + residual + LN2 in one kernel
                 char* dst = last_cls ? ws.ctx : (char*)d_h;
-                TRY(ag_side_mlp(a, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, stream));
+                TRY(ag_side_mlp(a, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, dyn, stream));
                 if (last_cls) {
                     hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R,
                                                     hipMemcpyDeviceToDevice, hs);
@@ -187,18 +188,18 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                 continue;
             }
             TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                        nullptr, nullptr, 0.f, nullptr, stream));
+                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
             char* pre = (a == ws.hx) ? ws.ha : ws.hx;
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
-                        nullptr, nullptr, 0.f, nullptr, stream));
+                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
             if (last_cls) {
                 // LayerNorm the compact [R,H] rows, then scatter them to token 0 of d_h
-                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
+                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, dyn, stream));
                 hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R,
                                                 hipMemcpyDeviceToDevice, hs);
                 if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
             } else {
-                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, d_h, nullptr, dt, stream));
+                TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, d_h, nullptr, dt, dyn, stream));
             }
         }
         h_in = (const char*)d_h;
@@ -233,7 +234,7 @@ extern "C" int ag_encoder_forward_chained(const ag_encoder_desc* d, const void* 
 // players are off on average: half the GEMM rows, a quarter of the attention.
 // Output contract = ag_encoder_forward(cls_only_last = 1): d_h [R,T,H] with token 0 of every row defined.
 // The packed row count never leaves the device: launches are sized for the upper bound R*T and clamp to it at run time
-// (ag_dynamic_rows), so this entry neither synchronises nor allocates and can be captured into a hipGraph.
+// (their d_rows argument), so this entry neither synchronises nor allocates and can be captured into a hipGraph.
 extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const void* d_h0, int R, int share,
                                               const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
                                               int* d_packed_rows_out, void* stream) {
@@ -241,11 +242,8 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     AG_REQUIRE(d->kind == AG_MASK_BERT_ADD, "ag_bert_encoder_forward_pruned: only the additive (BERT) mask prunes exactly");
     AG_REQUIRE(d->n_layers >= 1 && d->layers, "ag_bert_encoder_forward_pruned: no layers");
     if (d->n_layers == 1) {
-        if (d_packed_rows_out) {
-            const int all = R * d->T;
-            AG_HIP_CHECK(hipMemcpyAsync(d_packed_rows_out, &all, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
-            AG_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        }
+        if (d_packed_rows_out)   // (a 32-bit fill: asynchronous and legal under stream capture, unlike a copy from the stack)
+            AG_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)d_packed_rows_out, R * d->T, 1, (hipStream_t)stream));
         return ag_encoder_forward(d, d_h0, R, share, d_mask_bits, d_h, 1, d_workspace, workspace_bytes, stream);
     }
     AG_REQUIRE(workspace_bytes >= ag_encoder_workspace_bytes(d, R), "ag_bert_encoder_forward_pruned: workspace too small");
@@ -259,7 +257,7 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
     d0.n_layers = 1;
     TRY(ag_encoder_forward(&d0, d_h0, R, share, d_mask_bits, d_h, 0, d_workspace, workspace_bytes, stream));
     // plan + pack.  The packed row count N lives on the device (cu[R]); nothing is read back: the launches of the packed
-    // section are sized for the upper bound R*T and run under ag_dynamic_rows(cu + R), their kernels clamp to N.
+    // section are sized for the upper bound R*T and get d_rows = cu + R, their kernels clamp to N.
     int* cu = ws.idx;
     int* tok_src = ws.idx + R + 1;
     TRY(ag_seq_compact_plan(d_mask_bits, R, T, cu, tok_src, stream));
@@ -281,15 +279,9 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         const ag_layer_weights& w = d->layers[l];
         if (!w.ln1_g || !w.ln2_g || !w.w_fc1_ln || (l >= 2 && !w.w_qkv_ln)) fold = false;
     }
-    struct DynScope {                      // launches inside run on *dN rows; restored on every exit path
-        const int* prev;
-        explicit DynScope(const int* p) : prev(g_ag_dyn_rows) { g_ag_dyn_rows = p; }
-        ~DynScope() { g_ag_dyn_rows = prev; }
-        void off() { g_ag_dyn_rows = prev; }
-        void on(const int* p) { g_ag_dyn_rows = p; }
-    } dyn(dN);
+    const int* dyn = dN;                   // d_rows of the packed section's launches (NULL again for the last layer's CLS rows)
     char* x = ws.xs;                       // packed stream entering the layer
-    TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, stream));
+    TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, dyn, stream));
     char* xn = (char*)d_h;                 // d_h is free again (only token 0 of each row is defined at exit): ping-pong
     bool x_pre = false;                    // fold: x holds pre-LN rows of the previous layer's output.LayerNorm, ws.st2 their statistics
     for (int l = 1; l < d->n_layers; ++l) {
@@ -299,20 +291,20 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         const ag_layer_weights& wp = d->layers[l - 1];
         if (x_pre)
             TRY(ag_gemm(x, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, ws.st2, w.s_qkv_ln,
-                        d->ln_eps, nullptr, stream));
+                        d->ln_eps, nullptr, dyn, stream));
         else
-            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         TRY(ag_masked_attention_varlen(ws.qkv, cu, ws.ctx, R, T, H, d->heads, last ? 1 : 0, dt, stream));
         if (fold && !last) {
             // h1 = ctx Wo^T + bo + (l == 1 ? x : LN2_prev(x)) with statistics; inter = gelu(LN1(h1) W1^T + b1) folded;
             // h2 = inter W2^T + b2 + LN1(h1) recomputed, with statistics: the next layer's input
             if (x_pre)
-                TRY(ag_gemm_resid_ln(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, ws.st2, wp.ln2_g, wp.ln2_b, d->ln_eps, N, H, H, ws.st1, stream));
+                TRY(ag_gemm_resid_ln(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, ws.st2, wp.ln2_g, wp.ln2_b, d->ln_eps, N, H, H, ws.st1, dyn, stream));
             else
-                TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, stream));
+                TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, dyn, stream));
             TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, ws.st1, w.s_fc1_ln,
-                        d->ln_eps, nullptr, stream));
-            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, xn, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, stream));
+                        d->ln_eps, nullptr, dyn, stream));
+            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, xn, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, dyn, stream));
             char* t = x; x = xn; xn = t;
             x_pre = true;
             continue;
@@ -321,34 +313,34 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         const char* res = x;
         int Mo = N;
         if (last) {   // CLS rows only: compact [R,H] copies of the attention output and of the residual; exact row count from here on
-            dyn.off();
-            TRY(ag_gather_rows(ws.ctx, H, cu, ws.inter, H, R, H, dt, stream));
+            dyn = nullptr;
+            TRY(ag_gather_rows(ws.ctx, H, cu, ws.inter, H, R, H, dt, dyn, stream));
             char* rres = ws.inter + (size_t)R * H * es;
             if (x_pre) {   // the residual is LN2_prev of the (pre-LN) CLS rows: R rows, normalised here
                 char* tmp = ws.inter + 2 * (size_t)R * H * es;
-                TRY(ag_gather_rows(x, H, cu, tmp, H, R, H, dt, stream));
-                TRY(ag_layernorm(tmp, dt, H, R, H, wp.ln2_g, wp.ln2_b, d->ln_eps, rres, nullptr, dt, stream));
+                TRY(ag_gather_rows(x, H, cu, tmp, H, R, H, dt, dyn, stream));
+                TRY(ag_layernorm(tmp, dt, H, R, H, wp.ln2_g, wp.ln2_b, d->ln_eps, rres, nullptr, dt, dyn, stream));
             } else {
-                TRY(ag_gather_rows(x, H, cu, rres, H, R, H, dt, stream));
+                TRY(ag_gather_rows(x, H, cu, rres, H, R, H, dt, dyn, stream));
             }
             ctx = ws.inter; res = rres; Mo = R;
         }
-        TRY(ag_gemm(ctx, H, w.w_o, w.b_o, ws.hx, H, res, H, 1, 1, Mo, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(ctx, H, w.w_o, w.b_o, ws.hx, H, res, H, 1, 1, Mo, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         const char* a = ws.hx;
         if (w.ln1_g) {
-            TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+            TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, dyn, stream));
             a = ws.ha;
         }
         char* inter = last ? ws.qkv : ws.inter;   // (last: ws.inter holds the gathered CLS rows)
-        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         char* pre = (a == ws.hx) ? ws.ha : ws.hx;
-        TRY(ag_gemm(inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         if (last) {
-            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, stream));
+            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, dyn, stream));
             hipError_t e = hipMemcpy2DAsync(d_h, (size_t)T * H * es, ws.ctx, (size_t)H * es, (size_t)H * es, (size_t)R, hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipMemcpy2DAsync: %s", hipGetErrorString(e));
         } else {
-            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, xn, nullptr, dt, stream));
+            TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, xn, nullptr, dt, dyn, stream));
             char* t = x; x = xn; xn = t;
         }
     }
@@ -360,7 +352,8 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
 // such calls): x [N, H] holds the visible tokens of R sequences, cu_seqlens [R+1] their ranges; every packed token is a
 // visible key (mask-free varlen attention).  All tokens are processed (no CLS-only shortcut); out [N, H] must not alias x.
 extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const void* d_x, const int* d_cu_seqlens, int R, int N,
-                                             void* d_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+                                             void* d_out, void* d_workspace, size_t workspace_bytes, const int* d_rows, void* stream) {
+    const int* const dyn = d_rows;         // N is an upper bound when given: the kernels clamp to *d_rows
     AG_REQUIRE(d && d_x && d_cu_seqlens && d_out && d_workspace, "ag_bert_layers_forward_packed: null pointer");
     AG_REQUIRE(d->kind == AG_MASK_BERT_ADD, "ag_bert_layers_forward_packed: only the additive (BERT) mask prunes exactly");
     AG_REQUIRE(d->n_layers >= 1 && d->layers && R >= 1 && N >= R && N <= R * d->T, "ag_bert_layers_forward_packed: bad shape (R=%d N=%d)", R, N);
@@ -383,44 +376,44 @@ extern "C" int ag_bert_layers_forward_packed(const ag_encoder_desc* d, const voi
         const ag_layer_weights& w = d->layers[l];
         AG_REQUIRE(w.ln2_g, "ag_bert_layers_forward_packed: BERT output.LayerNorm missing in layer %d", l);
         if (fold_ok && w.ln1_g && w.w_fc1_ln) {
-            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+            TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
             TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
-            TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, stream));
+            TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, dyn, stream));
             TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, ws.st1, w.s_fc1_ln, d->ln_eps,
-                        nullptr, stream));
-            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, ws.ha, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, stream));
+                        nullptr, dyn, stream));
+            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, ws.ha, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, dyn, stream));
             char* dst_f = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
-            TRY(ag_layernorm(ws.ha, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst_f, nullptr, dt, stream));
+            TRY(ag_layernorm(ws.ha, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst_f, nullptr, dt, dyn, stream));
             x = dst_f;
             continue;
         }
         const char* a = ws.hx;
         if (side_lin) {   // narrow layers (LTT ladder): QKV, and out-proj + residual + LayerNorm, as one kernel each
-            TRY(ag_side_linear(x, H, N, H, 3 * H, w.w_qkv, w.b_qkv, nullptr, nullptr, nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, stream));
+            TRY(ag_side_linear(x, H, N, H, 3 * H, w.w_qkv, w.b_qkv, nullptr, nullptr, nullptr, 0, nullptr, nullptr, d->ln_eps, ws.qkv, 3 * H, dyn, stream));
             TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
             TRY(ag_side_linear(ws.ctx, H, N, H, H, w.w_o, w.b_o, nullptr, nullptr, x, H, w.ln1_g, w.ln1_b, d->ln_eps,
-                               w.ln1_g ? ws.ha : ws.hx, H, stream));
+                               w.ln1_g ? ws.ha : ws.hx, H, dyn, stream));
             if (w.ln1_g) a = ws.ha;
         } else {
-        TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         TRY(ag_masked_attention_varlen(ws.qkv, d_cu_seqlens, ws.ctx, R, T, H, d->heads, 0, dt, stream));
-        TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         if (w.ln1_g) {
-            TRY(ag_layernorm(ws.hx, dt, H, N, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, stream));
+            TRY(ag_layernorm(ws.hx, dt, H, N, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.ha, nullptr, dt, dyn, stream));
             a = ws.ha;
         }
         }
         // the last layer writes the caller's buffer; intermediate ones ping-pong through ws.xs (never an input of this loop)
         char* dst = (l == d->n_layers - 1) ? (char*)d_out : ws.xs;
         if (side_mlp) {
-            TRY(ag_side_mlp(a, H, N, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, stream));
+            TRY(ag_side_mlp(a, H, N, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 1, dst, H, dyn, stream));
             x = dst;
             continue;
         }
-        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, stream));
+        TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         char* pre = (a == ws.hx) ? ws.ha : ws.hx;
-        TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, N, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, stream));
-        TRY(ag_layernorm(pre, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst, nullptr, dt, stream));
+        TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, N, H, I, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
+        TRY(ag_layernorm(pre, dt, H, N, H, w.ln2_g, w.ln2_b, d->ln_eps, dst, nullptr, dt, dyn, stream));
         x = dst;
     }
     return AG_OK;

@@ -292,7 +292,7 @@ int dispatch(int epi, const GemmArgs& a, hipStream_t s) {
 extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                        const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K,
                        int epilogue, int dtype, const float* d_ln_stats, const float* d_ln_colsum, float ln_eps,
-                       float* d_stats_out, void* stream) {
+                       float* d_stats_out, const int* d_rows, void* stream) {
     if (M == 0) return AG_OK;   // empty row sets (an empty torch tensor has a null data pointer) are legal no-ops
     AG_REQUIRE(d_A && d_W && d_C, "ag_gemm: null pointer");
     AG_REQUIRE(M >= 0 && N > 0 && K > 0, "ag_gemm: bad shape M=%d N=%d K=%d", M, N, K);
@@ -316,13 +316,13 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
         AG_HIP_CHECK(hipMemset(zero_chunk, 0, 256));
     }
     a.zeros = zero_chunk;
-    a.dyn = g_ag_dyn_rows;
+    a.dyn = d_rows;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic work of this launch: 2*M*N*K flops; bytes = A + W + C (+R) each touched once
     const double out_es = (epilogue == AG_EPI_BIAS_F32) ? 4.0 : (double)es;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * out_es + (has_r ? (double)M * N * es : 0.0), s,
-                     g_ag_dyn_rows ? (double)M : 0.0);
+                     d_rows, (double)M);
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
     const bool big = dtype == AG_BF16 && !force_small && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
     AG_REQUIRE(big || (!d_ln_stats && !d_stats_out), "ag_gemm: LayerNorm folding is only available on the large-M bf16 path "
@@ -333,10 +333,10 @@ extern "C" int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const floa
     // (resid_share <= 1: the residual row of output row m is row m whatever rows_per_seq says)
     if (dtype == AG_BF16 && !map_off && resid_share <= 1 &&
         ag_side_map_eligible(M, N, K, lda, ldc, ldr, epilogue, epilogue == AG_EPI_BIAS_GELU_ADD))
-        return ag_side_map(d_A, lda, d_W, d_bias, epilogue == AG_EPI_BIAS_GELU_ADD ? d_R : nullptr, ldr, d_C, ldc, M, N, K, 1, s);
+        return ag_side_map(d_A, lda, d_W, d_bias, epilogue == AG_EPI_BIAS_GELU_ADD ? d_R : nullptr, ldr, d_C, ldc, M, N, K, 1, d_rows, s);
     if (big)
         return ag_gemm_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue,
-                           d_ln_stats, d_ln_colsum, ln_eps, d_stats_out, s);
+                           d_ln_stats, d_ln_colsum, ln_eps, d_stats_out, d_rows, s);
     return dtype == AG_BF16 ? dispatch<bf16_t>(epilogue, a, s) : dispatch<float>(epilogue, a, s);
 }
 

@@ -582,8 +582,8 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
     // N = 768 GEMMs of a single-input inference step (75 tiles, K up to 3072), where the ring is 7 % faster.
     // fp32-output launches are the training step's (bf16 operands, fp32 activations): nothing folds a LayerNorm into them and
     // with the counted-vmcnt ring of the 64-tile kernel the break-even moved up: 130 tiles (duo BERT-base step -5 %, ViT -1.5 %).
-    const char* mt = getenv("AG_GEMM_BIG_MIN_TILES");       // (read per call: the kernel parity tests pin the ring with it)
-    const int min_tiles = mt ? atoi(mt) : (epilogue == AG_EPI_BIAS_F32 ? 130 : 48);
+    static AgKnob k_min_tiles("AG_GEMM_BIG_MIN_TILES");    // (the kernel parity tests pin the ring with it: ag_reload_knobs)
+    const int min_tiles = (int)k_min_tiles.get(epilogue == AG_EPI_BIAS_F32 ? 130 : 48);
     if ((long)ceil_div(M, BT) * ceil_div(N, BT) < min_tiles) return false;
     return M >= 1024 && N >= 256 && (N % 8) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);
@@ -592,7 +592,7 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                    const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
                    const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out,
-                   const float* d_rln_g, const float* d_rln_b, hipStream_t s) {
+                   const float* d_rln_g, const float* d_rln_b, const int* d_rows, hipStream_t s) {
     BigArgs a;
     a.rln_g = d_rln_g; a.rln_b = d_rln_b;
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
@@ -604,22 +604,24 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
     a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, BT);
     if (d_rln_g) { a.ln_inv_h = 1.0f / (float)N; a.ln_nslab = ceil_div(N, BT); }   // the statistics describe the residual rows [M, N]
     a.dbg = nullptr;
-    a.dyn = g_ag_dyn_rows;
-    if (getenv("AG_GEMM_DBG")) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
+    a.dyn = d_rows;
+    static AgKnob k_dbg("AG_GEMM_DBG");
+    if (k_dbg.is_set()) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
         static unsigned long long* dbuf = nullptr;
         if (!dbuf) { (void)hipMalloc((void**)&dbuf, 2 * 8 * 128 * 8 * sizeof(unsigned long long)); }
         a.dbg = dbuf;
-        FILE* f = fopen(getenv("AG_GEMM_DBG"), "w");
+        FILE* f = fopen(k_dbg.str, "w");
         if (f) { fprintf(f, "%p\n", (void*)dbuf); fclose(f); }
     }
     // group width: one group (the plain N-fastest order) unless the weight matrix overflows an XCD's 4 MiB L2 while the
     // A panels are cheap to fetch again (short K): then groups of <= 2.5 MiB of weight rows (fc1 768->3072: 2 groups of 6
     // tiles, measured -1.7 %; splitting fc2's 3 tiles (K = 3072) costs +16 %: its A panels are 1.5 MB each)
-    const int ngrp_env = getenv("AG_GEMM_NGRP") ? atoi(getenv("AG_GEMM_NGRP")) : 0;   // read per call: the parity tests toggle it
+    static AgKnob k_ngrp("AG_GEMM_NGRP"), k_wfit("AG_GEMM_WFIT_MB"), k_nt("AG_GEMM_NT");   // (the parity tests toggle them)
+    const int ngrp_env = (int)k_ngrp.get(0);
     {
         const int tiles_n = ceil_div(N, BT);
         const double wbytes = (double)N * K * 2.0;
-        const double wfit_mb = getenv("AG_GEMM_WFIT_MB") ? atof(getenv("AG_GEMM_WFIT_MB")) : 4.0;   // (experiment knob)
+        const double wfit_mb = k_wfit.get(4.0);   // (experiment knob)
         int groups = (wbytes > wfit_mb * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (2.5 * 1024 * 1024) + 0.999) : 1;
         int g = ngrp_env > 0 ? ngrp_env : ceil_div(tiles_n, groups);
         // wide outputs (16 or more N-tiles: none in the encoder): the 32 tiles an XCD runs at a time would be ONE row of
@@ -630,7 +632,7 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
         if (g > tiles_n) g = tiles_n;
         a.ngrp = g;
     }
-    const int nt_env = getenv("AG_GEMM_NT") ? atoi(getenv("AG_GEMM_NT")) : -1;
+    const int nt_env = (int)k_nt.get(-1);
     a.nt_store = nt_env >= 0 ? nt_env : ((double)M * N * 2.0 > 192.0 * 1024 * 1024);
     if (d_rln_g) return launch_ring_var<AG_EPI_BIAS_RESID, 3>(a, s);
     switch (epilogue) {
@@ -645,24 +647,24 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
 
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                 const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
-                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, hipStream_t s) {
+                const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, const int* d_rows, hipStream_t s) {
     return run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, rows_per_seq, resid_share, M, N, K, epilogue, d_ln_stats, d_ln_colsum,
-                   ln_eps, d_stats_out, nullptr, nullptr, s);
+                   ln_eps, d_stats_out, nullptr, nullptr, d_rows, s);
 }
 
 // C = A·Wᵀ + bias + LayerNorm(Rpre) with the LayerNorm recomputed in the epilogue from the pre-LN rows and their slab
 // statistics, and the statistics of the rows written handed on (see include/autognothi_hip.h).
 extern "C" int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                                 const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b,
-                                float ln_eps, int M, int N, int K, float* d_stats_out, void* stream) {
+                                float ln_eps, int M, int N, int K, float* d_stats_out, const int* d_rows, void* stream) {
     if (M == 0) return AG_OK;
     AG_REQUIRE(d_A && d_W && d_C && d_Rpre && d_r_stats && d_ln_g && d_ln_b && d_stats_out, "ag_gemm_resid_ln: null pointer");
     AG_REQUIRE(ag_gemm_resid_ln_supported(M, N, K, lda, ldc, ldr), "ag_gemm_resid_ln: shape M=%d N=%d K=%d is not served by the large-M "
                "bf16 kernel (check ag_gemm_resid_ln_supported first)", M, N, K);
     AgProfScope prof(AG_EPI_BIAS_RESID, 2.0 * M * (double)N * K, ((double)M * K + (double)N * K + 2.0 * (double)M * N) * 2.0, (hipStream_t)stream,
-                     g_ag_dyn_rows ? (double)M : 0.0);
+                     d_rows, (double)M);
     return run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_Rpre, ldr, 1, 1, M, N, K, AG_EPI_BIAS_RESID, d_r_stats, nullptr, ln_eps, d_stats_out,
-                   d_ln_g, d_ln_b, (hipStream_t)stream);
+                   d_ln_g, d_ln_b, d_rows, (hipStream_t)stream);
 }
 
 extern "C" int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr) {

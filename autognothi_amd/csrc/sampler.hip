@@ -316,6 +316,13 @@ extern "C" int ag_mask_purely_uniform(void* d_state, int batch, int n_players, i
     return run_sampler(d_state, batch, n_players, 0, nullptr, d_mask_i64, d_mask_bits, d_scratch, stream);
 }
 
+extern "C" int ag_mask_purely_uniform_rows(void* d_state, int batch_total, int row_lo, int row_hi, int n_players, int64_t* d_mask_i64,
+                                           uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream) {
+    AG_REQUIRE(d_state && d_scratch && n_players >= 1 && 0 <= row_lo && row_lo <= row_hi && row_hi <= batch_total,
+               "ag_mask_purely_uniform_rows: bad arguments (rows [%d, %d) of %d)", row_lo, row_hi, batch_total);
+    return run_sampler(d_state, row_hi - row_lo, n_players, 0, nullptr, d_mask_i64, d_mask_bits, d_scratch, stream, row_lo, batch_total);
+}
+
 extern "C" int ag_pack_mask(const int64_t* d_mask_i64, int rows, int n_players, uint32_t* d_mask_bits, void* stream) {
     if (rows == 0) return AG_OK;
     AG_REQUIRE(d_mask_i64 && d_mask_bits && rows >= 0 && n_players >= 1, "ag_pack_mask: bad arguments");

@@ -589,7 +589,7 @@ extern "C" int ag_side_mlp_supported(int h, int I, int dtype) {
 
 extern "C" int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, const void* d_w1, const float* d_b1, const void* d_w2,
                            const float* d_b2, const float* d_ln_g, const float* d_ln_b, float ln_eps, int post_ln, void* d_out,
-                           int64_t ldo, void* stream) {
+                           int64_t ldo, const int* d_rows, void* stream) {
     if (M == 0) return AG_OK;
     AG_REQUIRE(d_x && d_w1 && d_w2 && d_out && M > 0, "ag_side_mlp: null pointer");
     AG_REQUIRE(ag_side_mlp_supported(h, I, AG_BF16), "ag_side_mlp: h=%d I=%d unsupported (bf16, h in {32,64,96,128}, I %% 32 == 0, "
@@ -600,9 +600,9 @@ extern "C" int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, co
     a.x = (const bf16_t*)d_x; a.ldx = ldx; a.out = (bf16_t*)d_out; a.ldo = ldo;
     a.w1 = (const bf16_t*)d_w1; a.b1 = d_b1; a.w2 = (const bf16_t*)d_w2; a.b2 = d_b2;
     a.g = d_ln_g; a.be = d_ln_b; a.eps = ln_eps; a.M = M; a.h = h; a.I = I; a.post_ln = post_ln;
-    a.dyn = g_ag_dyn_rows;
+    a.dyn = d_rows;
     hipStream_t s = (hipStream_t)stream;
-    AgProfScope prof(AG_EPI_BIAS_GELU, 4.0 * M * (double)h * I, (double)M * h * 2.0 * 2.0 + 4.0 * h * I, s, g_ag_dyn_rows ? (double)M : 0.0);
+    AgProfScope prof(AG_EPI_BIAS_GELU, 4.0 * M * (double)h * I, (double)M * h * 2.0 * 2.0 + 4.0 * h * I, s, d_rows, (double)M);
     switch (h) {
         case 32: return launch_side<32>(a, s);
         case 64: return launch_side<64>(a, s);
@@ -618,7 +618,8 @@ extern "C" int ag_side_linear_supported(int h, int N, int post_ln, int dtype) {
 
 extern "C" int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N, const void* d_w, const float* d_b,
                               const float* d_pre_g, const float* d_pre_b, const void* d_resid, int64_t ldr,
-                              const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, void* stream) {
+                              const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, const int* d_rows,
+                              void* stream) {
     if (M == 0) return AG_OK;
     AG_REQUIRE(d_x && d_w && d_out && M > 0, "ag_side_linear: null pointer");
     AG_REQUIRE(ag_side_linear_supported(h, N, d_post_g != nullptr, AG_BF16), "ag_side_linear: h=%d N=%d unsupported", h, N);
@@ -627,10 +628,10 @@ extern "C" int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N,
     LinArgs a;
     a.x = (const bf16_t*)d_x; a.ldx = ldx; a.w = (const bf16_t*)d_w; a.b = d_b; a.resid = (const bf16_t*)d_resid; a.ldr = ldr;
     a.out = (bf16_t*)d_out; a.ldo = ldo; a.g0 = d_pre_g; a.b0 = d_pre_b; a.g1 = d_post_g; a.b1 = d_post_b; a.eps = ln_eps;
-    a.M = M; a.h = h; a.N = N; a.dyn = g_ag_dyn_rows;
+    a.M = M; a.h = h; a.N = N; a.dyn = d_rows;
     hipStream_t s = (hipStream_t)stream;
     AgProfScope prof(d_resid ? AG_EPI_BIAS_RESID : AG_EPI_BIAS, 2.0 * M * (double)h * N,
-                     (double)M * (h + N + (d_resid ? N : 0)) * 2.0 + 2.0 * h * N, s, g_ag_dyn_rows ? (double)M : 0.0);
+                     (double)M * (h + N + (d_resid ? N : 0)) * 2.0 + 2.0 * h * N, s, d_rows, (double)M);
     switch (h) {
         case 32: return launch_lin<32>(a, s);
         case 64: return launch_lin<64>(a, s);
@@ -647,10 +648,10 @@ bool ag_side_map_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 }
 
 int ag_side_map(const void* d_x, int64_t ldx, const void* d_w, const float* d_b, const void* d_resid, int64_t ldr, void* d_out,
-                int64_t ldo, int M, int N, int K, int gelu, hipStream_t s) {
+                int64_t ldo, int M, int N, int K, int gelu, const int* d_rows, hipStream_t s) {
     MapArgs a;
     a.x = (const bf16_t*)d_x; a.ldx = ldx; a.w = (const bf16_t*)d_w; a.b = d_b; a.resid = (const bf16_t*)d_resid; a.ldr = ldr;
-    a.out = (bf16_t*)d_out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.dyn = g_ag_dyn_rows;
+    a.out = (bf16_t*)d_out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.gelu = gelu; a.dyn = d_rows;
     switch (N) {
         case 32: return launch_map<32>(a, s);
         case 64: return launch_map<64>(a, s);

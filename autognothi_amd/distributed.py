@@ -28,6 +28,49 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def is_main() -> bool:
+    return world()[0] == 0
+
+
+def barrier() -> None:
+    if world()[1] > 1:
+        dist.barrier()
+
+
+class MainOnly:
+    """Rank-0-only view of the reference's ExpEnv for the pipeline entry points (scripts/train_*.py): ``log`` / ``metrics`` /
+    ``flush_cfg`` act on rank 0 and are no-ops elsewhere; everything else (``config``, ``model_path``, ``d_loader`` ...) reads
+    through.  The reference is single-process; with one process per GPU, N ranks appending to one ``.log.txt`` and rewriting
+    one ``.hparams.json`` would interleave."""
+
+    def __init__(self, env):
+        object.__setattr__(self, "_env", env)
+        object.__setattr__(self, "_main", is_main())
+
+    def __getattr__(self, name):
+        attr = getattr(self._env, name)
+        if name in ("log", "metrics", "flush_cfg") and not self._main:
+            return lambda *a, **k: None
+        return attr
+
+    def __setattr__(self, name, value):
+        setattr(self._env, name, value)
+
+
+def main_only(env):
+    return env if (env is None or world()[1] == 1) else MainOnly(env)
+
+
+def gather_objects(obj) -> list:
+    """every rank's python object, in rank order, on every rank (small host-side results: curves, counts)."""
+    _, w = world()
+    if w == 1:
+        return [obj]
+    out = [None] * w
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def shard_range(n_items: int, rank: Optional[int] = None, world_size: Optional[int] = None) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of n_items for `rank`; the first n % world ranks get one extra item."""
     r, w = world()
@@ -155,6 +198,13 @@ class GradBucketReducer:
         self._inflight: List[Tuple[object, Tensor, List[Tensor]]] = []
         self._seen = set()
         self.collectives = 0
+        self._weight: Optional[float] = None
+
+    def begin(self, weight: Optional[float] = None) -> None:
+        """Start a step.  ``weight`` = this rank's share of the step's global batch (inputs of this rank / inputs of all ranks):
+        the exchange then computes sum_r weight_r * grad_r — the gradient of the GLOBAL batch-mean loss when every rank
+        back-propagated its LOCAL batch-mean loss, also for ragged shards — instead of the plain average (weight None)."""
+        self._weight = weight
 
     def ready(self, p: Tensor) -> None:
         _, w = world()
@@ -175,22 +225,28 @@ class GradBucketReducer:
             return
         ps = self._pending
         flat = torch.cat([q.grad.reshape(-1) for q in ps])
+        if self._weight is not None:
+            flat *= self._weight
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._inflight.append((work, flat, ps))
         self._pending, self._pending_bytes = [], 0
         self.collectives += 1
 
-    def finish(self) -> int:
-        """-> number of collectives of this step."""
+    def finish(self, fill_missing: bool = False) -> int:
+        """-> number of collectives of this step.  ``fill_missing``: trainable parameters without a gradient take part as
+        zeros (a rank whose shard of the step is EMPTY still has to enter every collective, with the same bucket layout as
+        the others: such steps run un-instrumented on all ranks, in parameter order)."""
         _, w = world()
         if w > 1:
             for p in self.params:                 # gradients nobody reported (un-instrumented backward)
+                if p.grad is None and fill_missing:
+                    p.grad = torch.zeros_like(p)
                 if p.grad is not None and id(p) not in self._seen:
                     self.ready(p)
             self._flush()
             for work, flat, ps in self._inflight:
                 work.wait()
-                if self.average:
+                if self.average and self._weight is None:
                     flat /= w
                 off = 0
                 for q in ps:
@@ -198,7 +254,7 @@ class GradBucketReducer:
                     q.grad.copy_(flat[off:off + n].view_as(q.grad))
                     off += n
         n_coll = self.collectives
-        self._inflight, self._seen, self.collectives = [], set(), 0
+        self._inflight, self._seen, self.collectives, self._weight = [], set(), 0, None
         return n_coll
 
 

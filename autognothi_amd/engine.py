@@ -86,6 +86,31 @@ def invalidate_weight_caches() -> None:
     _WEIGHTS_EPOCH[0] += 1
 
 
+def watch_optimizer(optimizer) -> None:
+    """Make every ``optimizer.step()`` visible to the weight caches: a post-step hook bumps ``_ag_step`` of exactly the
+    parameters the optimiser owns (fused / foreach optimisers update without advancing ``Tensor._version``, and a forward
+    between ``backward`` and ``step`` would otherwise refill the caches under the post-backward key and keep serving the
+    pre-step weights).  Idempotent; the train_* entry points call it on the optimisers they build, the epoch bodies on the
+    one they are handed."""
+    if getattr(optimizer, "_ag_watched", False):
+        return
+
+    def bump(opt, *args, **kwargs):
+        for group in opt.param_groups:
+            for q in group["params"]:
+                q.__dict__["_ag_step"] = q.__dict__.get("_ag_step", 0) + 1
+    optimizer.register_step_post_hook(bump)
+    optimizer._ag_watched = True
+
+
+_CAPTURE_LOG: Optional[list] = None     # GraphedStep: the packs a capture baked pointers of
+
+
+def _log_pack(pack, key, tensors) -> None:
+    if _CAPTURE_LOG is not None:
+        _CAPTURE_LOG.append((pack, key, tensors))
+
+
 def _versions(params: Sequence[Tensor]) -> Tuple:
     return tuple(param_key(p) for p in params)
 
@@ -107,7 +132,11 @@ class PackedLinear:
                 self.w = ops.cast(w, dtype)
                 self.b = torch.cat([x.detach().float() for x in self.biases], dim=0).contiguous()
             self.key = key
+        _log_pack(self, key, (self.w, self.b))
         return self.w, self.b
+
+    def current_key(self, dtype: int) -> Tuple:
+        return (dtype, _versions(self.weights + self.biases))
 
 
 class PackedFoldedLinear:
@@ -131,7 +160,11 @@ class PackedFoldedLinear:
                 self.b = (b + w @ beta).contiguous()
                 self.s = self.w.float().sum(dim=1).contiguous()
             self.key = key
+        _log_pack(self, key, (self.w, self.b, self.s))
         return self.w, self.b, self.s
+
+    def current_key(self, dtype: int) -> Tuple:
+        return (dtype, _versions(self.weights + self.biases + [self.ln.weight, self.ln.bias]))
 
 
 def _f32(p: Optional[Tensor]) -> Optional[Tensor]:
@@ -242,8 +275,9 @@ class PackedEncoder:
         return out
 
 
-def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype: int) -> Tensor:
-    """(BERT kind) this encoder's layers on packed rows x [N, H] (visible tokens of `rows` sequences, cu_seqlens) -> [N, H]."""
+def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype: int, rows_dev: Optional[Tensor] = None) -> Tensor:
+    """(BERT kind) this encoder's layers on packed rows x [N, H] (visible tokens of `rows` sequences, cu_seqlens) -> [N, H].
+    rows_dev: device int32 [1] holding the actual packed row count (n_packed is then the upper bound)."""
     L.require_gpu(x, cu)
     if self.kind != L.AG_MASK_BERT_ADD:
         raise ValueError("packed (token-pruned) layers exist for the additive BERT mask only")
@@ -254,7 +288,7 @@ def _forward_packed(self, x: Tensor, cu: Tensor, rows: int, n_packed: int, dtype
         need = L.lib().ag_encoder_workspace_bytes(C.byref(d), rows)
         ws = WORKSPACE.get(x.device, need)
         L.check(L.lib().ag_bert_layers_forward_packed(C.byref(d), L.ptr(x), L.ptr(cu), rows, n_packed, L.ptr(out), L.ptr(ws),
-                                                      ws.numel(), L.stream()))
+                                                      ws.numel(), L.ptr(rows_dev), L.stream()))
     return out
 
 
@@ -313,21 +347,49 @@ class GraphedStep:
     Capture goes through torch.cuda.CUDAGraph (= hipStreamBeginCapture / hipGraphInstantiate on the launch stream) so that
     the tensors ``fn`` allocates come from a pool owned by the graph and stay valid across replays.
     The token-pruned BERT forward is capturable too: its data-dependent packed row count stays on the device
-    (ag_dynamic_rows).  Not capturable: host reads (``.item()``), in-library event timing (ag_profile_enable)."""
+    (the d_rows arguments of the C ABI).  Not capturable: host reads (``.item()``), in-library event timing (ag_profile_enable).
+    The graph keeps the workspace buffer and the weight packs of its capture alive and re-captures itself when a parameter
+    behind one of them has changed (``check=False`` skips that test: ~50 us of host time per replay on ViT-base)."""
 
-    def __init__(self, fn, warmup: int = 2):
-        self.fn = fn
+    def __init__(self, fn, warmup: int = 2, check: bool = True):
+        self.fn, self.warmup, self.check = fn, warmup, check
+        self._capture()
+
+    def _capture(self) -> None:
+        global _CAPTURE_LOG
+        fn = self.fn
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # weight packing, workspace growth, lazy kernel attributes: all before capture
-            for _ in range(max(1, warmup)):
+            for _ in range(max(1, self.warmup)):
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        _CAPTURE_LOG = []
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+            packs = _CAPTURE_LOG
+        finally:
+            _CAPTURE_LOG = None
+        # The graph holds RAW device pointers of storage it does not own: the shared workspace and the packed weights.  Keep
+        # references to exactly the tensors that were live at capture (a later, larger forward may make WORKSPACE drop its
+        # buffer; an optimiser step rebuilds the packs) so that a replay can never write into memory the allocator has handed
+        # out again, and remember what they were packed FROM so that a replay on stale weights is detected.
+        self._ws = dict(WORKSPACE.buf)
+        seen, self._packs = set(), []
+        for pack, key, tensors in packs:
+            if id(pack) not in seen:
+                seen.add(id(pack))
+                self._packs.append((pack, key, tensors))
+
+    def stale(self) -> bool:
+        """have the weights a captured launch reads been updated since capture?"""
+        return any(pack.current_key(key[0]) != key for pack, key, _ in self._packs)
 
     def __call__(self):
+        if self.check and self.stale():        # parameters changed (optimizer.step(), load_state_dict): capture again on the new packs
+            self._capture()
         self.graph.replay()
         return self.out

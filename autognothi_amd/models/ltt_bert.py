@@ -187,7 +187,7 @@ class LttBertModel(nn.Module):
         # layer 0 on every token (its QKV is shared by the K masks of an input), then pack
         hidden = self._bb[t][0].forward(self.embed(input_ids, token_type_ids, dtype), rows, rows // b, bits, False, dtype)
         # the packed row count stays on the device: the packed section is sized for the upper bound rows * t and its kernels
-        # clamp to cu[rows] (ops.dynamic_rows): no host read, the whole forward can be captured into a hipGraph
+        # clamp to cu[rows] (rows_dev): no host read, the whole forward can be captured into a hipGraph
         cu, src, n = ops.seq_compact_plan(bits, t, sync=False)
         n_dev = cu[rows:rows + 1]
         side: Dict[int, Optional[Tensor]] = {i_b: None for i_b in branches}
@@ -197,19 +197,18 @@ class LttBertModel(nn.Module):
                 w, bias = self._maps[f"{i_b}_0"].get(dtype)
                 s0 = ops.gemm(flat, w, bias, L.AG_EPI_BIAS_GELU, dtype)
                 s0 = self._side[(t, f"{i_b}_0")].forward(s0.view(rows, t, c.s_attn_hidden_size), rows, 1, bits, False, dtype)
-                with ops.dynamic_rows(n_dev):
-                    side[i_b] = ops.gather_rows(s0, src, n, dtype)
-        with ops.dynamic_rows(n_dev):
-            hidden = ops.gather_rows(hidden, src, n, dtype)
-            for i_ly in range(1, enc.num_layers):
-                hidden = self._bb[t][i_ly].forward_packed(hidden, cu, rows, n, dtype)
-                if i_ly >= enc._ltt_freeze_layer:
-                    continue
-                for i_b in branches:
-                    key = f"{i_b}_{i_ly}"
-                    w, bias = self._maps[key].get(dtype)
-                    s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1)
-                    side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype)
+                side[i_b] = ops.gather_rows(s0, src, n, dtype, rows_dev=n_dev)
+        hidden = ops.gather_rows(hidden, src, n, dtype, rows_dev=n_dev)
+        for i_ly in range(1, enc.num_layers):
+            hidden = self._bb[t][i_ly].forward_packed(hidden, cu, rows, n, dtype, rows_dev=n_dev)
+            if i_ly >= enc._ltt_freeze_layer:
+                continue
+            for i_b in branches:
+                key = f"{i_b}_{i_ly}"
+                w, bias = self._maps[key].get(dtype)
+                s_new = ops.gemm(hidden, w, bias, L.AG_EPI_BIAS_GELU_ADD, dtype, resid=side[i_b], rows_per_seq=1, resid_share=1,
+                                 rows_dev=n_dev)
+                side[i_b] = self._side[(t, key)].forward_packed(s_new, cu, rows, n, dtype, rows_dev=n_dev)
         engine.note_packed_rows(hidden.device, n_dev)
         h_cls = ops.gather_rows(hidden, cu, rows, dtype).view(rows, 1, c.hidden_size)
         s_cls = [ops.gather_rows(side[i_b], cu, rows, dtype).view(rows, 1, c.s_attn_hidden_size) for i_b in branches]

@@ -157,6 +157,20 @@ def mask_purely_uniform(rng: DeviceMT19937, batch: int, n_players: int, want_i64
     return mi, mb
 
 
+def mask_purely_uniform_rows(rng: DeviceMT19937, batch_total: int, row_lo: int, row_hi: int, n_players: int, want_i64: bool = True,
+                             want_bits: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """rows [row_lo, row_hi) of ``mask_purely_uniform(batch_total, n_players)``; the generator advances by the whole call."""
+    dev = rng.device
+    n = row_hi - row_lo
+    mi = torch.empty((n, n_players), dtype=torch.int64, device=dev) if want_i64 else None
+    mb = torch.empty((n, mask_words(n_players)), dtype=torch.int32, device=dev) if want_bits else None
+    scratch = torch.empty(max(1, n * (n_players + 1)), dtype=torch.int32, device=dev)
+    with L.on(dev):
+        L.check(L.lib().ag_mask_purely_uniform_rows(L.ptr(rng.state), batch_total, row_lo, row_hi, n_players, L.ptr(mi), L.ptr(mb),
+                                                    L.ptr(scratch), L.stream()))
+    return mi, mb
+
+
 def pack_mask(mask_i64: Tensor) -> Tensor:
     """[R,P] int64 0/1 -> [R, ceil((P+1)/32)] key bits with the always-on CLS bit prepended
     (recipes/vanilla_vit.py:219-224)."""
@@ -195,8 +209,10 @@ def cast(src: Tensor, dtype: int) -> Tensor:
 
 
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, rows: Optional[int] = None,
-              ldx: Optional[int] = None, want_store: bool = True, want_f32: bool = False):
-    """x [..., H] fp32 or bf16 (or a strided view described by rows/ldx); statistics in fp32."""
+              ldx: Optional[int] = None, want_store: bool = True, want_f32: bool = False, rows_dev: Optional[Tensor] = None):
+    """x [..., H] fp32 or bf16 (or a strided view described by rows/ldx); statistics in fp32.  ``rows_dev`` (here and in gemm /
+    gemm_resid_ln / gather_rows / side_*): device int32 tensor whose first element is the ACTUAL row count — ``rows`` is then
+    an upper bound that sizes the launch (the C ABI's ``d_rows`` argument)."""
     L.require_gpu(x, gamma, beta)
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"layernorm: unsupported input dtype {x.dtype}")
@@ -208,7 +224,7 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, ro
     yf = torch.empty((rows, h), dtype=torch.float32, device=x.device) if want_f32 else None
     with L.on(x.device):
         L.check(L.lib().ag_layernorm(L.ptr(x), x_dtype, ldx, rows, h, L.ptr(gamma), L.ptr(beta), eps, L.ptr(ys), L.ptr(yf),
-                                     dtype, L.stream()))
+                                     dtype, L.ptr(rows_dev), L.stream()))
     return ys, yf
 
 
@@ -216,7 +232,7 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
          lda: Optional[int] = None, resid: Optional[Tensor] = None, ldr: Optional[int] = None,
          rows_per_seq: int = 1, resid_share: int = 1, out: Optional[Tensor] = None, ldc: Optional[int] = None,
          ln_stats: Optional[Tensor] = None, ln_colsum: Optional[Tensor] = None, ln_eps: float = 0.0,
-         stats_out: Optional[Tensor] = None) -> Tensor:
+         stats_out: Optional[Tensor] = None, rows_dev: Optional[Tensor] = None) -> Tensor:
     """epilogue(A[M,K] @ W[N,K]^T + bias).  a, w, resid in the storage dtype; bias fp32.  Output: fp32 for
     AG_EPI_BIAS_F32, else the storage dtype."""
     L.require_gpu(a, w, bias, resid, out)
@@ -234,12 +250,12 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     with L.on(a.device):
         L.check(L.lib().ag_gemm(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr,
                                 rows_per_seq, resid_share, m, n, k, epilogue, dtype, L.ptr(ln_stats), L.ptr(ln_colsum),
-                                float(ln_eps), L.ptr(stats_out), L.stream()))
+                                float(ln_eps), L.ptr(stats_out), L.ptr(rows_dev), L.stream()))
     return out
 
 
 def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r_stats: Tensor, ln_g: Tensor, ln_b: Tensor,
-                  ln_eps: float, stats_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                  ln_eps: float, stats_out: Optional[Tensor] = None, rows_dev: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """A @ W^T + bias + LayerNorm(r_pre) with the LayerNorm recomputed in the epilogue from r_pre's slab statistics
     (ag_gemm_resid_ln; bf16, ring-kernel shapes only) -> (out [M,N] bf16, its slab statistics)."""
     L.require_gpu(a, w, bias, r_pre, r_stats, ln_g, ln_b)
@@ -250,12 +266,12 @@ def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r
         stats_out = new_row_stats(m, n, a.device)
     with L.on(a.device):
         L.check(L.lib().ag_gemm_resid_ln(L.ptr(a), k, L.ptr(w), L.ptr(bias), L.ptr(out), n, L.ptr(r_pre), n, L.ptr(r_stats), L.ptr(ln_g),
-                                         L.ptr(ln_b), float(ln_eps), m, n, k, L.ptr(stats_out), L.stream()))
+                                         L.ptr(ln_b), float(ln_eps), m, n, k, L.ptr(stats_out), L.ptr(rows_dev), L.stream()))
     return out, stats_out
 
 
 def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], ln_g: Optional[Tensor],
-             ln_b: Optional[Tensor], eps: float, post_ln: bool) -> Tensor:
+             ln_b: Optional[Tensor], eps: float, post_ln: bool, rows_dev: Optional[Tensor] = None) -> Tensor:
     """fused MLP half of a narrow layer (ag_side_mlp): x [M, h] bf16 -> [M, h] bf16."""
     L.require_gpu(x, w1, w2, b1, b2, ln_g, ln_b)
     x = x.contiguous()
@@ -263,12 +279,12 @@ def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Option
     out = torch.empty_like(x)
     with L.on(x.device):
         L.check(L.lib().ag_side_mlp(L.ptr(x), h, m, h, w1.shape[0], L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(ln_g), L.ptr(ln_b),
-                                    float(eps), 1 if post_ln else 0, L.ptr(out), h, L.stream()))
+                                    float(eps), 1 if post_ln else 0, L.ptr(out), h, L.ptr(rows_dev), L.stream()))
     return out
 
 
 def side_linear(x: Tensor, w: Tensor, b: Optional[Tensor], pre_ln=None, resid: Optional[Tensor] = None, post_ln=None,
-                eps: float = 1e-12) -> Tensor:
+                eps: float = 1e-12, rows_dev: Optional[Tensor] = None) -> Tensor:
     """fused narrow Linear (ag_side_linear): LN_post(resid + W . LN_pre(x) + b); pre_ln / post_ln = (gamma, beta) or None."""
     L.require_gpu(x, w, b, resid)
     x = x.contiguous()
@@ -280,7 +296,7 @@ def side_linear(x: Tensor, w: Tensor, b: Optional[Tensor], pre_ln=None, resid: O
     r = resid.contiguous() if resid is not None else None
     with L.on(x.device):
         L.check(L.lib().ag_side_linear(L.ptr(x), h, m, h, n, L.ptr(w), L.ptr(b), L.ptr(g0), L.ptr(b0), L.ptr(r), n, L.ptr(g1), L.ptr(b1),
-                                       float(eps), L.ptr(out), n, L.stream()))
+                                       float(eps), L.ptr(out), n, L.ptr(rows_dev), L.stream()))
     return out
 
 
@@ -385,7 +401,7 @@ def kl_loss(ref: Tensor, cur: Tensor, want_grad: bool = True):
 def seq_compact_plan(mask_bits: Tensor, t: int, sync: bool = True):
     """BERT token pruning plan: key bits [R, Tw] -> (cu_seqlens int32 [R+1], packed-row source table int32 [R*t], N).
     sync=True reads the packed row count N back (a 4-byte device->host copy); sync=False returns the upper bound R*t
-    instead: run the packed section under ``dynamic_rows(cu[R:])`` and nothing leaves the device."""
+    instead: pass ``rows_dev=cu[R:R+1]`` to the ops of the packed section and nothing leaves the device."""
     L.require_gpu(mask_bits)
     rows = mask_bits.shape[0]
     cu = torch.empty(rows + 1, dtype=torch.int32, device=mask_bits.device)
@@ -395,31 +411,19 @@ def seq_compact_plan(mask_bits: Tensor, t: int, sync: bool = True):
     return cu, src, (int(cu[rows].item()) if sync else rows * t)
 
 
-class dynamic_rows:
-    """context: the row counts passed to gemm / layernorm / gather_rows / side_* inside are upper bounds; the kernels read
-    the actual count from ``count`` (a device int32 tensor, first element) when they run (ag_dynamic_rows)."""
-
-    def __init__(self, count: Tensor):
-        L.require_gpu(count)
-        self.count = count
-
-    def __enter__(self):
-        L.check(L.lib().ag_dynamic_rows(L.ptr(self.count)))
-        return self
-
-    def __exit__(self, *exc):
-        L.check(L.lib().ag_dynamic_rows(None))
-        return False
+def reload_knobs() -> None:
+    """have the library read its experiment / test knobs (AG_GEMM_* ...) from the environment again (they are cached)."""
+    L.check(L.lib().ag_reload_knobs())
 
 
-def gather_rows(src: Tensor, index: Tensor, n: int, dtype: int) -> Tensor:
+def gather_rows(src: Tensor, index: Tensor, n: int, dtype: int, rows_dev: Optional[Tensor] = None) -> Tensor:
     """dst[i, :] = src2d[index[i], :] for the first n entries of index (src viewed as [-1, H])."""
     L.require_gpu(src, index)
     h = src.shape[-1]
     s2 = src.contiguous().view(-1, h)
     out = torch.empty((n, h), dtype=s2.dtype, device=s2.device)
     with L.on(s2.device):
-        L.check(L.lib().ag_gather_rows(L.ptr(s2), h, L.ptr(index), L.ptr(out), h, n, h, dtype, L.stream()))
+        L.check(L.lib().ag_gather_rows(L.ptr(s2), h, L.ptr(index), L.ptr(out), h, n, h, dtype, L.ptr(rows_dev), L.stream()))
     return out
 
 

@@ -28,3 +28,42 @@ def device_rng(holder: Any, device: torch.device, seed: Optional[int]):
     elif seed is not None:
         cache[key].seed(seed)
     return cache[key]
+
+
+class MaskSource:
+    """The mask stream of an epoch, as the row-sharded ranks of a run consume it: ONE generator state, identical on every rank;
+    each call names the size of the GLOBAL batch and the input range [lo, hi) this rank owns, returns this rank's key bits and
+    advances the state by the WHOLE global call (ag_mask_shapley_new_rows / ag_mask_purely_uniform_rows: the other ranks' draws
+    are stepped over with twists only).  The union of the ranks' masks is bit-identical to the single-process reference loop
+    on the whole batch (models/shapley.py:56-79, :109-115), and at one rank this IS that loop."""
+
+    def __init__(self, rng):
+        self.rng = rng
+
+    def shapley(self, n_inputs_total: int, lo: int, hi: int, k: int, n_players: int):
+        from .. import ops
+        if lo == 0 and hi == n_inputs_total:
+            return ops.mask_shapley_new(self.rng, n_inputs_total * k, n_players, want_i64=False, want_bits=True)[1]
+        return ops.mask_shapley_new_rows(self.rng, n_inputs_total * k, lo * k, hi * k, n_players, want_i64=False, want_bits=True)[1]
+
+    def uniform(self, n_inputs_total: int, lo: int, hi: int, n_players: int):
+        from .. import ops
+        if lo == 0 and hi == n_inputs_total:
+            return ops.mask_purely_uniform(self.rng, n_inputs_total, n_players, want_i64=False, want_bits=True)[1]
+        return ops.mask_purely_uniform_rows(self.rng, n_inputs_total, lo, hi, n_players, want_i64=False, want_bits=True)[1]
+
+
+def mask_source(holder: Any, device: torch.device, seed: Optional[int]) -> MaskSource:
+    """the epoch's MaskSource on the (holder, device) generator of ``device_rng`` (reseeded when `seed` is given)."""
+    return MaskSource(device_rng(holder, device, seed))
+
+
+def shard(xs, zs=None):
+    """this rank's contiguous slice of a global batch (distributed.shard_range) -> (xs_local, zs_local, n_total, lo, hi).
+    One rank: the batch itself."""
+    from .. import distributed
+    n = xs.shape[0]
+    lo, hi = distributed.shard_range(n)
+    if lo == 0 and hi == n:
+        return xs, zs, n, lo, hi
+    return xs[lo:hi], (zs[lo:hi] if zs is not None else None), n, lo, hi

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from .. import ops
+from .. import distributed, ops
 from ..recipes.types import ModelRecipe
 from .common import Log
 
@@ -64,6 +64,7 @@ def measure_faithfulness(env: Any, device: torch.device, d_loader: Optional[Any]
     ``.config`` (``net``, ``train_*.epochs``, ``eval_faithfulness.resolution``), ``.model_path``, ``.log``; ``d_loader`` None
     falls back to ``env.d_loader`` (scripts/resources.load_cfg_dataset)."""
     from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env
+    env = distributed.main_only(env)
     env.log("loading final model...")
     config = env.config
     m_recipe, m_config = get_recipe(config)
@@ -90,20 +91,30 @@ def measure_faithfulness_loaded(env: Any, device: torch.device, recipe: ModelRec
                                 samples: Iterable[Tuple[Any, Any]], gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
                                 resolution: int) -> Dict[str, Any]:
     """reference measure_faithfulness (:41-140) given loaded models and a test iterator of single samples.
-    Returns the report fields (insertion / deletion AUC for target and non-target classes + raw curves)."""
-    env = env or Log()
-    ok_cls_l: List[int] = []
-    ins_curves: List[CurvePoint] = []
-    del_curves: List[CurvePoint] = []
+    Returns the report fields (insertion / deletion AUC for target and non-target classes + raw curves).
+    N > 1 ranks (the per-image loop :195-218 shards by image): every rank walks the same iterator, evaluates
+    sample i iff i % world == rank, and the per-sample curves are gathered (host objects, a few KB each) and re-ordered by
+    sample index, so every rank returns the single-process report."""
+    env = distributed.main_only(env) or Log()
+    rank, n_ranks = distributed.world()
+    mine: List[Tuple[int, int, CurvePoint, CurvePoint]] = []
     for i, (_inputs, _targets) in enumerate(samples):
+        if i % n_ranks != rank:
+            continue
         xs, zs = gen_input(_inputs, _targets)
         ok_cls = int(zs.item())
         explanation = explain(recipe, m_final, xs)
         ins_curve, del_curve = infer_perturbed(recipe, m_surrogate, xs, explanation, resolution)
-        ok_cls_l.append(ok_cls)
-        ins_curves.append(ins_curve)
-        del_curves.append(del_curve)
-        env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
+        mine.append((i, ok_cls, ins_curve, del_curve))
+        if n_ranks == 1:
+            env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
+    everything = sorted((item for part in distributed.gather_objects(mine) for item in part), key=lambda it: it[0])
+    ok_cls_l: List[int] = [it[1] for it in everything]
+    ins_curves: List[CurvePoint] = [it[2] for it in everything]
+    del_curves: List[CurvePoint] = [it[3] for it in everything]
+    if n_ranks > 1:
+        for i, ok_cls, ins_curve, del_curve in everything:
+            env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
 
     def paint(curves: List[Dict[int, float]]) -> Dict[str, Any]:
         items: Dict[int, List[float]] = {}

@@ -4,6 +4,7 @@ keys and shapes (tests/golden/state_keys*.json), so checkpoints trained by the r
 and checkpoints written here load into the reference, unchanged."""
 from __future__ import annotations
 
+import os
 import pathlib
 import re
 from collections import OrderedDict
@@ -75,14 +76,26 @@ def save_epoch_ckpt(path: pathlib.Path, section: str, ckpt_when: str, epochs: in
     if isinstance(state_dict, nn.Module):
         state_dict = OrderedDict((k, v.detach().cpu()) for k, v in state_dict.state_dict().items())
     this = ckpt_path(path, section, epoch)
-    if this.exists():
-        this.unlink()
-    torch.save(state_dict, this)
+    tmp = this.with_name(this.name + ".tmp")      # written aside and renamed: a reader (or a crash) never sees half a file
+    torch.save(state_dict, tmp)
+    os.replace(tmp, this)
     if not should_keep(epoch - 1):
-        last = ckpt_path(path, section, epoch - 1)
-        if last.exists():
-            last.unlink()
+        ckpt_path(path, section, epoch - 1).unlink(missing_ok=True)
     return True
+
+
+def save_epoch_ckpt_main(path: pathlib.Path, section: str, cfg, epoch: int, state_dict, env=None) -> bool:
+    """the pipelines' end-of-epoch write with one process per GPU: rank 0 writes the checkpoint (parameters are replicated) and
+    flushes the config, every rank then waits at a barrier so that none resumes from — or deletes — a file still being
+    written.  One rank: ``save_epoch_ckpt_cfg`` + ``env.flush_cfg()``, as the reference (scripts/train_explainer.py:119-123)."""
+    from .. import distributed
+    saved = True
+    if distributed.is_main():
+        saved = save_epoch_ckpt_cfg(path, section, cfg, epoch, state_dict)
+        if saved and env is not None and hasattr(env, "flush_cfg"):
+            env.flush_cfg()
+    distributed.barrier()
+    return saved
 
 
 def get_recipe(config) -> Tuple[object, object]:

@@ -10,9 +10,9 @@ from typing import Any, Callable, Iterable, List, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .. import distributed, ops
+from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, device_rng
+from .common import Log, MaskSource, mask_source as common_mask_source, shard
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -26,18 +26,21 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
                               d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                               optimizer: torch.optim.Optimizer, epoch: int,
                               gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
-                              target_rows: int = 1536) -> Tuple[float, float, float, float]:
+                              target_rows: int = 1536, mask_source: Optional[MaskSource] = None) -> Tuple[float, float, float, float]:
     """reference _duo_explainer_epoch_train (:121-213) -> (train_cls_loss, train_reg_loss, train_loss, train_cls_acc), the
     three losses as the reference accumulates them (sum of the per-batch values / samples).  The losses and the hit count stay
-    on the device during the epoch and are read once at its end."""
+    on the device during the epoch and are read once at its end.  N > 1 ranks: sharded exactly as
+    ``train_explainer.explainer_epoch_train`` (inputs of every batch by rank, one mask stream, gradients summed with weights
+    B_r / B, the epoch figures reduced once)."""
     from .. import training as _training
     from ..training import make_explainer_trainer
-    env = env or Log()
-    rng = device_rng(m_surrogate, device, seed)
+    env = distributed.main_only(env) or Log()
+    src = mask_source or common_mask_source(m_surrogate, device, seed)
     trainer = m_explainer.__dict__.get("_ag_trainer") or make_explainer_trainer(m_recipe, m_explainer)
     m_explainer.__dict__["_ag_trainer"] = trainer
     if not getattr(trainer, "duo", False):
         raise ValueError("duo_explainer_epoch_train: the explainer has no classification head (not a duo recipe)")
+    engine.watch_optimizer(optimizer)         # every step() invalidates the weight caches of the parameters it updates
     m_explainer.train()
     _, n_ranks = distributed.world()
     reducer = distributed.GradBucketReducer(m_explainer.parameters()) if n_ranks > 1 else None
@@ -48,7 +51,8 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
         group, rows = [], 0
         for idx, (_inputs, _targets) in enumerate(items):
             xs_, zs_ = gen_input(_inputs, _targets)
-            group.append((idx, xs_, zs_))
+            xs_, zs_, n_tot, lo, hi = shard(xs_, zs_)
+            group.append((idx, xs_, zs_, (n_tot, lo, hi)))
             rows += xs_.shape[0] * n_mask_samples
             if rows >= target_rows:
                 yield group
@@ -57,28 +61,39 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
             yield group
 
     for group in grouped(d_items):
-        tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, rng)
-        for (batch_idx, xs, zs), (bits, v_s, v_1) in zip(group, tg):
+        tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
+                                         spans=[g_[3] for g_ in group])
+        for (batch_idx, xs, zs, (n_tot, lo, hi)), (bits, v_s, v_1) in zip(group, tg):
             optimizer.zero_grad()
-            _training.GRAD_SINK = reducer.ready if reducer is not None else None
+            weight = (hi - lo) / float(n_tot)
+            ragged = n_tot < n_ranks
+            if reducer is not None:
+                reducer.begin(weight)
+            _training.GRAD_SINK = reducer.ready if (reducer is not None and not ragged) else None
             try:
-                trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True, seed=(seed or 0) + epoch)
+                if hi > lo:
+                    trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True, seed=(seed or 0) + epoch)
             finally:
                 _training.GRAD_SINK = None
             if reducer is not None:
-                reducer.finish()
+                reducer.finish(fill_missing=ragged)
             optimizer.step()
+            if hi == lo:
+                continue
             l_shap, l_cls, base = trainer.last_parts
             hits = base.argmax(dim=1).eq(zs.to(base.device)).sum().float()
-            parts.append(torch.stack([l_cls.reshape(()).float(), l_shap.reshape(()).float(), hits]))
+            wl = 1.0 if n_ranks == 1 else weight      # the two losses are batch means: this rank's share of the global mean
+            parts.append(torch.stack([l_cls.reshape(()).float() * wl, l_shap.reshape(()).float() * wl, hits]))
             total += xs.shape[0]
-            if getattr(env, "log_every_step", False):   # the reference logs every batch (three host reads per step)
+            if getattr(env, "log_every_step", False) and n_ranks == 1:   # the reference logs every batch (three host reads per step)
                 c_, s_, h_ = [float(v) for v in parts[-1].tolist()]
                 env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: cls {c_ / xs.shape[0]:.6f} shap {s_ / xs.shape[0]:.6f} "
                         f"tot {(c_ + s_) / xs.shape[0]:.6f}")
-    if not parts:
+    sums = [float(v) for v in torch.stack(parts).sum(0).tolist()] if parts else [0.0, 0.0, 0.0]
+    cls_loss, reg_loss, correct, total = distributed.reduce_scalars(sums + [total], device)
+    total = int(total)
+    if total == 0:
         return 0.0, 0.0, 0.0, 0.0
-    cls_loss, reg_loss, correct = [float(v) for v in torch.stack(parts).sum(0).tolist()]
     env.log(f"  > epoch {epoch} :train // loss: cls {cls_loss / total:.6f} shap {reg_loss / total:.6f} "
             f"tot {(cls_loss + reg_loss) / total:.6f} // acc: {100.0 * correct / total:.3f}%, {int(correct)}/{total}")
     return cls_loss / total, reg_loss / total, (cls_loss + reg_loss) / total, correct / total
@@ -86,28 +101,35 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
 
 def duo_explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                              d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer, epoch: int,
-                             gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None
-                             ) -> Tuple[float, float, float, float, List[Any]]:
+                             gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
+                             mask_source: Optional[MaskSource] = None) -> Tuple[float, float, float, float, List[Any]]:
     """reference _duo_explainer_epoch_eval (:216-307) -> (test_cls_loss, test_reg_loss, test_loss, test_cls_acc, test_plots);
     the plots list is empty there too (":todo: make plots")."""
-    env = env or Log()
-    rng = device_rng(m_surrogate, device, seed)
+    env = distributed.main_only(env) or Log()
+    src = mask_source or common_mask_source(m_surrogate, device, seed)
+    _, n_ranks = distributed.world()
     m_explainer.eval()
     parts: List[Tensor] = []
     total = 0
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, zs = gen_input(_inputs, _targets)
-        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
+        xs, zs, n_tot, lo, hi = shard(xs, zs)
+        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=(n_tot, lo, hi))
+        if hi == lo:
+            continue
+        wl = 1.0 if n_ranks == 1 else (hi - lo) / float(n_tot)
         l_shap, _, _, base = explainer_batch_loss(m_recipe, m_explainer, xs, bits, v_0, v_s, v_1, n_mask_samples, n_players)
         if base is None:
             raise ValueError("duo_explainer_epoch_eval: fw_explainer returned no class output (not a duo recipe)")
         l_cls = _cross_entropy_value(base, zs.to(base.device))
         hits = base.argmax(dim=1).eq(zs.to(base.device)).sum().float()
-        parts.append(torch.stack([l_cls.reshape(()).float(), l_shap.reshape(()).float(), hits]))
+        parts.append(torch.stack([l_cls.reshape(()).float() * wl, l_shap.reshape(()).float() * wl, hits]))
         total += xs.shape[0]
-    if not parts:
+    sums = [float(v) for v in torch.stack(parts).sum(0).tolist()] if parts else [0.0, 0.0, 0.0]
+    cls_loss, reg_loss, correct, total = distributed.reduce_scalars(sums + [total], device)
+    total = int(total)
+    if total == 0:
         return 0.0, 0.0, 0.0, 0.0, []
-    cls_loss, reg_loss, correct = [float(v) for v in torch.stack(parts).sum(0).tolist()]
     env.log(f"  > epoch {epoch} :test // loss: cls {cls_loss / total:.6f} shap {reg_loss / total:.6f} "
             f"tot {(cls_loss + reg_loss) / total:.6f} // acc: {100.0 * correct / total:.3f}%, {int(correct)}/{total}")
     return cls_loss / total, reg_loss / total, (cls_loss + reg_loss) / total, correct / total, []
@@ -118,7 +140,8 @@ def train_duo_explainer(env: Any, device: torch.device) -> None:
     script shares the key, :56), train + eval epoch, cosine schedule, the ten-field metrics entry, checkpoint.  ``env`` is
     duck-typed as in scripts/train_explainer.train_explainer."""
     from ..utils.tools import set_iterative_seed
-    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_cfg
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_main
+    env = distributed.main_only(env)
     env.log("[[[ !!! *experimental* train (duo) classifier + explainer !!! ]]]")
     config = env.config
     m_recipe, m_config = get_recipe(config)
@@ -150,5 +173,4 @@ def train_duo_explainer(env: Any, device: torch.device) -> None:
                          "test_cls_loss": te[0], "test_reg_loss": te[1], "test_loss": te[2], "test_cls_acc": te[3],
                          "test_plots": te[4]})
         env.log(f"  > epoch {epoch} done in {ts_delta:.2f}s // train_loss: shap {tr[1]:.6f} // test_loss: shap {te[1]:.6f}")
-        if save_epoch_ckpt_cfg(env.model_path, "explainer", tcfg, epoch, m_explainer) and hasattr(env, "flush_cfg"):
-            env.flush_cfg()
+        save_epoch_ckpt_main(env.model_path, "explainer", tcfg, epoch, m_explainer, env)

@@ -15,9 +15,10 @@ from typing import Any, Callable, Iterable, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .. import distributed, ops
+from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, device_rng
+from .common import Log, MaskSource, device_rng, shard
+from .common import mask_source as common_mask_source
 
 
 def surrogate_null(recipe: ModelRecipe, cfg, misc, m_surrogate, device: torch.device) -> Tensor:
@@ -30,10 +31,21 @@ def surrogate_null(recipe: ModelRecipe, cfg, misc, m_surrogate, device: torch.de
     return v0
 
 
-def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_samples: int, n_players: int, rng) -> Tuple[Tensor, Tensor, Tensor]:
-    """-> (mask key bits [B*K, Tw], v_s [B*K, C], v_1 [B, C]); row order [b0 s0, b0 s1, b1 s0, ...]."""
+def _source(rng_or_source) -> MaskSource:
+    return rng_or_source if hasattr(rng_or_source, "shapley") else MaskSource(rng_or_source)
+
+
+def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_samples: int, n_players: int, rng,
+                      span: Optional[Tuple[int, int, int]] = None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """-> (mask key bits [B*K, Tw], v_s [B*K, C], v_1 [B, C]); row order [b0 s0, b0 s1, b1 s0, ...].  ``xs`` are THIS rank's
+    inputs; ``span`` = (inputs of the global batch, lo, hi) names them inside the global batch (default: xs is the batch) — the
+    masks are this rank's rows of the global ``mask_shapley_new`` call (scripts/common.MaskSource).  ``rng``: a device
+    generator or a MaskSource.  An empty shard returns (bits [0, Tw], None, None)."""
     b = xs.shape[0]
-    _, bits = ops.mask_shapley_new(rng, b * n_mask_samples, n_players, want_i64=False, want_bits=True)
+    n_total, lo, hi = span if span is not None else (b, 0, b)
+    bits = _source(rng).shapley(n_total, lo, hi, n_mask_samples, n_players)
+    if b == 0:
+        return bits, None, None
     m_surrogate.eval()
     with torch.no_grad():
         v_s, _ = recipe.fw_surrogate(m_surrogate, xs, bits)          # B inputs, B*K mask rows: shared layer 0
@@ -42,25 +54,32 @@ def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_sampl
     return bits, v_s, v_1
 
 
-def surrogate_targets_lookahead(recipe: ModelRecipe, m_surrogate, xs_list, n_mask_samples: int, n_players: int, rng):
+def surrogate_targets_lookahead(recipe: ModelRecipe, m_surrogate, xs_list, n_mask_samples: int, n_players: int, rng, spans=None):
     """The surrogate is frozen while the explainer trains, so the K-mask targets of the NEXT batches do not depend on
     anything the optimiser does: the masked forwards of several consecutive batches are run as ONE forward over their
     concatenated inputs — the hot path then always works on a few thousand rows, whatever the training batch size is (the
     reference trains on 2-4 inputs per step: 64-128 rows, a fraction of one round of GEMM tiles).  Masks are drawn per
-    batch, in batch order, from the same device stream, so every batch gets exactly the masks (and values) it would get
-    from ``surrogate_targets`` called batch by batch.  -> list of (bits, v_s, v_1) per batch."""
-    bits_l = [ops.mask_shapley_new(rng, x.shape[0] * n_mask_samples, n_players, want_i64=False, want_bits=True)[1] for x in xs_list]
-    xs_all = torch.cat(list(xs_list), dim=0) if len(xs_list) > 1 else xs_list[0]
-    bits_all = torch.cat(bits_l, dim=0) if len(bits_l) > 1 else bits_l[0]
+    batch, in batch order, from the same stream, so every batch gets exactly the masks (and values) it would get
+    from ``surrogate_targets`` called batch by batch.  ``spans[i]`` = (global inputs, lo, hi) of batch i for row-sharded
+    ranks (xs_list holds the local slices).  -> list of (bits, v_s, v_1) per batch."""
+    src = _source(rng)
+    spans = spans if spans is not None else [(x.shape[0], 0, x.shape[0]) for x in xs_list]
+    bits_l = [src.shapley(n_tot, lo, hi, n_mask_samples, n_players) for (n_tot, lo, hi) in spans]
+    live = [i for i, x in enumerate(xs_list) if x.shape[0] > 0]
+    out = [(bits_l[i], None, None) for i in range(len(xs_list))]
+    if not live:
+        return out
+    xs_all = torch.cat([xs_list[i] for i in live], dim=0) if len(live) > 1 else xs_list[live[0]]
+    bits_all = torch.cat([bits_l[i] for i in live], dim=0) if len(live) > 1 else bits_l[live[0]]
     m_surrogate.eval()
     with torch.no_grad():
         v_s, _ = recipe.fw_surrogate(m_surrogate, xs_all, bits_all)
         ones = torch.ones((xs_all.shape[0], n_players), dtype=torch.long, device=xs_all.device)
         v_1, _ = recipe.fw_surrogate(m_surrogate, xs_all, ones)
-    out, r0, b0 = [], 0, 0
-    for x, bits in zip(xs_list, bits_l):
-        b = x.shape[0]
-        out.append((bits, v_s[r0:r0 + b * n_mask_samples], v_1[b0:b0 + b]))
+    r0, b0 = 0, 0
+    for i in live:
+        b = xs_list[i].shape[0]
+        out[i] = (bits_l[i], v_s[r0:r0 + b * n_mask_samples], v_1[b0:b0 + b])
         r0 += b * n_mask_samples
         b0 += b
     return out
@@ -79,20 +98,28 @@ def explainer_batch_loss(recipe: ModelRecipe, m_explainer, xs: Tensor, bits: Ten
 
 def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                          d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer, epoch: int,
-                         gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None) -> float:
-    """reference _explainer_epoch_eval (:210-281) -> test_reg_loss (mean over samples)."""
-    env = env or Log()
-    rng = device_rng(m_surrogate, device, seed)
+                         gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
+                         mask_source: Optional[MaskSource] = None) -> float:
+    """reference _explainer_epoch_eval (:210-281) -> test_reg_loss (sum of the per-batch mean losses / samples, as the
+    reference accumulates it).  N > 1 ranks: every rank walks the same batches and takes its input slice (as in
+    ``explainer_epoch_train``); the epoch figure is reduced once at the end."""
+    env = distributed.main_only(env) or Log()
+    src = mask_source or common_mask_source(m_surrogate, device, seed)
     reg_loss, total = 0.0, 0
     m_explainer.eval()
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, _zs = gen_input(_inputs, _targets)
-        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, rng)
+        xs, _zs, n_tot, lo, hi = shard(xs, _zs)
+        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=(n_tot, lo, hi))
+        if hi == lo:
+            continue
         loss, _, _, _ = explainer_batch_loss(m_recipe, m_explainer, xs, bits, v_0, v_s, v_1, n_mask_samples, n_players)
-        lv = float(loss.item())
+        lv = float(loss.item()) * ((hi - lo) / n_tot)      # this rank's share of the global batch-mean loss
         reg_loss += lv
-        total += xs.shape[0]
-        env.log(f"  > epoch {epoch} :{batch_idx}:test // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
+        total += hi - lo
+        if distributed.world()[1] == 1:
+            env.log(f"  > epoch {epoch} :{batch_idx}:test // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
+    reg_loss, total = distributed.reduce_scalars([reg_loss, total], device)
     return reg_loss / max(total, 1)
 
 
@@ -100,31 +127,42 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
                           d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                           optimizer: torch.optim.Optimizer, epoch: int,
                           gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
-                          target_rows: int = 1536) -> float:
+                          target_rows: int = 1536, mask_source: Optional[MaskSource] = None) -> float:
     """reference _explainer_epoch_train (:128-207) / _duo_explainer_epoch_train: per batch — K-mask surrogate
     targets (no grad, HIP inference path), explainer forward + Shapley loss + backward (HIP training kernels,
-    autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean)."""
+    autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean).
+
+    N > 1 ranks (one process per GPU; BASELINE config 5).  ``d_items`` yields the SAME global batches on every
+    rank (the reference's loader, unchanged); rank r takes inputs ``distributed.shard_range(B)`` of every batch together
+    with all K of their masks — its rows of the one global ``mask_shapley_new(B*K, P)`` call (``MaskSource``: no traffic,
+    bit-identical to the single-process stream) — runs targets, forward and backward on them, and the gradients are summed
+    over the ranks weighted by B_r / B (``GradBucketReducer``: 64 MiB buckets, each all-reduce in flight while the backward
+    below it still runs), which is exactly the gradient of the reference's batch-mean loss over the B inputs.  The epoch loss
+    is reduced ONCE at the end.  A batch with fewer inputs than ranks (the ragged tail of an epoch) leaves some ranks without
+    inputs: they enter the same collectives with zero gradients, and that step's exchange runs in parameter order on all
+    ranks.  With one rank this is the reference loop, step for step."""
     from ..training import make_explainer_trainer
-    env = env or Log()
-    rng = device_rng(m_surrogate, device, seed)
+    env = distributed.main_only(env) or Log()
+    src = mask_source or common_mask_source(m_surrogate, device, seed)
     from .. import training as _training
     trainer = m_explainer.__dict__.get("_ag_trainer") or make_explainer_trainer(m_recipe, m_explainer)
     m_explainer.__dict__["_ag_trainer"] = trainer
+    engine.watch_optimizer(optimizer)         # every step() invalidates the weight caches of the parameters it updates
     total = 0
     losses = []                                   # device scalars: read back ONCE per epoch (no per-step host sync)
     m_explainer.train()
-    # N > 1 ranks (rows sharded by input): gradients are averaged over RCCL in 64 MiB buckets whose all-reduce starts as soon
-    # as the backward has finished them (distributed.GradBucketReducer); a no-op at N = 1
     _, n_ranks = distributed.world()
     reducer = distributed.GradBucketReducer(m_explainer.parameters()) if n_ranks > 1 else None
     # surrogate targets are computed for groups of consecutive batches at once (surrogate_targets_lookahead): as many batches
     # as it takes to reach `target_rows` masked rows per forward (1536 = 48 inputs x 32 masks, the size the kernels are
     # tuned for); target_rows = 0 computes them batch by batch
+
     def grouped(items):
         group, rows = [], 0
         for idx, (_inputs, _targets) in enumerate(items):
             xs_, zs_ = gen_input(_inputs, _targets)
-            group.append((idx, xs_, zs_))
+            xs_, zs_, n_tot, lo, hi = shard(xs_, zs_)
+            group.append((idx, xs_, zs_, (n_tot, lo, hi)))
             rows += xs_.shape[0] * n_mask_samples
             if rows >= target_rows:
                 yield group
@@ -134,26 +172,37 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
 
     def batches():
         for group in grouped(d_items):
-            tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, rng)
-            for (idx, xs_, zs_), t_ in zip(group, tg):
-                yield idx, xs_, zs_, t_
+            tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
+                                             spans=[g_[3] for g_ in group])
+            for (idx, xs_, zs_, span), t_ in zip(group, tg):
+                yield idx, xs_, zs_, span, t_
 
-    for batch_idx, xs, zs, (bits, v_s, v_1) in batches():
+    for batch_idx, xs, zs, (n_tot, lo, hi), (bits, v_s, v_1) in batches():
         optimizer.zero_grad()
-        _training.GRAD_SINK = reducer.ready if reducer is not None else None
+        weight = (hi - lo) / float(n_tot)
+        ragged = n_tot < n_ranks                  # some rank holds no input of this batch: un-instrumented exchange for all
+        if reducer is not None:
+            reducer.begin(weight)
+        _training.GRAD_SINK = reducer.ready if (reducer is not None and not ragged) else None
         try:
-            loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
-                                                seed=(seed or 0) + epoch)
+            if hi > lo:
+                loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
+                                                    seed=(seed or 0) + epoch)
+                loss = loss.reshape(())
+            else:
+                loss = torch.zeros((), dtype=torch.float32, device=v_0.device)
         finally:
             _training.GRAD_SINK = None
         if reducer is not None:
-            reducer.finish()
+            reducer.finish(fill_missing=ragged)
         optimizer.step()
-        losses.append(loss.reshape(()))
-        total += xs.shape[0]
-        if getattr(env, "log_every_step", False):  # the reference logs the loss of every batch (a host read per step)
+        losses.append(loss if n_ranks == 1 else loss * weight)
+        total += hi - lo
+        if getattr(env, "log_every_step", False) and n_ranks == 1:  # the reference logs the loss of every batch (a host read per step)
             env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {float(loss.item()) / xs.shape[0]:.6f}, fin {total}")
     reg_loss = float(torch.stack(losses).sum().item()) if losses else 0.0
+    reg_loss, total = distributed.reduce_scalars([reg_loss, total], device)
+    total = int(total)
     env.log(f"  > epoch {epoch} :train // loss: shap {reg_loss / max(total, 1):.6f}, fin {total}")
     return reg_loss / max(total, 1)
 
@@ -168,13 +217,17 @@ def train_explainer(env: Any, device: torch.device) -> None:
     import time
 
     from ..utils.tools import set_iterative_seed
-    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_cfg
+    from .resources import get_recipe, load_cfg_dataset, load_epoch_model_env, save_epoch_ckpt_main
+    env = distributed.main_only(env)          # N > 1 ranks: log / metrics / config writes on rank 0 only
     env.log("[[[ train explainer ]]]")
     config = env.config
     m_recipe, m_config = get_recipe(config)
     if not m_recipe.training.support_explainer:
         env.log("[[[ skip: explainer cannot be trained ]]]")
         return
+    if m_recipe.training.exp_variant_duo:     # reference :26-27: duo recipes have their own loop and metrics
+        from .train_duo_explainer import train_duo_explainer
+        return train_duo_explainer(env, device)
     if m_recipe.training.exp_variant_kernel_shap:
         raise NotImplementedError("the kernel_shap explainer baseline is outside this build's scope")
     tcfg = config.train_explainer
@@ -210,5 +263,4 @@ def train_explainer(env: Any, device: torch.device) -> None:
             env.metrics({"epoch": epoch, "train_reg_loss": train_reg_loss, "test_reg_loss": test_reg_loss, "test_plots": []})
         env.log(f"  > epoch {epoch} done in {ts_delta:.2f}s // train_loss: shap {train_reg_loss:.6f} // "
                 f"test_loss: shap {test_reg_loss:.6f}")
-        if save_epoch_ckpt_cfg(env.model_path, "explainer", tcfg, epoch, m_explainer) and hasattr(env, "flush_cfg"):
-            env.flush_cfg()
+        save_epoch_ckpt_main(env.model_path, "explainer", tcfg, epoch, m_explainer, env)

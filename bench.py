@@ -295,8 +295,10 @@ def train_step_rate(job, dist, n_train, tb, precision):
     synth.load_synth_weights(m_exp, seed=1)
     m_exp = m_exp.to(dev)
     m_exp.train()
-    tx = torch.from_numpy(job.inputs(tb, 200 + job.rank)).to(dev)
-    labels = torch.zeros(tb, dtype=torch.long, device=dev)
+    # the GLOBAL batch (tb inputs per rank), identical on every rank: explainer_epoch_train takes this rank's slice of every batch,
+    # its rows of the one global mask call, and exchanges gradients from inside the backward (weak scaling: per-GPU work fixed)
+    tx = torch.from_numpy(job.inputs(tb * job.world, 200)).to(dev)
+    labels = torch.zeros(tb * job.world, dtype=torch.long, device=dev)
     opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5, fused=True)
     v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
     gen = lambda a, b_: (tx, labels)  # noqa: E731
@@ -330,6 +332,68 @@ def train_step_rate(job, dist, n_train, tb, precision):
     del m_exp, opt
     _tr.MIXED_BF16 = False
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
+
+
+FIXTURE_TAG = {"vit_base": "vit_base_l12", "bert_base": "bert_base_l12", "vit_large": "vit_large_l24",
+               "duo_bert_base": "duo_bert_base_l12", "froyo_vit_base": "froyo_vit_base_l12"}
+
+
+def bf16_vs_reference(workload, dev):
+    """Deviation of the throughput mode from the fp32 reference, from the committed full-depth fixture of this workload (one
+    input x K masks made by the reference itself, tests/golden/model_<tag>.npz), next to the reference's OWN deviation under
+    torch.autocast(bf16) on the same case (model_<tag>_bf16ref.npz).  Same code path as tests/test_gpu_fulldepth.py."""
+    tag = FIXTURE_TAG.get(workload)
+    if tag is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util as tu
+    if not os.path.exists(os.path.join(tu.GOLDEN, f"model_{tag}_bf16ref.npz")):
+        return None
+    c = tu.build_case(tag)
+    keep = engine.precision_name()
+    got = tu.run_fixture_case(c, dev, "bf16")
+    engine.set_precision(keep)
+    d = tu.bf16_deviation(got, c["g"], tu.golden(f"model_{tag}_bf16ref.npz"))
+    out = {k: (float("%.3g" % v) if isinstance(v, float) else {k2: float("%.3g" % v2) for k2, v2 in v.items()}) for k, v in d.items()}
+    out["fixture"] = f"tests/golden/model_{tag}.npz"
+    return out
+
+
+def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=None):
+    """One BASELINE config as a compact block of the driver line: `steps` timed steps of the same step function, in-library
+    event timing of its dominant kernel class."""
+    job = Job(workload, dev, rank, world, batch, 0, "bf16")
+    keep = engine.PRUNE_BERT_TOKENS
+    if prune is not None:
+        engine.PRUNE_BERT_TOKENS = prune
+    try:
+        for _ in range(2):
+            job.step()
+        torch.cuda.synchronize()
+        L.check(L.lib().ag_profile_enable(1))
+        for c in EPI_NAMES:
+            collect(c)
+        el, _ = timed(job.step, steps, 0, dist, dev)
+        L.check(L.lib().ag_profile_enable(0))
+        st = {c: collect(c) for c in EPI_NAMES}
+        packed = engine.last_packed_rows(dev)
+    finally:
+        engine.PRUNE_BERT_TOKENS = keep
+    value = job.R * world * steps / el
+    frac_vis = packed / float(job.R * job.T) if (job.kind in ("vanilla_bert", "duo_vanilla_bert") and packed and engine_prunes(prune)) else 1.0
+    f_exec = flops_executed(job.kind, job.params, job.T, job.K, frac_vis)
+    dom = max(st, key=lambda c: st[c][0])
+    ms, fl, _, n = st[dom]
+    return {"workload": WORKLOAD_LABEL[workload], "masks_per_input": job.K, "inputs_per_gpu_per_step": batch,
+            "value": round(value, 1), "unit": "masked-forwards/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
+            "dominant_kernel": EPI_NAMES[dom], "frac": round(fl / max(ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
+            "dominant_avg_us": round(1e3 * ms / max(1, n), 1),
+            "exec_frac_of_peak": round(value / world * f_exec / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "visible_token_fraction_after_layer0": round(frac_vis, 4)}
+
+
+def engine_prunes(prune):
+    return engine.PRUNE_BERT_TOKENS if prune is None else prune
 
 
 def main():
@@ -475,6 +539,31 @@ def main():
                                                         "row statistics); fc2's class average also contains the K = hidden out-projection",
                                                 "shapes": cal}
 
+    # ---- the other BASELINE configs that fit one GPU (configs 3 and 4), compact, same step function
+    if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16":
+        cfgs = {}
+        cfgs["bert_base_tayp_vanilla_seq128_K32"] = compact_config_line("bert_base", dev, rank, world, 48, dist)
+        cfgs["bert_base_tayp_vanilla_seq128_K32_token_pruning_off"] = compact_config_line("bert_base", dev, rank, world, 48, dist, prune=False)
+        cfgs["vit_large_imagenette_vanilla_K64"] = compact_config_line("vit_large", dev, rank, world, 48, dist, steps=3)
+        secondary["baseline_configs"] = {"what": "BASELINE.json configs 3 and 4 at one GPU per rank: masked-forwards/s, dominant-kernel "
+                                                 "fraction of the 2.5 PF bf16 peak (in-library hipEvents), whole-step executed fraction",
+                                         "configs": cfgs}
+
+    # ---- what the throughput mode costs in accuracy, from the committed reference fixtures (rank 0)
+    if not args.no_secondary and args.precision == "bf16" and rank == 0:
+        dev_blocks = {}
+        for wl in ([args.workload] + (["bert_base", "vit_large"] if args.workload == "vit_base" else [])):
+            blk = bf16_vs_reference(wl, dev)
+            if blk is not None:
+                dev_blocks[WORKLOAD_LABEL[wl]] = blk
+        if dev_blocks:
+            secondary["bf16_vs_reference"] = {
+                "what": "max / rms deviation of this library's bf16 mode from the fp32 reference outputs on the reference-made full-depth "
+                        "fixture (1 input x K masks): v_s = K-mask surrogate probabilities, phi = Shapley values relative to max|phi|; "
+                        "reference_autocast_bf16 = the reference itself under torch.autocast(bf16) against its fp32 self (the yardstick); "
+                        "fp32 mode meets 1e-4 (tests/test_gpu_fulldepth.py)",
+                "workloads": dev_blocks}
+
     # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +
     # surrogate + explainer forwards on all-ones masks -> phi [B, C, P]); untimed by the contract's K steps.
     attrs_per_s = None
@@ -514,6 +603,9 @@ def main():
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
                        "steps": 12,
+                       "sharding": "global batch = images_per_gpu_per_step x ranks; rank r trains on its input slice with its rows of the one "
+                                   "global mask call; gradients summed over RCCL in 64 MiB buckets from inside the backward "
+                                   "(scripts/train_explainer.explainer_epoch_train)",
                        "body": "K-mask surrogate targets (bf16; computed for groups of consecutive batches at once: the surrogate is frozen) + "
                                "explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 accumulate / activations / "
                                "optimizer state) + AdamW, as scripts/train_explainer.py:128-207",
@@ -565,6 +657,14 @@ def main():
                 "frac": round(fl / max(ms, 1e-9) / 1e9 / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel_source_sha16": build,
                 "algorithmic_bytes_per_launch": round(by / max(1, n)), "kernels": per_kernel})
+            if traffic is not None and args.workload in ("vit_base", "vit_large") and EPI_NAMES[dom] == "gemm<bias+residual>":
+                # the counter average is over the full-size launches of the class (L-1 out-projections + L-1 fc2; the last layer's two
+                # CLS-only launches are another kernel): pair it with the algorithmic bytes of exactly those launches
+                hid, inter_, m_rows = params["hidden_size"], params["intermediate_size"], R * T
+                algo_full = 0.5 * sum((m_rows * k_ + hid * k_ + 2.0 * m_rows * hid) * 2.0 for k_ in (hid, inter_))
+                roofline["traffic_launches"] = "full-size launches only (out-proj + fc2 of layers 0..L-2)"
+                roofline["algorithmic_bytes_per_traffic_launch"] = round(algo_full)
+                roofline["traffic_over_algorithmic"] = round(traffic / algo_full, 3)
         roofline["whole_step"] = {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
                                   "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
                                   "exec_tflops": round(value / world * f_exec / 1e12, 1),

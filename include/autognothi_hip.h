@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AG_ABI_VERSION 1
+#define AG_ABI_VERSION 2   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
@@ -85,6 +85,11 @@ int ag_mask_shapley_new_rows(void* d_state, int n_mask_samples_total, int row_lo
  * d_scratch: >= batch*(P+1) uint32. */
 int ag_mask_purely_uniform(void* d_state, int batch, int n_players, int64_t* d_mask_i64,
                            uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream);
+/* Rows [row_lo, row_hi) of the call ag_mask_purely_uniform(batch_total, ...) for a rank of a row-sharded run (the reference draws
+ * rand(B,P) first and rand(B,1) after it: a rank's rows are two spans of the stream); the state advances by the whole call.
+ * Outputs hold (row_hi - row_lo) rows; d_scratch: >= (row_hi - row_lo) * (P+1) uint32. */
+int ag_mask_purely_uniform_rows(void* d_state, int batch_total, int row_lo, int row_hi, int n_players, int64_t* d_mask_i64,
+                                uint32_t* d_mask_bits, uint32_t* d_scratch, void* stream);
 /* recipes/<kind>.py _fw_xs_preprocess: int64 [R,P] 0/1 mask -> [R, ceil((P+1)/32)] bits with CLS prepended. */
 int ag_pack_mask(const int64_t* d_mask_i64, int rows, int n_players, uint32_t* d_mask_bits, void* stream);
 /* scripts/measure_faithfulness.py:225-251 _get_perturbed_samples for `n_attr` attribution vectors
@@ -102,12 +107,18 @@ int ag_perturbed_masks(const float* d_attr, int n_attr, int n_players, int steps
 /* fp32 -> storage dtype conversion (weights packing). */
 int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream);
 
+/* Device-side row counts (`d_rows`).  ag_gemm, ag_gemm_resid_ln, ag_layernorm, ag_gather_rows, ag_side_mlp, ag_side_linear and
+ * ag_bert_layers_forward_packed take a `const int* d_rows` (device pointer, may be NULL).  NULL: the host-side row count (M / rows /
+ * n / N) is exact.  Non-NULL: the host-side count is an UPPER BOUND that sizes the launch; the kernel reads the actual count from
+ * d_rows[0] when it runs, builds its (XCD-aware) tile order from it, and surplus workgroups exit at once.  This is how the packed
+ * token count of a pruned BERT forward stays on the device: no device->host read, no synchronisation, graph-capturable. */
+
 /* torch.nn.LayerNorm over the last dim (reference call sites models/vanilla_vit.py:353-362,:205;
  * models/vanilla_bert.py:323,:559,:603).  x [rows, H] of dtype x_dtype (AG_F32 / AG_BF16) with row
  * stride ldx (elements); statistics in fp32; y_store (storage dtype, stride H) and/or y_f32
  * (stride H) may be NULL. */
 int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, const float* d_gamma, const float* d_beta,
-                 float eps, void* d_y_store, float* d_y_f32, int dtype, void* stream);
+                 float eps, void* d_y_store, float* d_y_f32, int dtype, const int* d_rows, void* stream);
 
 /* C[M,N] = epilogue(A[M,K] · W[N,K]ᵀ + bias[N]) — every nn.Linear on the path (q/k/v fused into
  * one [3H,H] weight: models/vanilla_vit.py:422-424; :477; :491; :510).  A, W in storage dtype
@@ -128,7 +139,7 @@ int ag_layernorm(const void* d_x, int x_dtype, int64_t ldx, int rows, int H, con
 int ag_gemm(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
             const void* d_R, int64_t ldr, int rows_per_seq, int resid_share,
             int M, int N, int K, int epilogue, int dtype,
-            const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, void* stream);
+            const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, const int* d_rows, void* stream);
 int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype);
 /* Post-LN residual without the LayerNorm pass (BERT, models/vanilla_bert.py:556-560 and :600-604: hidden = LayerNorm(dense(x) + input)
  * where `input` is itself the previous LayerNorm's output):  C = A·Wᵀ + bias + LayerNorm(Rpre)[m, n], bf16, large-M kernel only
@@ -139,7 +150,7 @@ int ag_gemm_supports_ln_fold(int M, int N, int K, int64_t lda, int64_t ldc, int6
  * residual (this call).  Together: a post-LN block chain in which no LayerNorm output is ever written or read. */
 int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                      const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps,
-                     int M, int N, int K, float* d_stats_out, void* stream);
+                     int M, int N, int K, float* d_stats_out, const int* d_rows, void* stream);
 int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr);
 /* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
  * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
@@ -147,20 +158,20 @@ int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, in
  *                 post_ln = 1 (BERT, models/vanilla_bert.py:576-577,:601-603):  out = LN(x + fc2(gelu(fc1(x))))
  * x [M, h] (row stride ldx), w1 [I, h], w2 [h, I] bf16, biases / LN parameters fp32, out [M, h] (row stride ldo).  Both weight
  * matrices stay in LDS, the I-wide intermediate never leaves registers.  ag_side_mlp_supported: h in {32, 64, 96, 128},
- * I % 32 == 0, weights fit the LDS.  Honours ag_dynamic_rows. */
+ * I % 32 == 0, weights fit the LDS. */
 int ag_side_mlp_supported(int h, int I, int dtype);
 int ag_side_mlp(const void* d_x, int64_t ldx, int M, int h, int I, const void* d_w1, const float* d_b1, const void* d_w2,
                 const float* d_b2, const float* d_ln_g, const float* d_ln_b, float ln_eps, int post_ln, void* d_out, int64_t ldo,
-                void* stream);
+                const int* d_rows, void* stream);
 /* One Linear of a narrow layer with its neighbours fused (bf16; the attention half of the ladder's side layers):
  *     out[M, N] = LN_post( resid + W . LN_pre(x) + b )       each of LN_pre (gamma/beta over h), resid [M,N], LN_post (over N) optional
  * = LN1 + QKV (ViT, models/vanilla_vit.py:369,:437-441), QKV (BERT), out-proj + residual (ViT :372,:477), out-proj + residual +
  * attention-output LayerNorm (BERT, models/vanilla_bert.py:557-559).  x [M, h], W [N, h]; h in {32,64,96,128}, N % 32 == 0,
- * N <= 384 (LN_post: N <= 128).  Honours ag_dynamic_rows. */
+ * N <= 384 (LN_post: N <= 128). */
 int ag_side_linear_supported(int h, int N, int post_ln, int dtype);
 int ag_side_linear(const void* d_x, int64_t ldx, int M, int h, int N, const void* d_w, const float* d_b,
                    const float* d_pre_g, const float* d_pre_b, const void* d_resid, int64_t ldr,
-                   const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, void* stream);
+                   const float* d_post_g, const float* d_post_b, float ln_eps, void* d_out, int64_t ldo, const int* d_rows, void* stream);
 /* row statistics (layout above) of a bf16 [rows,H] tensor -> d_stats [ceil(H/256), rows, 2]. */
 int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_stats, void* stream);
 
@@ -362,28 +373,26 @@ int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, 
  * layers 1.. on the packed visible tokens only (mask-free varlen attention).  Same output contract (token 0 of
  * every row of d_h [R,T,H]); d_packed_rows_out (optional, DEVICE int) receives the number of visible tokens.  Nothing is
  * read back to the host: the packed section's launches are sized for the upper bound R*T and clamp to the device-side count
- * (ag_dynamic_rows), so the call is asynchronous and graph-capturable.
+ * (their d_rows argument), so the call is asynchronous and graph-capturable.
  * Building blocks: ag_seq_compact_plan (cu_seqlens [R+1] by popcount + scan, packed-row -> source-row table [<= R*T]),
  * ag_gather_rows (dst[i,:] = src[index[i],:]), ag_masked_attention_varlen (rows = token ranges of cu_seqlens).
  * ---------------------------------------------------------------------------------------------- */
 int ag_seq_compact_plan(const uint32_t* d_mask_bits, int R, int T, int* d_cu_seqlens, int* d_tok_src, void* stream);
 int ag_gather_rows(const void* d_src, int64_t ld_src, const int* d_index, void* d_dst, int64_t ld_dst, int n, int H,
-                   int dtype, void* stream);
+                   int dtype, const int* d_rows, void* stream);
 int ag_masked_attention_varlen(const void* d_qkv, const int* d_cu_seqlens, void* d_ctx, int R, int t_max, int H,
                                int heads, int cls_only, int dtype, void* stream);
 /* desc's BERT layers on packed rows: x / out [N, H] (visible tokens of R sequences, ranges in cu_seqlens [R+1]), every packed
- * token a visible key, all tokens processed.  Workspace as ag_encoder_workspace_bytes(desc, R).  out must not alias x. */
+ * token a visible key, all tokens processed.  Workspace as ag_encoder_workspace_bytes(desc, R).  out must not alias x.
+ * d_rows (optional): N is an upper bound, the packed row count is read from d_rows[0] on the device (= d_cu_seqlens[R]). */
 int ag_bert_layers_forward_packed(const ag_encoder_desc* desc, const void* d_x, const int* d_cu_seqlens, int R, int N,
-                                  void* d_out, void* d_workspace, size_t workspace_bytes, void* stream);
+                                  void* d_out, void* d_workspace, size_t workspace_bytes, const int* d_rows, void* stream);
 int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0, int R, int share,
                                    const uint32_t* d_mask_bits, void* d_h, void* d_workspace, size_t workspace_bytes,
                                    int* d_packed_rows_out, void* stream);
-/* Row counts that only the device knows (the packed token count of a pruned forward): until reset with NULL, the row count
- * (M / rows / n) passed to ag_gemm, ag_layernorm and ag_gather_rows by THIS host thread is an upper bound that sizes the
- * launch; the kernels read the actual count from d_rows[0] when they run and skip the rest (surplus workgroups exit at
- * once; the XCD-aware tile order is built from the actual count).  Lets a data-dependent row count stay inside one
- * asynchronous, capturable stream of launches instead of a device->host read + synchronise. */
-int ag_dynamic_rows(const int* d_rows);
+/* Experiment / test knobs (AG_GEMM_*, AG_SIDE_MLP, AG_BERT_LN_FOLD, ...) are read from the environment ONCE per process, never on
+ * the launch path; a test that changes one calls this to have them read again. */
+int ag_reload_knobs(void);
 
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
  * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def ag_knobs(monkeypatch):
+    """set experiment knobs of the HIP library (AG_GEMM_* ...) for one test: the library caches them, so every change is
+    followed by ag_reload_knobs(), also when the test's environment is restored."""
+    from autognothi_amd import ops
+
+    def set_(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        ops.reload_knobs()
+    yield set_
+    monkeypatch.undo()
+    ops.reload_knobs()
+
+
 @pytest.fixture(scope="session")
 def cuda_device():
     import torch

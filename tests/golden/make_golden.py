@@ -412,6 +412,52 @@ def gen_full_depth_aux():
         print(tag, "reference fp32 vs fp64: v_s", np.abs(v_s64.numpy() - g["v_s"]).max(), "phi", np.abs(phi64.numpy() - g["phi"]).max(),
               "| pred absmax", pred.abs().max().item(), "phi absmax", np.abs(g["phi"]).max())
 
+def _full_depth_table():
+    return {
+        "vit_base_l12": (r_vvit.vanilla_vit_recipe, hparams("vit_base_imagenette_vanilla"), "vit", 32),
+        "bert_base_l12": (r_vbert.vanilla_bert_recipe, dict(hparams("bert_base_tayp_vanilla"), max_position_embeddings=128), "bert", 32),
+        "vit_large_l24": (r_vvit.vanilla_vit_recipe, hparams("vit_large_imagenette_vanilla"), "vit", 64),
+        "duo_bert_base_l12": (r_dbert.duo_vanilla_bert_recipe, dict(hparams("bert_base_tayp_duo_vanilla"), max_position_embeddings=128), "bert", 32),
+        "froyo_vit_base_l12": (r_fvit.froyo_vit_recipe, hparams("vit_base_imagenette_vanilla"), "vit", 32),
+    }
+
+
+def gen_full_depth_bf16ref():
+    """The yardstick for the throughput mode (round 3): the REFERENCE ITSELF in its own reduced-precision mode — the same
+    modules, weights, inputs and masks as model_<tag>.npz run under torch.autocast("cpu", dtype=torch.bfloat16), i.e. what a
+    reference user gets from stock mixed precision (bf16 matmul operands, fp32 LayerNorm / soft-max / residual adds).  Stored:
+    its v_s / v_1 / phi, so that the bf16 tests and bench.py can state the HIP bf16 mode's deviation from the fp32 reference
+    NEXT TO the reference's own bf16 deviation from itself."""
+    for tag, (recipe_fn, params, kind, K) in _full_depth_table().items():
+        g = np.load(os.path.join(HERE, f"model_{tag}.npz"))
+        recipe = recipe_fn()
+        cfg = recipe.t_config(**params)
+        P = recipe.n_players(cfg)
+        m_srg, m_exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
+        synth.load_synth_weights(m_srg, seed=0)
+        synth.load_synth_weights(m_exp, seed=1)
+        m_srg.eval(); m_exp.eval()
+        if kind == "vit":
+            Xs = torch.from_numpy(synth.synth_images(1, params["img_px_size"], params["img_channels"], seed=0))
+        else:
+            Xs = torch.from_numpy(synth.synth_token_ids(1, params["max_position_embeddings"], params["vocab_size"], seed=0))
+        masks = torch.from_numpy(np.unpackbits(g["masks"], axis=-1)[:, :P].astype(np.int64))
+        ones = torch.ones((1, P), dtype=torch.long)
+        v_1, v_0 = torch.from_numpy(g["v_1"]), torch.from_numpy(g["v_0"])
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            v_s_ac, _ = recipe.fw_surrogate(m_srg, torch.repeat_interleave(Xs, K, dim=0), masks)
+            v_1_ac, _ = recipe.fw_surrogate(m_srg, Xs, ones)
+            out = recipe.fw_explainer(m_exp, Xs, ones, v_1, v_0)
+        phi_ac = out[0].float().numpy()
+        v_s_ac, v_1_ac = v_s_ac.float().numpy(), v_1_ac.float().numpy()
+        e_vs, e_phi = np.abs(v_s_ac - g["v_s"]), np.abs(phi_ac - g["phi"])
+        save(f"model_{tag}_bf16ref.npz", v_s=v_s_ac, v_1=v_1_ac, phi=phi_ac,
+             v_s_maxabs=np.asarray([e_vs.max()]), v_s_rms=np.asarray([np.sqrt((e_vs ** 2).mean())]),
+             phi_maxabs=np.asarray([e_phi.max()]), phi_rms=np.asarray([np.sqrt((e_phi ** 2).mean())]),
+             phi_absmax=np.asarray([np.abs(g["phi"]).max()]))
+        print(tag, "reference under autocast(bf16) vs its fp32 self: v_s max", e_vs.max(), "rms", np.sqrt((e_vs ** 2).mean()),
+              "| v_1", np.abs(v_1_ac - g["v_1"]).max(), "| phi max", e_phi.max(), "=", e_phi.max() / np.abs(g["phi"]).max(), "of max|phi|")
+
 
 def gen_perturbed_ties():
     """_get_perturbed_samples on attributions WITH ties (SURVEY §8c fixture 4).  The reference ranks with np.argsort's
@@ -574,9 +620,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
         gen_mc_shapley()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "full_depth_aux", "perturbed_ties", "train_step"):   # round-2 additions
+    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "full_depth_aux", "full_depth_bf16ref", "perturbed_ties", "train_step"):   # round-2 additions
         {"full_depth": gen_full_depth, "full_depth_aux": gen_full_depth_aux, "perturbed_ties": gen_perturbed_ties,
-         "train_step": gen_train_step}[sys.argv[1]]()
+         "train_step": gen_train_step, "full_depth_bf16ref": gen_full_depth_bf16ref}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
         gen_ltt_models()

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _pin_ring_kernel(monkeypatch):
+def _pin_ring_kernel(ag_knobs):
     """ag_gemm sends problems of fewer than 48 tiles to the 128-tile kernel; these tests are about the ring kernel at every
-    shape class, small ones included (the selector reads the variable per call)."""
-    monkeypatch.setenv("AG_GEMM_BIG_MIN_TILES", "1")
+    shape class, small ones included."""
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1)
 
 BF16 = 1
 TOL = dict(rtol=1e-2, atol=2e-2)      # bf16 storage of the result: half an ulp at |x| <= 4 is 1.6e-2
@@ -195,7 +195,7 @@ def test_ring_producer_feeds_consumer(cuda_device):
 
 
 @pytest.mark.parametrize("env", [{"AG_GEMM_NT": "1"}, {"AG_GEMM_NGRP": "2"}, {"AG_GEMM_NGRP": "5"}, {"AG_GEMM_NT": "1", "AG_GEMM_NGRP": "3"}])
-def test_ring_store_and_tile_order_variants(cuda_device, env):
+def test_ring_store_and_tile_order_variants(cuda_device, env, ag_knobs):
     """the non-temporal store path (taken by itself when the output exceeds 192 MiB) and tile-order groups that do not divide
     the column tiles (ragged last group): same results as the default order."""
     from autognothi_amd import _lib as L, ops
@@ -204,17 +204,10 @@ def test_ring_store_and_tile_order_variants(cuda_device, env):
     dev = cuda_device
     A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
     r = _r(g.standard_normal((m, n)).astype(np.float32))
-    old = {kk: os.environ.get(kk) for kk in env}
-    os.environ.update(env)
-    try:
-        out = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
-        out_r = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev)).float().cpu().numpy()
-    finally:
-        for kk, v in old.items():
-            if v is None:
-                os.environ.pop(kk, None)
-            else:
-                os.environ[kk] = v
+    ag_knobs(**env)
+    out = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
+    out_r = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=_dev(r, dev)).float().cpu().numpy()
+    ag_knobs(AG_GEMM_NT=-1, AG_GEMM_NGRP=0)      # back to the defaults for the comparison run
     np.testing.assert_allclose(out, ref, **TOL)
     np.testing.assert_allclose(out_r, ref + r, **TOL)
     base = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16).float().cpu().numpy()
@@ -265,7 +258,7 @@ def test_ring_residual_is_layernorm_of_stored_rows(cuda_device, m, n, k):
 def test_ring_post_ln_chain_without_layernorm_passes(cuda_device):
     """two BERT sub-blocks chained as encoder.cpp chains them — h1 = ctx Wo^T + bo + x (statistics), inter = gelu(LN1(h1) W1^T + b1)
     folded, h2 = inter W2^T + b2 + LN1(h1) recomputed (statistics), q = LN2(h2) Wq^T + bq folded — against the same chain with
-    the LayerNorms materialised in float64; with a data-dependent row count (ag_dynamic_rows) on top."""
+    the LayerNorms materialised in float64; with a data-dependent row count (the ops' rows_dev / the C ABI's d_rows) on top."""
     from autognothi_amd import _lib as L, ops
     m, h, i = 1411, 768, 3072
     g = np.random.default_rng(123)
@@ -282,16 +275,14 @@ def test_ring_post_ln_chain_without_layernorm_passes(cuda_device):
         return wf, t((b_ + w_ @ bet).astype(np.float32)), wf.float().sum(1).contiguous()
 
     def chain(rows_dev=None):
-        import contextlib
-        cm = ops.dynamic_rows(rows_dev) if rows_dev is not None else contextlib.nullcontext()
-        with cm:
-            st1 = ops.new_row_stats(m, h, dev)
-            h1 = ops.gemm(_dev(ctx, dev), _dev(wo, dev), t(bo), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(x, dev), stats_out=st1)
-            w1f, b1f, s1f = fold(w1, b1, g1, be1)
-            inter = ops.gemm(h1, w1f, b1f, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st1, ln_colsum=s1f, ln_eps=1e-12)
-            h2, st2 = ops.gemm_resid_ln(inter, _dev(w2, dev), t(b2), h1, st1, t(g1), t(be1), 1e-12)
-            wqf, bqf, sqf = fold(wq, bq, g2, be2)
-            q = ops.gemm(h2, wqf, bqf, L.AG_EPI_BIAS, BF16, ln_stats=st2, ln_colsum=sqf, ln_eps=1e-12)
+        rd = dict(rows_dev=rows_dev)
+        st1 = ops.new_row_stats(m, h, dev)
+        h1 = ops.gemm(_dev(ctx, dev), _dev(wo, dev), t(bo), L.AG_EPI_BIAS_RESID, BF16, resid=_dev(x, dev), stats_out=st1, **rd)
+        w1f, b1f, s1f = fold(w1, b1, g1, be1)
+        inter = ops.gemm(h1, w1f, b1f, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st1, ln_colsum=s1f, ln_eps=1e-12, **rd)
+        h2, st2 = ops.gemm_resid_ln(inter, _dev(w2, dev), t(b2), h1, st1, t(g1), t(be1), 1e-12, **rd)
+        wqf, bqf, sqf = fold(wq, bq, g2, be2)
+        q = ops.gemm(h2, wqf, bqf, L.AG_EPI_BIAS, BF16, ln_stats=st2, ln_colsum=sqf, ln_eps=1e-12, **rd)
         return h1, inter, h2, q
 
     h1, inter, h2, q = chain()

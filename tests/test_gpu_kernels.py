@@ -229,11 +229,11 @@ def test_cpu_tensors_rejected():
         ops.gemm(torch.zeros(4, 64), torch.zeros(4, 64), None, L.AG_EPI_BIAS_F32, F32)
 
 
-def test_gemm_layernorm_fold(cuda_device, monkeypatch):
+def test_gemm_layernorm_fold(cuda_device, ag_knobs):
     """Linear(LayerNorm(x)) through the folded epilogue (row statistics + gamma-scaled weights) vs the oracle, and
     the producer side (statistics accumulated by the epilogue that writes the rows)."""
     from autognothi_amd import _lib as L, ops
-    monkeypatch.setenv("AG_GEMM_BIG_MIN_TILES", "1")     # the 2048 x 768 producer is 24 tiles: pin the ring kernel
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1)     # the 2048 x 768 producer is 24 tiles: pin the ring kernel
     g = np.random.default_rng(21)
     m, h, n = 2048, 768, 2304
     x = _bf16_round((g.standard_normal((m, h)) * 1.5 + 0.3).astype(np.float32))
@@ -297,7 +297,7 @@ def test_token_pruning_blocks(cuda_device, dtype, t, heads, rows, cls_only):
         qkv = _bf16_round(qkv)
     QKV = _to_store(qkv, dtype, dev)
     packed = torch.empty((n, 3 * h), dtype=QKV.dtype, device=dev)
-    L.check(L.lib().ag_gather_rows(L.ptr(QKV), 3 * h, L.ptr(src), L.ptr(packed), 3 * h, n, 3 * h, dtype, L.stream()))
+    L.check(L.lib().ag_gather_rows(L.ptr(QKV), 3 * h, L.ptr(src), L.ptr(packed), 3 * h, n, 3 * h, dtype, None, L.stream()))
     np.testing.assert_array_equal(packed.float().cpu().numpy(), qkv.reshape(rows * t, 3 * h)[want_src])
     ctx = torch.zeros((n, h), dtype=QKV.dtype, device=dev)
     L.check(L.lib().ag_masked_attention_varlen(L.ptr(packed), L.ptr(cu), L.ptr(ctx), rows, t, h, heads, cls_only, dtype, L.stream()))
@@ -337,12 +337,12 @@ def test_empty_inputs(cuda_device):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-def test_dynamic_row_counts(cuda_device, dtype, monkeypatch):
-    """ag_dynamic_rows: launches sized for an upper bound, the actual row count read from device memory (the packed token
+def test_dynamic_row_counts(cuda_device, dtype, ag_knobs):
+    """d_rows (ops: rows_dev): launches sized for an upper bound, the actual row count read from device memory (the packed token
     count of a pruned BERT forward never visits the host): rows below the count are computed exactly as by an exact-size
     launch, rows at or above it are left untouched — for the 128-tile GEMM, the ring GEMM, LayerNorm and the row gather."""
     from autognothi_amd import _lib as L, ops
-    monkeypatch.setenv("AG_GEMM_BIG_MIN_TILES", "1")     # 9 x 4 tiles: pin the ring kernel for the large-M case
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1)     # 9 x 4 tiles: pin the ring kernel for the large-M case
     dev = cuda_device
     g = np.random.default_rng(4)
     upper, actual, k, n = 2304, 1237, 768, 776
@@ -353,32 +353,25 @@ def test_dynamic_row_counts(cuda_device, dtype, monkeypatch):
     cnt = torch.tensor([actual], dtype=torch.int32, device=dev)
     sentinel = 768.0      # (exactly representable in bf16)
 
-    def run(fn):
-        L.check(L.lib().ag_dynamic_rows(L.ptr(cnt)))
-        try:
-            return fn()
-        finally:
-            L.check(L.lib().ag_dynamic_rows(None))
-
     for m_up in (upper, 600):         # ring kernel (bf16, M >= 1024) and the 128-tile kernel
         act = min(actual, m_up) if m_up == upper else 333
         cnt.fill_(act)
         want = ops.gemm(A[:act], W, B, L.AG_EPI_BIAS_GELU, dtype).float()
         out = torch.full((m_up, n), sentinel, dtype=want.dtype if dtype == F32 else torch.bfloat16, device=dev)
-        run(lambda: ops.gemm(A[:m_up], W, B, L.AG_EPI_BIAS_GELU, dtype, out=out))
+        ops.gemm(A[:m_up], W, B, L.AG_EPI_BIAS_GELU, dtype, out=out, rows_dev=cnt)
         assert torch.equal(out[:act].float(), want)
         assert bool((out[act:].float() == sentinel).all())
     cnt.fill_(actual)
     x = _to_store(a, dtype, dev)
     gam, bet = torch.from_numpy(g.standard_normal(k).astype(np.float32)).to(dev), torch.from_numpy(g.standard_normal(k).astype(np.float32)).to(dev)
     want, _ = ops.layernorm(x[:actual], gam, bet, 1e-12, dtype)
-    got, _ = run(lambda: ops.layernorm(x, gam, bet, 1e-12, dtype))
+    got, _ = ops.layernorm(x, gam, bet, 1e-12, dtype, rows_dev=cnt)
     assert torch.equal(got[:actual], want)
     idx = torch.from_numpy(g.permutation(upper).astype(np.int32)).to(dev)
     want = ops.gather_rows(x, idx, actual, dtype)
-    dst = run(lambda: ops.gather_rows(x, idx, upper, dtype))
+    dst = ops.gather_rows(x, idx, upper, dtype, rows_dev=cnt)
     assert torch.equal(dst[:actual], want)
-    # the state is per host thread and was reset: an ordinary call afterwards sees its full row count
+    # there is no mode to leak: a call without rows_dev sees its full row count
     full = ops.gemm(A, W, B, L.AG_EPI_BIAS, dtype)
     assert bool(torch.isfinite(full.float()).all()) and float(full[actual:].float().abs().max()) > 0
 

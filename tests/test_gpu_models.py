@@ -5,37 +5,13 @@ import numpy as np
 import pytest
 import torch
 
-from util import LTT_TAGS, MODEL_TAGS, build_case
+from util import LTT_TAGS, MODEL_TAGS, build_case, run_fixture_case
 
 pytestmark = pytest.mark.gpu
 
 
 def _run(c, dev, precision, share_inputs=True):
-    from autognothi_amd import engine, ops
-    engine.set_precision(precision)
-    recipe = c["recipe"]
-    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
-    xs = torch.from_numpy(c["xs"]).to(dev)
-    null = torch.from_numpy(c["null"]).to(dev)
-    masks = torch.from_numpy(c["masks"]).to(dev)
-    ones1 = torch.ones((1, c["P"]), dtype=torch.long, device=dev)
-    onesb = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
-    with torch.no_grad():
-        v_0, _ = recipe.fw_surrogate(srg, null, ones1)
-        xin = xs if share_inputs else torch.repeat_interleave(xs, c["K"], dim=0)
-        v_s, _ = recipe.fw_surrogate(srg, xin, masks)
-        v_1, _ = recipe.fw_surrogate(srg, xs, onesb)
-        edge = torch.stack([torch.zeros(c["P"], dtype=torch.long), torch.ones(c["P"], dtype=torch.long)]).to(dev)
-        v_edge, _ = recipe.fw_surrogate(srg, xs[:1], edge)
-        g = c["g"]
-        phi, extra = recipe.fw_explainer(exp, xs, onesb, torch.from_numpy(g["v_1"]).to(dev), torch.from_numpy(g["v_0"]).to(dev))
-        bits = ops.pack_mask(masks)
-        loss, dphi = ops.shapley_loss(bits, torch.from_numpy(g["v_0"]).to(dev), torch.from_numpy(g["v_s"]).to(dev),
-                                      torch.from_numpy(g["phi"]).to(dev), c["B"], c["K"])
-    out = dict(v_0=v_0, v_s=v_s, v_1=v_1, v_edge=v_edge, phi=phi, loss=loss, dphi=dphi)
-    if extra is not None:
-        out["exp_logits"] = extra
-    return {k: v.float().cpu().numpy() for k, v in out.items()}
+    return run_fixture_case(c, dev, precision, share_inputs)
 
 
 @pytest.mark.parametrize("tag", MODEL_TAGS)

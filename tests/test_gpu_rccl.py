@@ -76,6 +76,51 @@ def test_reducer_overlapped_with_backward_on_rccl(cuda_device, rccl_group, monke
     assert D.reduce_scalars([3.0, 4.0], dev) == [3.0, 4.0]
 
 
+def test_sharded_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
+    """scripts/train_explainer.explainer_epoch_train on its N > 1 path with the collectives on RCCL: the process pretends to be
+    rank 0 of 2, so of every global batch of 4 inputs it takes inputs [0, 2) and rows [0, 2K) of the global mask call, weights
+    its gradients by 1/2 and sums them over the (one real) rank.  Expected, from the plain pieces: masks = the first 2K rows of
+    mask_shapley_new(4K, P) on the epoch's seed, parameter step = lr * (1/2) * gradient of the local batch-mean loss, epoch
+    loss = (1/2) * loss / 2 inputs."""
+    from autognothi_amd import distributed as D, engine, ops, training as T
+    from autognothi_amd.scripts import train_explainer as te
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    engine.set_precision("fp32")
+    srg = c["surrogate"].to(dev).eval()
+    exp = c["explainer"].to(dev)
+    k, p = c["K"], c["P"]
+    xs4 = torch.cat([torch.from_numpy(c["xs"]), torch.from_numpy(c["xs"]).flip(0) * 0.5], 0).to(dev)     # a global batch of 4 inputs
+    zs4 = torch.zeros(4, dtype=torch.long, device=dev)
+    v_0 = torch.full((1, c["g"]["v_0"].shape[1]), 1.0 / c["g"]["v_0"].shape[1], device=dev)
+    seed, epoch = 99, 1
+    # expectation from the plain pieces
+    bits_full = ops.mask_shapley_new(ops.DeviceMT19937(dev, seed), 4 * k, p, want_i64=False, want_bits=True)[1]
+    bits = bits_full[:2 * k].contiguous()
+    with torch.no_grad():
+        v_s, _ = recipe.fw_surrogate(srg, xs4[:2], bits)
+        v_1, _ = recipe.fw_surrogate(srg, xs4[:2], torch.ones((2, p), dtype=torch.int64, device=dev))
+    trainer = T.make_explainer_trainer(recipe, exp)
+    exp.__dict__["_ag_trainer"] = trainer
+    params = [q for q in exp.parameters() if q.requires_grad]
+    exp.train()
+    for q in params:
+        q.grad = None
+    loss, _ = trainer.loss_and_grads(xs4[:2], bits, v_0, v_s, v_1, k, labels=zs4[:2], train=True, seed=seed + epoch)
+    want_grad = [q.grad.clone() for q in params]
+    before = [q.detach().clone() for q in params]
+    # the epoch body as rank 0 of 2
+    monkeypatch.setattr(D, "world", lambda: (0, 2))
+    opt = torch.optim.SGD(params, lr=0.5)
+    got = te.explainer_epoch_train(None, dev, k, p, v_0, [(None, None)], recipe, srg, exp, opt, epoch, lambda a, b_: (xs4, zs4),
+                                   seed=seed)
+    torch.cuda.synchronize()
+    assert abs(got - 0.5 * float(loss) / 2) <= 1e-5 * abs(float(loss))
+    gscale = max(float(w.abs().max()) for w in want_grad)
+    for q, q0, w in zip(params, before, want_grad):
+        torch.testing.assert_close(q0 - q.detach(), 0.5 * 0.5 * w, rtol=1e-4, atol=1e-6 * gscale)
+
+
 def test_bench_under_launcher_runs_rccl_barriers():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py`: the driver's N > 1 launch line with one rank."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -81,6 +81,49 @@ def build_case(tag):
     return out
 
 
+def bf16_deviation(got, g, ref):
+    """the figures bench.py reports as secondary.bf16_vs_reference: deviation of a bf16 run from the fp32 reference fixture,
+    next to the reference's own autocast(bf16) deviation (ref = model_<tag>_bf16ref.npz)."""
+    e_vs, e_phi = np.abs(got["v_s"] - g["v_s"]), np.abs(got["phi"] - g["phi"])
+    phi_max = float(np.abs(g["phi"]).max())
+    return dict(v_s_max_abs=float(e_vs.max()), v_s_rms=float(np.sqrt((e_vs ** 2).mean())),
+                v_1_max_abs=float(np.abs(got["v_1"] - g["v_1"]).max()),
+                phi_max_abs=float(e_phi.max()), phi_max_abs_over_max_phi=float(e_phi.max()) / phi_max,
+                phi_rms_over_max_phi=float(np.sqrt((e_phi ** 2).mean())) / phi_max,
+                reference_autocast_bf16=dict(v_s_max_abs=float(ref["v_s_maxabs"][0]), v_s_rms=float(ref["v_s_rms"][0]),
+                                             phi_max_abs_over_max_phi=float(ref["phi_maxabs"][0]) / phi_max))
+
+
+def run_fixture_case(c, dev, precision, share_inputs=True):
+    """the fixture's calls through the recipes' fw_* callables on the HIP path (same sequence as make_golden.gen_model_fixture) -> numpy dict."""
+    import torch
+    from autognothi_amd import engine, ops
+    engine.set_precision(precision)
+    recipe = c["recipe"]
+    srg, exp = c["surrogate"].to(dev), c["explainer"].to(dev)
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    null = torch.from_numpy(c["null"]).to(dev)
+    masks = torch.from_numpy(c["masks"]).to(dev)
+    ones1 = torch.ones((1, c["P"]), dtype=torch.long, device=dev)
+    onesb = torch.ones((c["B"], c["P"]), dtype=torch.long, device=dev)
+    with torch.no_grad():
+        v_0, _ = recipe.fw_surrogate(srg, null, ones1)
+        xin = xs if share_inputs else torch.repeat_interleave(xs, c["K"], dim=0)
+        v_s, _ = recipe.fw_surrogate(srg, xin, masks)
+        v_1, _ = recipe.fw_surrogate(srg, xs, onesb)
+        edge = torch.stack([torch.zeros(c["P"], dtype=torch.long), torch.ones(c["P"], dtype=torch.long)]).to(dev)
+        v_edge, _ = recipe.fw_surrogate(srg, xs[:1], edge)
+        g = c["g"]
+        phi, extra = recipe.fw_explainer(exp, xs, onesb, torch.from_numpy(g["v_1"]).to(dev), torch.from_numpy(g["v_0"]).to(dev))
+        bits = ops.pack_mask(masks)
+        loss, dphi = ops.shapley_loss(bits, torch.from_numpy(g["v_0"]).to(dev), torch.from_numpy(g["v_s"]).to(dev),
+                                      torch.from_numpy(g["phi"]).to(dev), c["B"], c["K"])
+    out = dict(v_0=v_0, v_s=v_s, v_1=v_1, v_edge=v_edge, phi=phi, loss=loss, dphi=dphi)
+    if extra is not None:
+        out["exp_logits"] = extra
+    return {k: v.float().cpu().numpy() for k, v in out.items()}
+
+
 def tie_split(attr, stop):
     """does a cut after the `stop` highest attributions fall INSIDE a group of equal values (top-`stop` set not unique)?"""
     v = np.sort(np.asarray(attr))[::-1]
