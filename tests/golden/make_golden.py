@@ -428,7 +428,10 @@ def gen_full_depth_bf16ref():
     reference user gets from stock mixed precision (bf16 matmul operands, fp32 LayerNorm / soft-max / residual adds).  Stored:
     its v_s / v_1 / phi, so that the bf16 tests and bench.py can state the HIP bf16 mode's deviation from the fp32 reference
     NEXT TO the reference's own bf16 deviation from itself."""
-    for tag, (recipe_fn, params, kind, K) in _full_depth_table().items():
+    table = dict(_full_depth_table())
+    if len(sys.argv) > 2 and sys.argv[2] == "ltt":
+        table = _ltt_full_params()
+    for tag, (recipe_fn, params, kind, K) in table.items():
         g = np.load(os.path.join(HERE, f"model_{tag}.npz"))
         recipe = recipe_fn()
         cfg = recipe.t_config(**params)
@@ -457,6 +460,67 @@ def gen_full_depth_bf16ref():
              phi_absmax=np.asarray([np.abs(g["phi"]).max()]))
         print(tag, "reference under autocast(bf16) vs its fp32 self: v_s max", e_vs.max(), "rms", np.sqrt((e_vs ** 2).mean()),
               "| v_1", np.abs(v_1_ac - g["v_1"]).max(), "| phi max", e_phi.max(), "=", e_phi.max() / np.abs(g["phi"]).max(), "of max|phi|")
+
+def _ltt_full_params():
+    """the shipped LTT shape (experiments/bert_base_tayp_ltt/.hparams.json: 12 layers, 96-wide ladder = 12 heads of 8, 384
+    intermediate) on BERT-base at L=128 (BASELINE's sequence length) and the same ladder on ViT-base (no shipped LTT ViT
+    experiment: the vanilla ViT-base backbone fields + the shipped ladder fields)."""
+    lbert = dict(hparams("bert_base_tayp_ltt"), max_position_embeddings=128)
+    base = hparams("vit_base_imagenette_vanilla")
+    lvit = {k: v for k, v in base.items() if not k.startswith("explainer_")}
+    lvit.update(explainer_s_attn_num_layers=1, explainer_s_head_hidden_size=3072, explainer_normalize=True,
+                s_attn_hidden_size=96, s_attn_intermediate_size=384)
+    return {"ltt_bert_base_l12": (r_lbert.ltt_bert_recipe, lbert, "bert", 32),
+            "ltt_vit_base_l12": (r_lvit.ltt_vit_recipe, lvit, "vit", 32)}
+
+
+def gen_ltt_full_depth():
+    """LTT at the shipped / benchmarked shape: 12 backbone layers, h = 96 ladder, K = 32, one input — the
+    shapes at which the ring GEMM with the ladder's map epilogue, the narrow-head MFMA attention at 6304 / 4096 rows and the
+    chained LayerNorm-fold statistics across the per-layer backbone calls are selected.  Besides the model fixture
+    (gen_model_fixture(ltt=True): v_0 / v_s / v_s_cls / v_1 / v_edge / phi / exp_logits / fin_logits / fin_phi) the ladder is
+    pinned at intermediate depths through the reference's own knob: ``ltt_freeze_layers_until(l)`` stops the side network after
+    l layers (models/ltt_vit.py:400-404, :424-426), so v_s under l = 1, 4, 8 is the head's view of the side state after l
+    layers — a per-layer side-state trace through the public interface."""
+    for tag, (recipe_fn, params, kind, K) in _ltt_full_params().items():
+        gen_model_fixture(tag, recipe_fn, params, kind, B=1, K=K, mask_seed=3407, ltt=True)
+        g = np.load(os.path.join(HERE, f"model_{tag}.npz"))
+        recipe = recipe_fn()
+        cfg = recipe.t_config(**params)
+        P = recipe.n_players(cfg)
+        m_srg = recipe.t_surrogate(cfg)
+        synth.load_synth_weights(m_srg, seed=0)
+        m_srg.eval()
+        if kind == "vit":
+            Xs = torch.from_numpy(synth.synth_images(1, params["img_px_size"], params["img_channels"], seed=0))
+        else:
+            Xs = torch.from_numpy(synth.synth_token_ids(1, params["max_position_embeddings"], params["vocab_size"], seed=0))
+        masks = torch.from_numpy(np.unpackbits(g["masks"], axis=-1)[:, :P].astype(np.int64))
+        out = {}
+        enc = (m_srg.vit if kind == "vit" else m_srg.bert).encoder
+        for l in (1, 4, 8):
+            enc.ltt_freeze_layers_until(l)
+            with torch.no_grad():
+                v_l, _ = recipe.fw_surrogate(m_srg, torch.repeat_interleave(Xs, K, dim=0), masks)
+            out[f"v_s_freeze{l}"] = v_l.numpy()
+        enc.ltt_freeze_layers_until(params["num_hidden_layers"])
+        save(f"model_{tag}_freeze.npz", **out)
+        # the reference's own fp32 rounding noise at this depth (its deviation from itself in float64): the yardstick of the
+        # fp32 comparison of phi, a small difference of pred-sized numbers (as gen_full_depth_aux does for the vanilla configs)
+        m_exp, m_fin = recipe.t_explainer(cfg), recipe.t_final(cfg)
+        synth.load_synth_weights(m_exp, seed=1)
+        synth.load_synth_weights(m_fin, seed=2)
+        m_srg.double().eval(); m_exp.double().eval(); m_fin.double().eval()
+        X64 = Xs.double() if kind == "vit" else Xs
+        ones = torch.ones((1, P), dtype=torch.long)
+        with torch.no_grad():
+            v_s64, _ = recipe.fw_surrogate(m_srg, torch.repeat_interleave(X64, K, dim=0), masks)
+            phi64 = recipe.fw_explainer(m_exp, X64, ones, torch.from_numpy(g["v_1"]).double(), torch.from_numpy(g["v_0"]).double())[0]
+            _, fin_phi64 = recipe.fw_final(m_fin, X64)
+        noise = dict(noise_v_s=np.asarray([np.abs(v_s64.numpy() - g["v_s"]).max()]), noise_phi=np.asarray([np.abs(phi64.numpy() - g["phi"]).max()]),
+                     noise_fin_phi=np.asarray([np.abs(fin_phi64.numpy() - g["fin_phi"]).max()]))
+        save(f"model_{tag}_aux.npz", **noise)
+        print(tag, "reference fp32 vs fp64:", {k_: float(v_[0]) for k_, v_ in noise.items()}, "| max|phi|", np.abs(g["phi"]).max())
 
 
 def gen_perturbed_ties():
@@ -620,9 +684,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
         gen_mc_shapley()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "full_depth_aux", "full_depth_bf16ref", "perturbed_ties", "train_step"):   # round-2 additions
+    if len(sys.argv) > 1 and sys.argv[1] in ("full_depth", "full_depth_aux", "full_depth_bf16ref", "ltt_full_depth", "perturbed_ties", "train_step"):   # round-2 additions
         {"full_depth": gen_full_depth, "full_depth_aux": gen_full_depth_aux, "perturbed_ties": gen_perturbed_ties,
-         "train_step": gen_train_step, "full_depth_bf16ref": gen_full_depth_bf16ref}[sys.argv[1]]()
+         "train_step": gen_train_step, "full_depth_bf16ref": gen_full_depth_bf16ref, "ltt_full_depth": gen_ltt_full_depth}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ltt":   # added after the first fixture set; leaves the others untouched
         gen_ltt_models()

@@ -106,7 +106,9 @@ def test_sharded_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
     exp.train()
     for q in params:
         q.grad = None
+    step0 = trainer.step                   # (the dropout streams are keyed on (seed, trainer.step): replay the same step below)
     loss, _ = trainer.loss_and_grads(xs4[:2], bits, v_0, v_s, v_1, k, labels=zs4[:2], train=True, seed=seed + epoch)
+    trainer.step = step0
     want_grad = [q.grad.clone() for q in params]
     before = [q.detach().clone() for q in params]
     # the epoch body as rank 0 of 2

@@ -39,6 +39,8 @@ MODEL_TAGS = ["vit_tiny_c1", "vit_base_l2", "vit_large_l2", "bert_base_l2", "duo
 
 
 LTT_TAGS = ["ltt_vit_tiny_l3", "ltt_bert_base_l2"]
+# the shipped ladder (h = 96: 12 heads of 8, 384 intermediate) on the 12-layer base backbones, K = 32, one input
+LTT_FULL_TAGS = ["ltt_bert_base_l12", "ltt_vit_base_l12"]
 
 # the shipped configs at their real depth and K, one input each (BASELINE configs 2-5)
 FULL_TAGS = ["vit_base_l12", "bert_base_l12", "vit_large_l24", "duo_bert_base_l12", "froyo_vit_base_l12"]
