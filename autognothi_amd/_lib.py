@@ -92,6 +92,7 @@ SIGNATURES = {
     "ag_masked_attention_bwd_mixed": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_mc_shapley_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ag_probe_mfma": (i32, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
+    "ag_probe_dma": (i32, [i32, i32, i32, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_profile_enable": (i32, [i32]),
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),

@@ -373,8 +373,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t ldsA_w = lds0 + wave * 2048, ldsW_w = ldsA_w + HALF_OP_BYTES;   // this wave's piece pair inside a slot
     auto refill4 = [&](int jn, int slot) {  // this wave's A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of half-step jn into ring slot `slot`
+#if defined(AG_EXP_PLAIN_LOADS)   // experiment (wrong results): the same four 1 KiB requests as plain loads into (dead) registers
+        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+        u32x4v d0, d1, d2, d3;
+        asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %9\n\tglobal_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %9"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                     : "v"(offA[0]), "v"(offW[0]), "v"(offA[1]), "v"(offW[1]), "s"(tileA + jn * HROWB), "s"(tileW + jn * HROWB) : "memory");
+#elif defined(AG_EXP_NO_DMA)
+        (void)jn; (void)slot;
+#elif defined(AG_EXP_DWORD_DMA)   // experiment (wrong results): the same four LDS-DMA instructions moving 4 B per lane instead of 16
+        {
+            uint32_t keep;
+            const uint32_t ldsA0 = ldsA_w + slot * SLOT_BYTES, ldsW0 = ldsW_w + slot * SLOT_BYTES;
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %2, %6\n\t"
+                         "s_add_u32 m0, %7, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, %5\n\t"
+                         "s_add_u32 m0, %8, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %4, %6\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(offA[0]), "v"(offW[0]), "v"(offA[1]), "v"(offW[1]), "s"(tileA + jn * HROWB), "s"(tileW + jn * HROWB),
+                           "s"(ldsA0), "s"(ldsW0) : "memory", "scc");
+        }
+#else
         glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
                      ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
+#endif
     };
     // ---- tile constants: requested BEFORE the ring's first fill (so that they are the oldest loads in flight) and parked in the
     // LDS tail once the prologue's counted wait has let them land; the epilogue then needs nothing from memory but the residual
@@ -475,11 +498,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
         const char* sA = smem + slot * SLOT_BYTES;
         const char* sW = sA + HALF_OP_BYTES;
         uint4 fw[4], fx[8];
+#if defined(AG_EXP_DMA_FIRST)     // experiment: the refills requested BEFORE the fragment reads of the phase
+        if (do_refill) refill4(j + 3, (slot + 3) & 3);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
+#if defined(AG_EXP_FEWER_READS)   // experiment (wrong results): 8 instead of 12 fragment reads per wave and half-step
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
+#pragma unroll
+        for (int s = 4; s < 8; ++s) fx[s] = fx[s - 4];
+#else
 #pragma unroll
         for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
+#endif
+#if defined(AG_EXP_HALF_DMA)      // experiment (wrong results): every other refill skipped
+        if (do_refill && (j & 1)) refill4(j + 3, (slot + 3) & 3);
+        else if (do_refill) { }
+#elif defined(AG_EXP_DMA_IN_MFMA) || defined(AG_EXP_DMA_FIRST)
+#else
         if (do_refill) refill4(j + 3, (slot + 3) & 3);                  // into the slot read one half-step ago
+#endif
         AG_STAMP(2)
         __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my fragments are in registers (the builtin,
         asm volatile("" ::: "memory");                                  // so hipcc does not add its own per-MFMA lgkmcnt waits)
@@ -493,12 +532,27 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
         // ---- MFMA phase: nothing but the 32 MFMAs (splitting the refills 2/2 across the phases measured slower) ----
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+#if defined(AG_EXP_DMA_IN_MFMA)   // experiment: the four LDS-DMA requests issued from inside the MFMA phase (after the 8th MFMA)
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm)
+                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
+                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
+            if (sn == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_refill) refill4(j + 3, (slot + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn)
 #pragma unroll
             for (int sm = 0; sm < 8; ++sm)
                 acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
                                                                       __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         AG_STAMP(5)

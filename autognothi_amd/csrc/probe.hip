@@ -101,6 +101,120 @@ __global__ __launch_bounds__(512, 2) void mfma_probe32_kernel(int iters, int zer
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+
+// ---- LDS-DMA feed probe: what the global -> LDS path of one CU sustains with nothing else running --------------------------
+// The ring GEMM moves 32 KiB per K=32 half-step and CU through 32 `global_load_lds_dwordx4` wave-instructions (16-row x 64-B
+// pieces of two row-major operands).  This kernel issues exactly those requests — same addressing, same 4-slot ring, same
+// counted vmcnt — from `waves` waves per workgroup (one workgroup per CU) and reports bytes per shader clock and CU.
+//   flags bit 0: one s_barrier per half-step (as the GEMM's slot hand-over); bit 1: every workgroup reads the SAME 256-row
+//   panels (L2-resident after the first touch) instead of its own (an HBM stream); bit 2: plain global_load_dwordx4 into
+//   registers instead of LDS-DMA.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dma_probe_kernel(const char* A, const char* W, long ld_b, int nh, int flags, int panels,
+                                                               unsigned long long* clocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int PER = 16 / WAVES;                     // pieces of each operand per wave and half-step
+    const int panel = (flags & 2) ? 0 : (int)(blockIdx.x % panels);
+    const int jmask = (flags & 8) ? 1 : 0x7FFFFFFF;    // bit 3: every workgroup re-reads ITS OWN two half-steps (64 KiB per CU: L2-resident, distinct lines per CU)
+    const char* tileA = A + (long)panel * 256 * ld_b;
+    const char* tileW = W + (long)(panel % 3) * 256 * ld_b;
+    // bit 4: pieces of 8 rows x 128 B (whole cache lines; a piece pair = the 16 rows of a K=64 step) instead of 16 rows x 64 B
+    const bool full_lines = flags & 16;
+    const int r_in = full_lines ? (lane >> 3) : (lane >> 2), chunk = full_lines ? (lane & 7) : (lane & 3);
+    uint32_t off[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        off[i] = full_lines ? (uint32_t)((((wave * PER + i) >> 1) * 16 + ((wave * PER + i) & 1) * 8 + r_in) * (int)ld_b + chunk * 16)
+                            : (uint32_t)(((wave * PER + i) * 16 + r_in) * (int)ld_b + chunk * 16);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned long long c0, c1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v sink = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < nh; ++j) {
+        const int slot = j & 3;
+        const char* a = tileA + (full_lines ? (long)((j & jmask) >> 1) * 128 + (long)(j & 1) * 128 * ld_b : (long)(j & jmask) * 64);
+        const char* w = ((flags & 8) ? tileA + 128 : tileW) + (full_lines ? (long)((j & jmask) >> 1) * 128 + (long)(j & 1) * 128 * ld_b : (long)(j & jmask) * 64);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t la = lds0 + slot * 32768 + (wave * PER + i) * 1024, lw = la + 16384;
+            if (flags & 4) {
+                u32x4v d0, d1;
+                asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %4" : "=&v"(d0), "=&v"(d1) : "v"(off[i]), "s"(a), "s"(w) : "memory");
+                sink ^= d0 ^ d1;    // (consumed only after the loop's waits: the xor below is ordered by the final vmcnt(0))
+            } else {
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                             "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(off[i]), "s"(a), "s"(w), "s"(la), "s"(lw) : "memory");
+            }
+        }
+        // leave the two newest half-steps of this wave in flight (the GEMM's counted wait)
+        if (PER == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (PER == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (flags & 1) asm volatile("s_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    if ((sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x12345678u) clocks[0] = 1;
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+}  // namespace
+
+extern "C" int ag_probe_dma(int waves, int half_steps, int flags, const void* d_A, const void* d_W, int64_t ld_bytes, int panels,
+                            double* bytes_per_clk_per_cu, double* gbytes_per_s, double* shader_ghz, void* stream) {
+    AG_REQUIRE((waves == 4 || waves == 8 || waves == 16) && half_steps > 0 && d_A && d_W && panels > 0 && bytes_per_clk_per_cu && gbytes_per_s && shader_ghz,
+               "ag_probe_dma: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    AG_HIP_CHECK(hipGetDevice(&dev));
+    AG_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    static AgKnob k_grid("AG_PROBE_GRID");      // (experiment: fewer workgroups than CUs — is the limit per CU or per L2?)
+    cus = (int)k_grid.get(cus);
+    unsigned long long* clocks = nullptr;
+    AG_HIP_CHECK(hipMalloc((void**)&clocks, sizeof(unsigned long long) * 2 * cus));
+    const int lds = 4 * 32768;
+    auto launch = [&]() {
+        if (waves == 4) hipLaunchKernelGGL(dma_probe_kernel<4>, dim3(cus), dim3(256), lds, s, (const char*)d_A, (const char*)d_W, (long)ld_bytes, half_steps, flags, panels, clocks);
+        else if (waves == 8) hipLaunchKernelGGL(dma_probe_kernel<8>, dim3(cus), dim3(512), lds, s, (const char*)d_A, (const char*)d_W, (long)ld_bytes, half_steps, flags, panels, clocks);
+        else hipLaunchKernelGGL(dma_probe_kernel<16>, dim3(cus), dim3(1024), lds, s, (const char*)d_A, (const char*)d_W, (long)ld_bytes, half_steps, flags, panels, clocks);
+    };
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dma_probe_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dma_probe_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dma_probe_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipEvent_t e0, e1;
+    AG_HIP_CHECK(hipEventCreate(&e0));
+    AG_HIP_CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) launch();
+    AG_HIP_CHECK(hipEventRecord(e0, s));
+    launch();
+    AG_HIP_CHECK(hipEventRecord(e1, s));
+    AG_HIP_CHECK(hipEventSynchronize(e1));
+    AG_LAUNCH_CHECK();
+    float ms = 0.f;
+    AG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(2 * cus);
+    AG_HIP_CHECK(hipMemcpy(h.data(), clocks, sizeof(unsigned long long) * 2 * cus, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    for (int i = 0; i < cus; ++i) { cyc += (double)h[2 * i]; real += (double)h[2 * i + 1]; }
+    const double bytes_wg = (double)half_steps * 32768.0;
+    *shader_ghz = real > 0 ? cyc / real * 0.1 : 0.0;
+    *bytes_per_clk_per_cu = bytes_wg / (cyc / cus);
+    *gbytes_per_s = bytes_wg * cus / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(clocks);
+    return AG_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream) {

@@ -402,6 +402,13 @@ int ag_reload_knobs(void);
  * Synchronous.  No reference counterpart. */
 int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream);
 
+/* Measurement aid: what the global -> LDS feed of one CU sustains when a workgroup issues nothing but the ring GEMM's staging requests
+ * (32 `global_load_lds_dwordx4` pieces of 16 rows x 64 B per K=32 half-step, 4-slot ring, counted vmcnt) from `waves` (4 / 8 / 16) waves.
+ * d_A: [panels*256, ld_bytes] bytes, d_W: [768, ld_bytes] bytes, half_steps <= ld_bytes / 64.  flags: bit 0 one s_barrier per half-step,
+ * bit 1 every workgroup reads the same (L2-resident) panels, bit 2 plain loads into registers instead of LDS-DMA.  Synchronous. */
+int ag_probe_dma(int waves, int half_steps, int flags, const void* d_A, const void* d_W, int64_t ld_bytes, int panels,
+                 double* bytes_per_clk_per_cu, double* gbytes_per_s, double* shader_ghz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["AG_GEMM_DBG"] = "/tmp/ag_dbg_ptr.txt"
 from autognothi_amd import _lib as L, ops
+if os.environ.get("GB_LIB"):
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ["GB_LIB"])
 dev = torch.device("cuda:0")
 M, N, K = 100864, 2304, int(os.environ.get("GB_K", 768))
 a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
