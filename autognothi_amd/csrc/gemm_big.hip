@@ -587,6 +587,390 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
 #undef AG_MARK
 }
 
+// =====================================================================================================================
+// gemm_line_kernel — the same tile, waves, phases and epilogue, fed by WHOLE 128-byte cache lines.
+//
+// What was measured (round 3, tools/dma_probe.py = ag_probe_dma, tools/exp_variants.sh): the ring above stages 16-row x 64-byte
+// pieces (K = 32 per half-step).  A 64-byte row segment is half a 128-byte line; the other half is requested one half-step
+// later, after 32 KiB of other lines have passed through the CU's 32 KiB vector L1, so EVERY line crosses the L2 -> L1 path
+// twice.  With all 256 CUs pulling, that path delivers 28 B/clk/CU of such pieces (a 32 KiB half-step = 1 170 cycles, more
+// than the 1 024 cycles its 256 MFMAs take: the kernel was feed-bound, and removing the loads altogether made it 33 % faster)
+// against 47 B/clk/CU for 8-row x 128-byte pieces (700 cycles).  So: K is walked in 64-element steps, a step image is
+// A[256 x 128 B] + W[256 x 128 B] = 64 KiB, a piece is 8 rows x 128 B (one line per row, each line requested once per CU),
+// the ring has two step slots (LDS: 128 KiB + the 5 KiB tail, as before).
+//   LDS image: row-major 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (applied on the SOURCE
+//   address of the LDS-DMA, whose destination is linear, and on the ds_read_b128): the 16 lanes of a fragment read (16 rows,
+//   one k-chunk) hit 16 different 16-byte bank groups.  Layout [A slot 0 | A slot 1 | W slot 0 | W slot 1] so that one base
+//   VGPR per operand and k-half reaches both slots through the 16-bit ds offset.
+//   Phases: unchanged (two wave groups half a phase apart, read phase / MFMA phase of 32 MFMAs, K = 32 per phase pair).
+//   Refills: step s+1 is requested during step s into the slot step s-1 was read from, i.e. less than one step ahead, so
+//   (1) the requests are placed by group so that every piece has at least one full phase to land: group 0's waves stage A, group
+//   1's stage W, eight pieces each; group 0 (which meets its next "a" barrier after an MFMA phase) requests four pieces in its
+//   read-lo and four in its read-hi phase and waits after its MFMA-hi phase; group 1 (which meets it after a read phase) requests
+//   all eight in read-lo and waits at the end of read-hi; per barrier interval the CU's texture-address unit sees 16 / 32 / 16 / 0
+//   pieces;
+//   (2) HBM latency is taken by a PREFETCH of the A stream (W stays L2-resident: every CU of an XCD re-reads the same few
+//   panels): one LDS-DMA dword per group-0 wave and step touches one dword of each of the wave's 64 A lines of step s+2,
+//   pulling them into the XCD's L2 a step before their pieces are requested; it lands in a 256-byte LDS sink (a register
+//   destination would be written asynchronously, after the compiler has re-used it) and is the youngest vector-memory
+//   operation of the wave when the step's pieces are waited for (vmcnt(1)).  Measured (M = 302 592, same box): sum of the four
+//   encoder GEMMs 4 230 us without, 4 105 us with it (fc2 1 279 -> 1 221 us); for both operands 4 262; distances 1 / 3 / 4: 4 301 /
+//   4 177 / 4 163.
+//   What did NOT work here, each built and measured: requests issued from inside the MFMA phases, spread one per eight MFMAs
+//   (+12 %: a vector-memory issue stalls the wave's MFMA issue for much longer than one MFMA's shadow); group 0 requesting all
+//   eight pieces in its first read phase for the longest lookahead (+8 %: 32 pieces in one barrier interval); the same number
+//   of pieces in every read phase (the last interval's pieces then have no time to land).
+constexpr int LROWB = 128;                       // bytes of K per row per step (64 bf16)
+constexpr int LOP_BYTES = BT * LROWB;            // 32 KiB per operand per step
+constexpr int LW_BASE = 2 * LOP_BYTES;           // W slots behind the two A slots
+// defaults = what measured best (round 3, tools/exp_variants.sh): L2 prefetch ON, for the A stream only (group 0), two steps ahead
+#if !defined(AG_LINE_NO_PF) && !defined(AG_LINE_PF)
+#define AG_LINE_PF
+#define AG_LINE_PF_A_ONLY
+#endif
+#ifndef AG_LINE_PF_AHEAD
+#define AG_LINE_PF_AHEAD 2
+#endif
+constexpr int PF_AHEAD = AG_LINE_PF_AHEAD;       // L2 prefetch distance in steps
+
+// four 1 KiB pieces of one operand (SGPR base + per-lane offsets) to four consecutive LDS kilobytes
+__device__ __forceinline__ void glds_x4(const char* base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t lds0) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, %6, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, %6, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, %6, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(lds0) : "memory", "scc");
+}
+// the same four pieces as two piece pairs: pieces 0, 1 from base0 and pieces 2, 3 from base1 (= 16 rows further), per-lane offsets o0 / o1
+__device__ __forceinline__ void glds_x4b(const char* base0, const char* base1, uint32_t o0, uint32_t o1, uint32_t lds0) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, %5, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_add_u32 m0, %5, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_add_u32 m0, %5, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base0), "s"(base1), "s"(lds0) : "memory", "scc");
+}
+// one piece (the wave-uniform operands are forced into SGPRs: behind a group-dependent branch the compiler no longer proves them uniform)
+__device__ __forceinline__ void glds_x1(const char* base_, uint32_t o, uint32_t lds_) {
+    const uint64_t bv = (uint64_t)(uintptr_t)base_;
+    const uint64_t bu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
+    const char* base = (const char*)(uintptr_t)bu;
+    const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o), "s"(base), "s"(lds) : "memory");
+}
+// touch one dword per lane (L2 prefetch of that lane's line).  The data must go SOMEWHERE: a plain load's destination VGPR would
+// be written whenever the load returns, long after the compiler has given that register to something else (first version of
+// this kernel: memory faults from clobbered address registers) — so it is an LDS-DMA into a 256-byte sink behind the tail.
+constexpr int PF_SINK = NSLOT * SLOT_BYTES + TAIL_BYTES;
+constexpr int LINE_LDS_BYTES = PF_SINK + 256;
+__device__ __forceinline__ void l2_touch(const char* base, uint32_t voff, uint32_t lds_sink) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_sink) : "memory");
+}
+
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
+    BigArgs p = pin;
+    p.M = ag_dyn_clamp(p.M, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = wave >> 2, gw = wave & 3;         // wave group (phase offset) and index inside it
+
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
+    const int nwg = tiles_m * tiles_n;
+    if ((int)blockIdx.x >= nwg) return;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    int tm, tn;
+    {   // tile order: as gemm_ring_kernel
+        const int ngrp = p.ngrp;
+        const int full = (tiles_n / ngrp) * ngrp * tiles_m;
+        if (wg < full) {
+            const int g = wg / (ngrp * tiles_m), rem = wg - g * (ngrp * tiles_m);
+            tm = rem / ngrp; tn = g * ngrp + rem % ngrp;
+        } else {
+            const int w = tiles_n % ngrp, rem = wg - full;
+            tm = rem / w; tn = (tiles_n / ngrp) * ngrp + rem % w;
+        }
+    }
+    const int m0 = tm * BT, n0 = tn * BT;
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int ns = p.K / 64;                          // steps
+    const char* tileA = p.A + (long)m0 * p.lda_b;
+    const char* tileW = p.W + (long)n0 * p.ldw_b;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // ---- this wave's pieces: group 0 (waves 0-3) stages A, group 1 (waves 4-7) stages W; wave g of a group owns rows
+    // [64 g, 64 g + 64) of its operand = 8 pieces of 8 rows.  Piece q = 2 k + par: rows 64 g + 16 k + 8 par + (lane >> 3); its
+    // per-lane source offset is vb[par] + k * 16 rows, so two loop-invariant VGPRs serve all eight pieces (the register budget
+    // of this kernel is what decides its structure: 128 accumulators + 48 fragment registers of 256, and a single spilled value
+    // inside the loop would make hipcc drain the hand-counted LDS-DMA queue with a vmcnt(0) of its own).  Rows past the matrix
+    // edge are clamped to the last valid row by a v_min against `off_max`.
+    const char* const tileX = grp == 0 ? tileA : tileW;
+    const int ldx = grp == 0 ? (int)p.lda_b : (int)p.ldw_b;
+    const int vrows = grp == 0 ? min(BT, p.M - m0) : min(BT, p.N - n0);           // valid rows of this tile's operand
+    const uint32_t off_max = (uint32_t)((vrows - 1) * ldx + 112);
+    const uint32_t d16 = (uint32_t)(16 * ldx);
+    uint32_t vb[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = gw * 64 + par * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);               // source chunk that lands at linear position lane & 7
+        vb[par] = (uint32_t)(row * ldx + ch * 16);
+    }
+    const uint32_t ldsX_w = lds0 + (grp == 0 ? 0 : LW_BASE) + gw * 8192;         // + slot * LOP_BYTES
+    // pieces 4 h .. 4 h + 3 (h = 0, 1) of step `step` into ring slot `slot`.  Interior tiles (all 256 rows valid): the 16-row
+    // advance of a piece pair goes into the SGPR base (scalar adds), the two loop-invariant per-lane offsets are used as they
+    // are: no vector instruction on the request path.  Edge tiles: per-lane offsets made and clamped here.
+    const bool edge = vrows < BT;
+    auto refill4 = [&](int step, int slot, int h) {
+        const uint32_t lds = ldsX_w + slot * LOP_BYTES + h * 4096;
+        if (!edge) {
+            const char* b0 = tileX + (long)step * LROWB + (long)(2 * h) * d16;
+            glds_x4b(b0, b0 + d16, vb[0], vb[1], lds);
+        } else {
+            uint32_t d = d16, om = off_max;
+            asm volatile("" : "+s"(d), "+s"(om));   // (made here, four short-lived temporaries: not hoisted into registers that do not exist)
+            uint32_t o0 = vb[0] + (2 * h) * d, o1 = vb[1] + (2 * h) * d, o2 = vb[0] + (2 * h + 1) * d, o3 = vb[1] + (2 * h + 1) * d;
+            o0 = min(o0, om); o1 = min(o1, om); o2 = min(o2, om); o3 = min(o3, om);      // rows past the edge -> the last valid row
+            glds_x4(tileX + (long)step * LROWB, o0, o1, o2, o3, lds);
+        }
+    };
+    // piece q (0..7) of step `step` into ring slot `slot`, by itself (issued between MFMAs)
+    auto piece1 = [&](int step, int slot, int q) {
+        const uint32_t lds = ldsX_w + slot * LOP_BYTES + q * 1024;
+        if (!edge) {
+            glds_x1(tileX + (long)step * LROWB + (long)(q >> 1) * d16, vb[q & 1], lds);
+        } else {
+            uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d16), om = (uint32_t)__builtin_amdgcn_readfirstlane((int)off_max);
+            asm volatile("" : "+s"(d), "+s"(om));
+            glds_x1(tileX + (long)step * LROWB, min(vb[q & 1] + (q >> 1) * d, om), lds);
+        }
+    };
+    // L2 prefetch: lane l of wave g touches the line of row 64 g + l of the wave's operand
+    auto prefetch = [&](int step) {
+        if (step < ns) {
+            int lx = ldx;
+            uint32_t om = off_max - 112u, ones = ~0u;
+            asm volatile("" : "+s"(lx), "+s"(om), "+s"(ones));
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));   // lane id, re-made here: no live register
+            const uint32_t po = min((uint32_t)((gw * 64 + ln) * lx), om);
+            l2_touch(tileX + (long)step * LROWB, po, lds0 + PF_SINK);
+        }
+    };
+    // fragment read addresses: row r = lane & 15, k-chunk c = lane >> 4 (+ 4 for the upper K half = ^ 64 bytes after the swizzle)
+    const int fr = lane & 15, fc = lane >> 4;
+    const uint32_t frag_lo = (uint32_t)(fr * LROWB + ((fc ^ ((fr >> 1) & 7)) << 4));
+    uint32_t vA = lds0 + frag_lo + wm * (128 * LROWB), vW = lds0 + frag_lo + LW_BASE + wn * (64 * LROWB);
+    // (opaque to the optimiser: otherwise it re-associates LW_BASE with the slot offset into constants beyond the 16-bit ds offset
+    // field and keeps a separate address register per fragment)
+    asm volatile("" : "+v"(vA), "+v"(vW));
+
+    // ---- tile constants (as gemm_ring_kernel): requested first, parked in the LDS tail once the prologue's wait has let them land
+    constexpr bool ROWST = (VAR == 1 || VAR == 3);
+    float c_a = 0.f, c_b = 0.f;
+    f32x2v_t c_st[4] = {f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}, f32x2v_t{0.f, 0.f}};
+    {
+        int n = n0 + (tid & 255);
+        n = n < p.N ? n : p.N - 1;
+        if (tid < 256) {
+            if (p.bias) c_a = gload_f32_async(p.bias + n);
+            if (VAR == 3) c_b = gload_f32_async(p.rln_b + n);
+        } else {
+            if (VAR == 1) c_a = gload_f32_async(p.ln_s + n);
+            if (VAR == 3) c_a = gload_f32_async(p.rln_g + n);
+        }
+        if (ROWST && lane < 32) {
+            int m = m0 + wm * 128 + wn * 32 + lane;
+            m = m < p.M ? m : p.M - 1;
+            const float* sp = p.ln_stats + 2 * (long)m;
+#pragma unroll
+            for (int s_i = 0; s_i < 4; ++s_i) c_st[s_i] = gload_f32x2_async(sp + (s_i < p.ln_nslab ? s_i : 0) * p.stats_slab);
+        }
+    }
+    // ---- prologue: L2 prefetch of step 2, then steps 0 and 1 into slots 0 and 1
+#if defined(AG_LINE_PF)
+#if defined(AG_LINE_PF_A_ONLY)
+    if (grp == 0) prefetch(2);
+#else
+    prefetch(2);
+#endif
+#endif
+    refill4(0, 0, 0); refill4(0, 0, 1);
+    refill4(1, 1, 0); refill4(1, 1, 1);                 // (ns >= 2)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    {   // everything older than step 0's pieces has landed too: the tile constants -> LDS tail
+        gload_landed(c_a); gload_landed(c_b);
+        char* const tail = smem + NSLOT * SLOT_BYTES;
+        if (tid < 256) {
+            *reinterpret_cast<float*>(tail + TAIL_C0 + (tid & 255) * 4) = c_a;
+            if (VAR == 3) *reinterpret_cast<float*>(tail + TAIL_C2 + (tid & 255) * 4) = c_b;
+        } else if (VAR == 1 || VAR == 3) {
+            *reinterpret_cast<float*>(tail + TAIL_C1 + (tid & 255) * 4) = c_a;
+        }
+        if (ROWST) {
+#pragma unroll
+            for (int s_i = 0; s_i < 4; ++s_i) gload_landed(c_st[s_i]);
+            if (lane < 32) {
+                float sx = c_st[0].x, sq = c_st[0].y;
+#pragma unroll
+                for (int s_i = 1; s_i < 4; ++s_i) {
+                    sx += s_i < p.ln_nslab ? c_st[s_i].x : 0.f; sq += s_i < p.ln_nslab ? c_st[s_i].y : 0.f;
+                }
+                if (p.ln_nslab > 4) {
+                    int m = m0 + wm * 128 + wn * 32 + lane;
+                    m = m < p.M ? m : p.M - 1;
+                    for (int s_i = 4; s_i < p.ln_nslab; ++s_i) {
+                        const float2 w = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m + s_i * p.stats_slab);
+                        sx += w.x; sq += w.y;
+                    }
+                }
+                const float mean = sx * p.ln_inv_h;
+                const float rstd = rsqrtf(fmaxf(sq * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
+                *reinterpret_cast<float2*>(tail + TAIL_STAT + (wm * 128 + wn * 32 + lane) * 8) = make_float2(mean, rstd);
+            }
+        }
+    }
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");
+
+    // one K = 32 half of step `s` (KH = 0 lower / 1 upper K half) from ring slot SLOT.  What is requested / waited for in it
+    // depends on the group and the half (see the header); all of SLOT, KH, REFILL are literals at the call sites.
+    auto half = [&](const int s, const int slot, const int kh, const bool refill) {
+        asm volatile("s_barrier" ::: "memory");                        // "a"
+        // requests first (their address temporaries die before the fragments arrive): group 0 four pieces in each half, group 1 all
+        // eight in the lower half
+#if !defined(AG_LINE_NO_REFILL) && !defined(AG_LINE_ISSUE_IN_MFMA)
+        if (refill) {
+#if defined(AG_LINE_SYMMETRIC)      // experiment: both groups request four pieces in each half
+            refill4(s + 1, slot ^ 1, kh);
+#else
+#if defined(AG_LINE_G0_EARLY)       // experiment: group 0 (the A stream: HBM latency) requests all eight pieces in its read-lo phase too
+            if (kh == 0) { refill4(s + 1, slot ^ 1, 0); refill4(s + 1, slot ^ 1, 1); }
+#else
+            if (grp == 0) refill4(s + 1, slot ^ 1, kh);
+            else if (kh == 0) { refill4(s + 1, slot ^ 1, 0); refill4(s + 1, slot ^ 1, 1); }
+#endif
+#endif
+        }
+#endif
+#if defined(AG_LINE_PF)           // (L2 prefetch; for both operands it cost more than it gave: A only by default)
+#if defined(AG_LINE_PF_A_ONLY)
+        if (kh == 1 && grp == 0) prefetch(s + PF_AHEAD);
+#else
+        if (kh == 1) prefetch(s + PF_AHEAD);
+#endif
+#endif
+        uint32_t x64 = kh ? 64u : 0u;
+        asm volatile("" : "+s"(x64));                                  // (made here, two temporaries: not hoisted into two more registers)
+        typedef __attribute__((address_space(3))) const char* lds_cptr;
+        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const u32x4v* lds_u4ptr;
+        const lds_cptr pa = (lds_cptr)(uintptr_t)(vA ^ x64) + slot * LOP_BYTES;      // (an LDS address is the byte offset itself)
+        const lds_cptr pw = (lds_cptr)(uintptr_t)(vW ^ x64) + slot * LOP_BYTES;
+        u32x4v fw[4], fx[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = *(lds_u4ptr)(pw + i * (16 * LROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fx[i] = *(lds_u4ptr)(pa + i * (16 * LROWB));
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        // group 1 meets the barrier that opens step s+1 at the end of THIS read phase (upper half): its pieces of step s+1
+        // (requested two phases ago) must have landed; the prefetch just issued stays in flight
+#if defined(AG_LINE_PF) && !defined(AG_LINE_PF_A_ONLY)
+        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#else
+        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        asm volatile("s_barrier" ::: "memory");                        // "b"
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#if defined(AG_LINE_ISSUE_IN_MFMA)
+        // experiment: the requests are issued from inside the MFMA phases, spread out (one or two after every eight MFMAs), where the
+        // texture-address unit is not shared with another wave's burst and an issue slot costs about one MFMA's shadow:
+        //   group 0 (A): all eight pieces of step s+1 in its MFMA-lo phase (barrier interval 2 of step s);
+        //   group 1 (W): pieces 4..7 of step s+1 in its MFMA-lo phase (interval 3), pieces 0..3 of step s+2 in its MFMA-hi phase
+        //   (interval 1 of step s+1), into the slot both groups have just finished reading.
+        const bool g0_issue = grp == 0 && kh == 0 && refill;
+        const bool g1_issue_lo = grp == 1 && kh == 0 && refill;
+        const bool g1_issue_hi = grp == 1 && kh == 1 && s + 2 < ns;
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm)
+                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
+                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g0_issue) { piece1(s + 1, slot ^ 1, 2 * sn); piece1(s + 1, slot ^ 1, 2 * sn + 1); }
+            if (g1_issue_lo) piece1(s + 1, slot ^ 1, 4 + sn);
+            if (g1_issue_hi) piece1(s + 2, slot, sn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn)
+#pragma unroll
+            for (int sm = 0; sm < 8; ++sm)
+                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
+                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 0 meets that barrier after this MFMA phase (upper half): its 8 pieces of step s+1 had at least a phase to land
+#if defined(AG_LINE_PF)
+        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#else
+        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    };
+    auto step = [&](const int s, const int slot, const bool refill) {
+        half(s, slot, 0, refill);
+        half(s, slot, 1, refill);
+    };
+    // ns is even (K % 128 == 0: the launcher's condition), so the walk is straight-line code around one loop — no branch joins
+    // with the 128 accumulator registers live, which is what lets the register allocator keep them in place
+    step(0, 0, false);                                                 // the prologue requested step 1 already
+    int s = 1;
+    for (; s + 1 < ns; s += 2) {                                       // steps 1 .. ns-2: each has a successor to request
+        step(s, 1, true);
+        step(s + 1, 0, true);
+    }
+    step(s, 1, false);                                                 // s == ns - 1
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
+}
+
+template <int EPI, int VAR>
+int launch_line_var(const BigArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_line_kernel<EPI, VAR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LINE_LDS_BYTES);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_line): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    hipLaunchKernelGGL((gemm_line_kernel<EPI, VAR>), dim3(tiles), dim3(NT), LINE_LDS_BYTES, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 template <int EPI, int VAR>
 int launch_ring_var(const BigArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -596,6 +980,9 @@ int launch_ring_var(const BigArgs& a, hipStream_t s) {
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_ring): %s", hipGetErrorString(e));
         attr_set = true;
     }
+    // whole-line staging (K = 64 steps, gemm_line_kernel) wherever K allows; AG_GEMM_LINE=0 keeps the K = 32 ring (A/B, parity tests)
+    static AgKnob k_line("AG_GEMM_LINE");
+    if (a.K % 128 == 0 && (int)k_line.get(1) != 0) return launch_line_var<EPI, VAR>(a, s);
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
