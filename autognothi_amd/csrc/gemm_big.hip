@@ -712,8 +712,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K / 64;                          // steps
+#if defined(AG_LINE_HOT)          // experiment (wrong results): every tile stages the SAME panels (always L2 hits): latency vs issue cost
+    const char* tileA = p.A;
+    const char* tileW = p.W;
+#else
     const char* tileA = p.A + (long)m0 * p.lda_b;
     const char* tileW = p.W + (long)n0 * p.ldw_b;
+#endif
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // ---- this wave's pieces: group 0 (waves 0-3) stages A, group 1 (waves 4-7) stages W; wave g of a group owns rows
     // [64 g, 64 g + 64) of its operand = 8 pieces of 8 rows.  Piece q = 2 k + par: rows 64 g + 16 k + 8 par + (lane >> 3); its

@@ -349,3 +349,43 @@ def test_ring_random_shapes_all_variants(cuda_device, m, n, k):
     np.testing.assert_allclose(h2n, ref + ln, **TOL)
     got2 = ops.reduce_row_stats(st2, m, n).cpu().numpy()
     np.testing.assert_allclose(got2[:, 0], h2n.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
+
+
+@pytest.mark.parametrize("m,n,k", [(1300, 2056, 768), (2048, 768, 3072), (1537, 776, 1024), (4096, 2304, 128)])
+def test_whole_line_kernel_equals_the_k32_ring_bit_for_bit(cuda_device, ag_knobs, m, n, k):
+    """gemm_line_kernel (K % 128 == 0: whole-line pieces, K = 64 steps, round 3) and gemm_ring_kernel (K = 32 half-steps) feed the
+    same MFMAs the same fragments in the same order: every epilogue must give bit-identical outputs and row statistics — ragged M / N
+    edge tiles (clamped request rows), LayerNorm-fold consumer, statistics producer, residual-LayerNorm variant."""
+    from autognothi_amd import _lib as L, ops
+    g, a, w, b, ref = _case(m, n, k, 7)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    R = _dev(_r(g.standard_normal((m, n)).astype(np.float32)), dev)
+    st_in = ops.row_stats(A) if k <= 1024 else None
+    colsum = W.float().sum(1).contiguous()
+    gam, bet = torch.from_numpy((1 + 0.1 * g.standard_normal(n)).astype(np.float32)).to(dev), torch.from_numpy((0.1 * g.standard_normal(n)).astype(np.float32)).to(dev)
+    r_st = ops.row_stats(R) if n % 8 == 0 and n <= 1024 else None
+
+    def run_all():
+        out = {}
+        out["bias"] = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16)
+        out["gelu"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16)
+        out["f32"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_F32, BF16)
+        st = ops.new_row_stats(m, n, dev)
+        out["resid"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=R, stats_out=st)
+        out["resid_stats"] = st
+        if st_in is not None:
+            out["fold"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st_in, ln_colsum=colsum, ln_eps=1e-12)
+        if r_st is not None:
+            o, s2 = ops.gemm_resid_ln(A, W, B, R, r_st, gam, bet, 1e-12)
+            out["rln"], out["rln_stats"] = o, s2
+        return out
+
+    ag_knobs(AG_GEMM_LINE=1)
+    line = run_all()
+    ag_knobs(AG_GEMM_LINE=0)
+    ring = run_all()
+    assert set(line) == set(ring)
+    for key in line:
+        assert torch.equal(line[key], ring[key]), key
+    np.testing.assert_allclose(line["bias"].float().cpu().numpy(), ref, **TOL)
