@@ -93,6 +93,7 @@ SIGNATURES = {
     "ag_mc_shapley_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ag_probe_mfma": (i32, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_probe_dma": (i32, [i32, i32, i32, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
+    "ag_probe_store": (i32, [i32, i32, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_profile_enable": (i32, [i32]),
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),

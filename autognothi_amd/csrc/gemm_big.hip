@@ -704,6 +704,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         }
     }
     const int m0 = tm * BT, n0 = tn * BT;
+    if (p.dbg && tid == 0) {      // timeline diagnostic (AG_GEMM_DBG, tools/gemm_timeline.py): workgroup start, 100 MHz clock + hardware id
+        unsigned long long t_; uint32_t hw_;
+        asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw_)::"memory");
+        p.dbg[8 * (long)b + 0] = t_; p.dbg[8 * (long)b + 3] = hw_;
+    }
 
     f32x4_t acc[4][8];
 #pragma unroll
@@ -770,7 +775,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
     };
     // L2 prefetch: lane l of wave g touches the line of row 64 g + l of the wave's operand
     auto prefetch = [&](int step) {
-        if (step < ns) {
+        {   // past the last step: the last step's lines again (an L2 hit) — the waits below COUNT this request (vmcnt(1))
+            step = step < ns ? step : ns - 1;
             int lx = ldx;
             uint32_t om = off_max - 112u, ones = ~0u;
             asm volatile("" : "+s"(lx), "+s"(om), "+s"(ones));
@@ -856,7 +862,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
 
     // one K = 32 half of step `s` (KH = 0 lower / 1 upper K half) from ring slot SLOT.  What is requested / waited for in it
     // depends on the group and the half (see the header); all of SLOT, KH, REFILL are literals at the call sites.
-    auto half = [&](const int s, const int slot, const int kh, const bool refill) {
+    auto half = [&](const int s, const int slot, const int kh, const bool refill, const bool last) {
         asm volatile("s_barrier" ::: "memory");                        // "a"
         // requests first (their address temporaries die before the fragments arrive): group 0 four pieces in each half, group 1 all
         // eight in the lower half
@@ -876,9 +882,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
 #endif
 #if defined(AG_LINE_PF)           // (L2 prefetch; for both operands it cost more than it gave: A only by default)
 #if defined(AG_LINE_PF_A_ONLY)
-        if (kh == 1 && stA) prefetch(s + PF_AHEAD);
+        if (kh == 1 && stA && !last) prefetch(s + PF_AHEAD);
 #else
-        if (kh == 1) prefetch(s + PF_AHEAD);
+        if (kh == 1 && !last) prefetch(s + PF_AHEAD);
 #endif
 #endif
         uint32_t x64 = kh ? 64u : 0u;
@@ -900,7 +906,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
 #if defined(AG_LINE_PF) && !defined(AG_LINE_PF_A_ONLY)
         if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #else
-        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (grp == 1 && kh == 1 && !last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (last step: nothing was requested)
 #endif
         asm volatile("s_barrier" ::: "memory");                        // "b"
         __builtin_amdgcn_sched_barrier(0);
@@ -938,28 +944,37 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         __builtin_amdgcn_sched_barrier(0);
         // group 0 meets that barrier after this MFMA phase (upper half): its 8 pieces of step s+1 had at least a phase to land
 #if defined(AG_LINE_PF)
-        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (grp == 0 && kh == 1 && !last) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #else
         if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     };
-    auto step = [&](const int s, const int slot, const bool refill) {
-        half(s, slot, 0, refill);
-        half(s, slot, 1, refill);
+    auto step = [&](const int s, const int slot, const bool refill, const bool last) {
+        half(s, slot, 0, refill, last);
+        half(s, slot, 1, refill, last);
     };
     // ns is even (K % 128 == 0: the launcher's condition), so the walk is straight-line code around one loop — no branch joins
     // with the 128 accumulator registers live, which is what lets the register allocator keep them in place
-    step(0, 0, false);                                                 // the prologue requested step 1 already
+    if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)b + 4] = t_; }
+    step(0, 0, false, false);                                          // the prologue requested step 1 already
     int s = 1;
     for (; s + 1 < ns; s += 2) {                                       // steps 1 .. ns-2: each has a successor to request
-        step(s, 1, true);
-        step(s + 1, 0, true);
+        step(s, 1, true, false);
+        step(s + 1, 0, true, false);
     }
-    step(s, 1, false);                                                 // s == ns - 1
+    step(s, 1, false, true);                                           // s == ns - 1: nothing left to request or to wait for
+    if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)b + 5] = t_; }
     if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3>(p, acc, m0 + wm * 128, n0 + wn * 64, smem + wave * 16384, lane, smem, tn);
+    if (p.dbg) {                  // timeline diagnostic: epilogue issued / this wave's stores acknowledged (waves 0 and 7)
+        unsigned long long t1, t2;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+        if (tid == 0) { p.dbg[8 * (long)b + 1] = t1; p.dbg[8 * (long)b + 2] = t2; }
+    }
 }
 
 template <int EPI, int VAR>
@@ -1055,8 +1070,9 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
     static AgKnob k_dbg("AG_GEMM_DBG");
     if (k_dbg.is_set()) {  // diagnostic build: stamps into a lazily allocated device buffer (never in production)
         static unsigned long long* dbuf = nullptr;
-        if (!dbuf) { (void)hipMalloc((void**)&dbuf, 2 * 8 * 128 * 8 * sizeof(unsigned long long)); }
-        a.dbg = dbuf;
+        constexpr int DBG_WGS = 32768;      // 8 stamps per workgroup (gemm_line_kernel's timeline); larger launches go unstamped
+        if (!dbuf) { (void)hipMalloc((void**)&dbuf, 8L * DBG_WGS * sizeof(unsigned long long)); }
+        if (ceil_div(M, BT) * ceil_div(N, BT) <= DBG_WGS) a.dbg = dbuf;
         FILE* f = fopen(k_dbg.str, "w");
         if (f) { fprintf(f, "%p\n", (void*)dbuf); fclose(f); }
     }

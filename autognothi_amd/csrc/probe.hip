@@ -163,6 +163,93 @@ __global__ __launch_bounds__(WAVES * 64) void dma_probe_kernel(const char* A, co
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+
+// ---- store probe: what the output path of one CU sustains for the GEMM epilogue's store shapes ------------------------------
+// Every workgroup (8 waves) writes `tiles` 256 x 256 bf16 tiles (128 KiB each) of a row-major [rows, ld] matrix, nothing else.
+//   shape 0: the ring GEMM's epilogue: a wave owns a 64-column strip; one store = 8 rows x 128 B (8 lanes x 16 B per row)
+//   shape 1: a wave owns 32 whole tile rows; one store = 2 rows x 512 B (32 lanes x 16 B per row)
+//   shape 2: as 0 with 4 rows x 256 B (a wave owns a 128-column strip)
+//   flags bit 0: non-temporal stores
+__global__ __launch_bounds__(512) void store_probe_kernel(char* C, long ld_b, int tiles_per_wg, int tiles_n, int shape, int flags,
+                                                          unsigned long long* clocks) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 val = {0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + wave};
+    unsigned long long c0, c1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        const int tile = blockIdx.x + t * gridDim.x;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        char* base = C + (long)tm * 256 * ld_b + (long)tn * 512;
+        if (shape == 0) {            // wave (wm, wn): rows wm*128 .. +128, byte columns wn*128 .. +128; 16 stores of 8 rows
+            const int wm = wave >> 2, wn = wave & 3;
+            char* p0 = base + (long)(wm * 128 + (lane >> 3)) * ld_b + wn * 128 + (lane & 7) * 16;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                u32x4* dst = reinterpret_cast<u32x4*>(p0 + (long)i * 8 * ld_b);
+                if (flags & 1) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
+        } else if (shape == 1) {     // wave w: rows w*32 .. +32, all 512 bytes; 16 stores of 2 rows
+            char* p0 = base + (long)(wave * 32 + (lane >> 5)) * ld_b + (lane & 31) * 16;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                u32x4* dst = reinterpret_cast<u32x4*>(p0 + (long)i * 2 * ld_b);
+                if (flags & 1) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
+        } else {                     // wave (wm 0..3, wn 0..1): rows wm*64 .. +64, byte columns wn*256 .. +256; 16 stores of 4 rows
+            const int wm = wave >> 1, wn = wave & 1;
+            char* p0 = base + (long)(wm * 64 + (lane >> 4)) * ld_b + wn * 256 + (lane & 15) * 16;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                u32x4* dst = reinterpret_cast<u32x4*>(p0 + (long)i * 4 * ld_b);
+                if (flags & 1) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = c1 - c0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+}  // namespace
+
+extern "C" int ag_probe_store(int shape, int flags, void* d_C, int64_t ld_bytes, int rows, int grid, double* bytes_per_clk_per_cu,
+                              double* gbytes_per_s, void* stream) {
+    AG_REQUIRE(d_C && bytes_per_clk_per_cu && gbytes_per_s && shape >= 0 && shape <= 2 && ld_bytes % 512 == 0 && rows % 256 == 0 && grid > 0,
+               "ag_probe_store: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_n = (int)(ld_bytes / 512), tiles = (rows / 256) * tiles_n;
+    const int per_wg = tiles / grid;
+    AG_REQUIRE(per_wg >= 1, "ag_probe_store: fewer tiles than workgroups");
+    unsigned long long* clocks = nullptr;
+    AG_HIP_CHECK(hipMalloc((void**)&clocks, sizeof(unsigned long long) * 2 * grid));
+    hipEvent_t e0, e1;
+    AG_HIP_CHECK(hipEventCreate(&e0));
+    AG_HIP_CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep)
+        hipLaunchKernelGGL(store_probe_kernel, dim3(grid), dim3(512), 0, s, (char*)d_C, (long)ld_bytes, per_wg, tiles_n, shape, flags, clocks);
+    AG_HIP_CHECK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(store_probe_kernel, dim3(grid), dim3(512), 0, s, (char*)d_C, (long)ld_bytes, per_wg, tiles_n, shape, flags, clocks);
+    AG_HIP_CHECK(hipEventRecord(e1, s));
+    AG_HIP_CHECK(hipEventSynchronize(e1));
+    AG_LAUNCH_CHECK();
+    float ms = 0.f;
+    AG_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(2 * grid);
+    AG_HIP_CHECK(hipMemcpy(h.data(), clocks, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    double cyc = 0;
+    for (int i = 0; i < grid; ++i) cyc += (double)h[2 * i];
+    const double bytes_wg = (double)per_wg * 131072.0;
+    *bytes_per_clk_per_cu = bytes_wg / (cyc / grid);
+    *gbytes_per_s = bytes_wg * grid / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(clocks);
+    return AG_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int ag_probe_dma(int waves, int half_steps, int flags, const void* d_A, const void* d_W, int64_t ld_bytes, int panels,

@@ -409,6 +409,12 @@ int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_g
 int ag_probe_dma(int waves, int half_steps, int flags, const void* d_A, const void* d_W, int64_t ld_bytes, int panels,
                  double* bytes_per_clk_per_cu, double* gbytes_per_s, double* shader_ghz, void* stream);
 
+/* Measurement aid: what the output path of a CU sustains for 256 x 256 bf16 output tiles of a row-major [rows, ld_bytes / 2] matrix written by
+ * `grid` 8-wave workgroups and nothing else.  shape 0: 8 rows x 128 B per store instruction (the large-M GEMM's epilogue: a wave owns a
+ * 64-column strip), 1: 2 rows x 512 B, 2: 4 rows x 256 B; flags bit 0: non-temporal stores.  Synchronous. */
+int ag_probe_store(int shape, int flags, void* d_C, int64_t ld_bytes, int rows, int grid, double* bytes_per_clk_per_cu, double* gbytes_per_s,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
