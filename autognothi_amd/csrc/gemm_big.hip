@@ -140,20 +140,26 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
 // requested up front in one batch and the residual rows are prefetched one 16-row block ahead: the epilogue
 // runs with the matrix cores idle, so every exposed L2 round trip in it is paid in full.
 // Out-of-range rows / columns are clamped for the loads and masked at the stores; no divergent branches.
-template <int EPI, bool LNF, bool STATS, bool RLN = false>
+template <int EPI, bool LNF, bool STATS, bool RLN = false, int LAYOUT = 0>
 __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
-                                              char* stg, const int lane, const char* smem_base, const int tile_n) {
+                                              char* stg, const int lane, const char* smem_base, const int tile_n,
+                                              const char* tail_at = nullptr) {
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
     constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
     constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
-    constexpr int STAT_OFF = 8192;  // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its 16 KB
+    // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its LDS piece.  LAYOUT 0: 16 KiB per wave from
+    // the start of the ring; LAYOUT 1 (gemm_stream_kernel: step slot 0 already holds the NEXT tile's first step image): 8 KiB per
+    // wave in step slot 1 — waves 0-3 in the A half (32 KiB ..), waves 4-7 in the W half (96 KiB ..)
+    constexpr int STAT_OFF = LAYOUT ? 4608 : 8192;
+    constexpr int WPIECE = LAYOUT ? 8192 : 16384, GPIECE = LAYOUT ? 65536 : 65536, GBASE = LAYOUT ? 32768 : 0;
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
 
     // ---- row and column constants: parked in the LDS tail by the kernel's prologue (tile_constants_*) ----
-    const char* const tail = smem_base + NSLOT * SLOT_BYTES;
+    const char* const tail = tail_at ? tail_at : smem_base + NSLOT * SLOT_BYTES;   // (gemm_stream_kernel alternates between two tails)
     const float2* const stat_lds = reinterpret_cast<const float2*>(tail + TAIL_STAT);
-    const int wave_id = (int)((stg - smem_base) >> 14);
+    const int stg_off = (int)(stg - smem_base) - GBASE;
+    const int wave_id = (stg_off / GPIECE) * 4 + (stg_off % GPIECE) / WPIECE;
     constexpr bool ROWST = LNF || RLN;   // this tile's rows need (mean, rstd): of the A rows (fold) or of the residual rows
     float4 bv[4], sv[4];
     float4 gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
@@ -293,11 +299,11 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         const int wave = wave_id, wn = wave & 3;
         if (lane < 32) {
             const int row = wn * 32 + lane;
-            const char* half = smem_base + (wave & 4) * 16384 + STAT_OFF + row * 8;
+            const char* half = smem_base + GBASE + (wave >> 2) * GPIECE + STAT_OFF + row * 8;
             float2 t = *reinterpret_cast<const float2*>(half);
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
-                const float2 u = *reinterpret_cast<const float2*>(half + w * 16384);
+                const float2 u = *reinterpret_cast<const float2*>(half + w * WPIECE);
                 t.x += u.x; t.y += u.y;
             }
             const int m = mw0 + row;
@@ -977,6 +983,295 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
     }
 }
 
+// gemm_stream_kernel — gemm_line_kernel as ONE request stream per CU.
+//
+// What tools/gemm_timeline.py shows for the whole-line kernel (M = 302 592): a K = 768 tile lives 2.1 us of prologue (cold first step
+// image) + 18-19 us of main loop + 3.5-5 us (bias / GELU) or 12-14 us (residual) of epilogue, and its CU then waits 1-2.3 us for the
+// successor workgroup: the matrix cores run in 64-72 % of a tile's period.  The epilogue needs the accumulators and cannot overlap
+// with the next tile in one workgroup; the prologue and the turn-over can: here a workgroup stays on its CU (grid = CU count, tiles
+// b, b + grid, ... — the same tiles on the same XCD as the hardware dispatch would give it) and the LAST step of a tile requests
+// step 0 of the NEXT tile into the ring slot that step ns-2 has released, exactly as any step requests its successor; the L2
+// prefetch runs two steps ahead across the tile boundary the same way.  When the epilogue starts, the next tile's first step image
+// is in LDS (slot 0), so the epilogue's staging pieces live in slot 1 (wave w's piece = the 8 KiB its own next LDS-DMA pieces go
+// to); after the epilogue: one barrier, tile constants, step 1's requests, and step 0 computes at once.
+// LDS behind the ring: two tails and two raw-partials areas (tiles alternate: the next tile's constants arrive while this tile's epilogue
+// reads its own), then the sink of the L2 touches
+constexpr int STREAM_TAIL = NSLOT * SLOT_BYTES;                  // + par * TAIL_BYTES
+constexpr int STREAM_RAW = STREAM_TAIL + 2 * TAIL_BYTES;         // + par * 8192: 8 waves x 4 slabs x (32 sums | 32 sums of squares)
+constexpr int STREAM_SINK = STREAM_RAW + 2 * 8192;
+constexpr int STREAM_LDS_BYTES = STREAM_SINK + 256;
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
+    BigArgs p = pin;
+    p.M = __builtin_amdgcn_readfirstlane(ag_dyn_clamp(p.M, p.dyn));   // (a scalar: everything derived from it — tile counts, edges, has_next — stays in SGPRs)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = wave >> 2, gw = wave & 3;         // wave group (phase offset) and index inside it
+    const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
+    const int nwg = tiles_m * tiles_n;
+    const int nres = (int)gridDim.x;                  // resident workgroups: a multiple of 8 (or all tiles)
+    int bt = blockIdx.x;
+    if (bt >= nwg) return;
+    const int ns = p.K / 64;                          // steps per tile (even)
+    const bool stA = grp == 0;                        // group 0 stages A, group 1 stages W (see gemm_line_kernel)
+    const int ldx = stA ? (int)p.lda_b : (int)p.ldw_b;
+    const uint32_t d16 = (uint32_t)(16 * ldx);
+    uint32_t vb[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int row = gw * 64 + par * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+        vb[par] = (uint32_t)(row * ldx + ch * 16);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t ldsX_w = lds0 + (stA ? 0 : LW_BASE) + gw * 8192;         // + slot * LOP_BYTES
+    const int fr = lane & 15, fc = lane >> 4;
+    const uint32_t frag_lo = (uint32_t)(fr * LROWB + ((fc ^ ((fr >> 1) & 7)) << 4));
+    uint32_t vA = lds0 + frag_lo + wm * (128 * LROWB), vW = lds0 + frag_lo + LW_BASE + wn * (64 * LROWB);
+    asm volatile("" : "+v"(vA), "+v"(vW));
+
+    // a tile of the stream: scalars only
+    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; };     // (whole words only: never copied through memory)
+    auto tile_of = [&](int b) {
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        int tm, tn;
+        const int ngrp = p.ngrp;
+        const int full = (tiles_n / ngrp) * ngrp * tiles_m;
+        if (wg < full) {
+            const int g = wg / (ngrp * tiles_m), rem = wg - g * (ngrp * tiles_m);
+            tm = rem / ngrp; tn = g * ngrp + rem % ngrp;
+        } else {
+            const int w = tiles_n % ngrp, rem = wg - full;
+            tm = rem / w; tn = (tiles_n / ngrp) * ngrp + rem % w;
+        }
+        Tile t;
+        t.m0 = __builtin_amdgcn_readfirstlane(tm * BT); t.n0 = __builtin_amdgcn_readfirstlane(tn * BT); t.tn = __builtin_amdgcn_readfirstlane(tn);
+        const int vrows = stA ? min(BT, p.M - t.m0) : min(BT, p.N - t.n0);
+        t.x = stA ? p.A + (long)t.m0 * p.lda_b : p.W + (long)t.n0 * p.ldw_b;
+        t.off_max = (uint32_t)((vrows - 1) * ldx + 112);
+        t.edge = vrows < BT ? 1 : 0;
+        return t;
+    };
+    auto refill4 = [&](const Tile& t, int step, int slot, int h) {
+        const uint32_t lds = ldsX_w + slot * LOP_BYTES + h * 4096;
+        if (!t.edge) {
+            const char* b0 = t.x + (long)step * LROWB + (long)(2 * h) * d16;
+            glds_x4b(b0, b0 + d16, vb[0], vb[1], lds);
+        } else {
+            uint32_t d = d16, om = t.off_max;
+            asm volatile("" : "+s"(d), "+s"(om));
+            uint32_t o0 = vb[0] + (2 * h) * d, o1 = vb[1] + (2 * h) * d, o2 = vb[0] + (2 * h + 1) * d, o3 = vb[1] + (2 * h + 1) * d;
+            o0 = min(o0, om); o1 = min(o1, om); o2 = min(o2, om); o3 = min(o3, om);
+            glds_x4(t.x + (long)step * LROWB, o0, o1, o2, o3, lds);
+        }
+    };
+    auto prefetch = [&](const Tile& t, int step) {     // lane l of wave g touches the line of row 64 g + l of its operand's step image
+        int lx = ldx;
+        uint32_t om = t.off_max - 112u, ones = ~0u;
+        asm volatile("" : "+s"(lx), "+s"(om), "+s"(ones));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const uint32_t po = min((uint32_t)((gw * 64 + ln) * lx), om);
+        l2_touch(t.x + (long)step * LROWB, po, lds0 + STREAM_SINK);
+    };
+
+    // tile constants (bias | LayerNorm column sums or residual-LN gamma | residual-LN beta by column; row-statistics partials by row):
+    // LDS-DMA dwords straight into the LDS tail / a raw-partials area, requested at the top of their tile and covered by the counted wait
+    // that follows.  (gemm_line_kernel loads them into registers with asynchronous loads the compiler cannot see; in a persistent loop
+    // hipcc spills such registers — before the load has landed — and every reload is a vmcnt(0) of its own.)
+    constexpr bool ROWST = (VAR == 1 || VAR == 3);
+    auto request_constants = [&](const Tile& t, const int par) {
+        const uint32_t lds_tail = lds0 + STREAM_TAIL + par * TAIL_BYTES;
+        uint32_t ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        int n = t.n0 + gw * 64 + ln;
+        n = n < p.N ? n : p.N - 1;
+        const uint32_t col_off = (uint32_t)n * 4u;
+        if (stA) {
+            if (p.bias) l2_touch(reinterpret_cast<const char*>(p.bias), col_off, lds_tail + TAIL_C0 + gw * 256);
+            if (VAR == 3) l2_touch(reinterpret_cast<const char*>(p.rln_b), col_off, lds_tail + TAIL_C2 + gw * 256);
+        } else {
+            if (VAR == 1) l2_touch(reinterpret_cast<const char*>(p.ln_s), col_off, lds_tail + TAIL_C1 + gw * 256);
+            if (VAR == 3) l2_touch(reinterpret_cast<const char*>(p.rln_g), col_off, lds_tail + TAIL_C1 + gw * 256);
+        }
+        if (ROWST) {   // lanes 0-31: the sums of rows [32 wn, 32 wn + 32) of this wave's row half, lanes 32-63: their sums of squares; slab s_i
+            int m = t.m0 + wm * 128 + wn * 32 + (ln & 31);
+            m = m < p.M ? m : p.M - 1;
+            const uint32_t row_off = (uint32_t)(2 * m + (ln >> 5)) * 4u;
+#pragma unroll
+            for (int s_i = 0; s_i < 4; ++s_i)
+                l2_touch(reinterpret_cast<const char*>(p.ln_stats + (s_i < p.ln_nslab ? s_i : 0) * p.stats_slab), row_off,
+                         lds0 + STREAM_RAW + par * 8192 + (wave * 4 + s_i) * 256);
+        }
+    };
+    auto finish_constants = [&](const Tile& t, const int par) {     // raw partials -> (mean, rstd) per tile row
+        if (ROWST) {
+            // (tile-invariant inputs re-made from opaque values: hoisted out of the tile loop they would be registers held across the main
+            // loop, i.e. spills, i.e. a vmcnt(0) of the compiler's — which waits for step 1's pieces — at every reload)
+            int nslab = p.ln_nslab;
+            uint32_t ones = ~0u;
+            asm volatile("" : "+s"(nslab), "+s"(ones));
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+            if (ln < 32) {
+                const float* raw = reinterpret_cast<const float*>(smem + STREAM_RAW + par * 8192 + wave * 1024) + ln;
+                float sx = raw[0], sq = raw[32];
+#pragma unroll
+                for (int s_i = 1; s_i < 4; ++s_i) {
+                    const float kx = raw[s_i * 64], kq = raw[s_i * 64 + 32];     // (slabs past nslab hold a copy of slab 0: not added)
+                    sx += s_i < nslab ? kx : 0.f; sq += s_i < nslab ? kq : 0.f;
+                }
+                if (nslab > 4) {
+                    int m = t.m0 + wm * 128 + wn * 32 + ln;
+                    m = m < p.M ? m : p.M - 1;
+                    for (int s_i = 4; s_i < nslab; ++s_i) {
+                        const float2 w = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)m + s_i * p.stats_slab);
+                        sx += w.x; sq += w.y;
+                    }
+                }
+                const float mean = sx * p.ln_inv_h;
+                const float rstd = rsqrtf(fmaxf(sq * p.ln_inv_h - mean * mean, 0.f) + p.ln_eps);
+                *reinterpret_cast<float2*>(smem + STREAM_TAIL + par * TAIL_BYTES + TAIL_STAT + (wm * 128 + wn * 32 + ln) * 8) = make_float2(mean, rstd);
+            }
+        }
+    };
+    if (!p.bias && stA) {   // (no bias: zeros, once)
+        *reinterpret_cast<float*>(smem + STREAM_TAIL + TAIL_C0 + (gw * 64 + lane) * 4) = 0.f;
+        *reinterpret_cast<float*>(smem + STREAM_TAIL + TAIL_BYTES + TAIL_C0 + (gw * 64 + lane) * 4) = 0.f;
+    }
+
+    f32x4_t acc[4][8];
+    Tile cur = tile_of(bt);
+    int par = 0;                                                     // which tail / raw area holds the current tile's constants
+    request_constants(cur, 0);
+    refill4(cur, 0, 0, 0); refill4(cur, 0, 0, 1);                    // the stream's first step image
+    for (;;) {
+        const int bn = bt + nres;
+        const bool has_next = bn < nwg;
+        if (p.dbg && tid == 0) {
+            unsigned long long t_; uint32_t hw_;
+            asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw_)::"memory");
+            p.dbg[8 * (long)bt + 0] = t_; p.dbg[8 * (long)bt + 3] = hw_;
+        }
+        // ---- top of a tile: its step 0 and its constants are in LDS (first tile: on their way).  Step 1's requests go out first; the next
+        // tile's coordinates are worked out under their latency.  (Steps 0 and 1 were touched into L2 by the previous tile's last two
+        // steps, step 2 is touched by step 0 as usual.)
+        refill4(cur, 1, 1, 0); refill4(cur, 1, 1, 1);
+        const Tile nxt = tile_of(has_next ? bn : bt);                 // (no next tile: the prefetch slots re-touch this one)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // all but step 1's pieces (after the first tile: nothing but store acknowledgements)
+        finish_constants(cur, par);
+        if (grp == 1) asm volatile("s_barrier" ::: "memory");
+
+        // one K = 32 half of step `s` from ring slot SLOT (phases, request placement and waits: gemm_line_kernel).  `rt` / `rstep`:
+        // the step image this step requests (its own tile's step s+1, or the next tile's step 0), `pt` / `pstep`: the one it touches.
+        auto half = [&](const int slot, const int kh, const bool refill, const Tile& rt, const int rstep, const Tile& pt, const int pstep, const bool zero) {
+            asm volatile("s_barrier" ::: "memory");                        // "a"
+            if (refill) {
+                if (grp == 0) refill4(rt, rstep, slot ^ 1, kh);
+                else if (kh == 0) { refill4(rt, rstep, slot ^ 1, 0); refill4(rt, rstep, slot ^ 1, 1); }
+            }
+            if (kh == 1 && stA) prefetch(pt, pstep);
+            uint32_t x64 = kh ? 64u : 0u;
+            asm volatile("" : "+s"(x64));
+            typedef __attribute__((address_space(3))) const char* lds_cptr;
+            typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) const u32x4v* lds_u4ptr;
+            const lds_cptr pa = (lds_cptr)(uintptr_t)(vA ^ x64) + slot * LOP_BYTES;
+            const lds_cptr pw = (lds_cptr)(uintptr_t)(vW ^ x64) + slot * LOP_BYTES;
+            u32x4v fw[4], fx[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = *(lds_u4ptr)(pw + i * (16 * LROWB));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fx[i] = *(lds_u4ptr)(pa + i * (16 * LROWB));
+            __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0)
+            asm volatile("" ::: "memory");
+            if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");                        // "b"
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn)
+#pragma unroll
+                for (int sm = 0; sm < 8; ++sm)
+                    acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]), __builtin_bit_cast(bf16x8_t, fx[sm]),
+                                                                          zero ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[sn][sm], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        };
+        // step s of this tile: requests step s+1 (or the next tile's step 0), touches step s+2 (or the next tile's step s+2-ns)
+        auto step = [&](const int s, const int slot, const bool refill, const bool first) {
+            const bool own_r = s + 1 < ns, own_p = s + 2 < ns;
+            const Tile& rt = own_r ? cur : nxt;
+            const Tile& pt = own_p ? cur : nxt;
+            const int rstep = own_r ? s + 1 : 0, pstep = own_p ? s + 2 : s + 2 - ns;
+            half(slot, 0, refill, rt, rstep, pt, pstep, first);    // (first: the tile's accumulators start here, from a zero C operand)
+            half(slot, 1, refill, rt, rstep, pt, pstep, false);
+        };
+        if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 4] = t_; }
+        step(0, 0, false, true);                                           // step 1 was requested above
+        int s = 1;
+        for (; s + 1 < ns; s += 2) {
+            step(s, 1, true, false);
+            step(s + 1, 0, true, false);
+        }
+        step(s, 1, has_next, false);                                              // s == ns - 1: requests the NEXT tile's step 0 into slot 0
+        if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 5] = t_; }
+        if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
+
+        // (the next tile's step 0 has landed in slot 0: the last step's waits; the epilogue stages through slot 1.)  The next tile's constants
+        // are requested now, into the other tail: they land under the epilogue
+        if (has_next) request_constants(nxt, par ^ 1);
+        {   // (the lane id re-made from an opaque value: the epilogue's per-lane addresses are tile-invariant, and hoisted out of the tile
+            // loop they would be a dozen registers held across the main loop)
+            uint32_t ones = ~0u;
+            asm volatile("" : "+s"(ones));
+            const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+            wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3, 1>(p, acc, cur.m0 + wm * 128, cur.n0 + wn * 64,
+                                                                              smem + 32768 + grp * 65536 + gw * 8192, lane_e, smem, cur.tn,
+                                                                              smem + STREAM_TAIL + par * TAIL_BYTES);
+        }
+        if (p.dbg) {
+            unsigned long long t1, t2;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
+            if (tid == 0) { p.dbg[8 * (long)bt + 1] = t1; p.dbg[8 * (long)bt + 2] = t2; }
+        }
+        if (!has_next) break;
+        // this wave is done with its staging piece (= where its own step-1 pieces go next); the statistics producers also read each
+        // other's partials there: they wait for each other.  (The tails alternate: nobody waits for a tail.)
+        if (VAR == 2 || VAR == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        par ^= 1;
+        bt = bn;
+        cur = nxt;
+    }
+}
+
+template <int EPI, int VAR>
+int launch_stream_var(const BigArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
+        if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream): %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return ag_fail(AG_ERR_HIP, "gemm_stream: device properties");
+        n_cu = prop.multiProcessorCount & ~7;        // one resident workgroup per CU; a multiple of the 8 XCDs keeps a workgroup's tiles on its XCD
+        attr_set = true;
+    }
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 template <int EPI, int VAR>
 int launch_line_var(const BigArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -1003,6 +1298,8 @@ int launch_ring_var(const BigArgs& a, hipStream_t s) {
     }
     // whole-line staging (K = 64 steps, gemm_line_kernel) wherever K allows; AG_GEMM_LINE=0 keeps the K = 32 ring (A/B, parity tests)
     static AgKnob k_line("AG_GEMM_LINE");
+    static AgKnob k_stream("AG_GEMM_STREAM");
+    if (a.K % 128 == 0 && (int)k_line.get(1) != 0 && (int)k_stream.get(1) != 0) return launch_stream_var<EPI, VAR>(a, s);
     if (a.K % 128 == 0 && (int)k_line.get(1) != 0) return launch_line_var<EPI, VAR>(a, s);
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), LDS_BYTES, s, a);

@@ -9,13 +9,17 @@ from autognothi_amd import _lib as L, ops
 if os.environ.get("GB_LIB"): L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ["GB_LIB"])
 dev = torch.device("cuda:0")
 M, N, K = int(os.environ.get("GB_M", 302592)), int(os.environ.get("GB_N", 768)), int(os.environ.get("GB_K", 768))
-epi = {"resid": L.AG_EPI_BIAS_RESID, "gelu": L.AG_EPI_BIAS_GELU}[os.environ.get("GB_EPI", "resid")]
+epi = {"resid": L.AG_EPI_BIAS_RESID, "gelu": L.AG_EPI_BIAS_GELU, "bias": L.AG_EPI_BIAS}[os.environ.get("GB_EPI", "resid")]
+fold = os.environ.get("GB_FOLD", "0") == "1"      # LayerNorm-folded consumer (QKV, fc1 of the pre-LN encoder)
 a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
 w = ((torch.rand((N, K), device=dev) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
 b = torch.rand(N, device=dev); r = torch.rand((M, N), device=dev).to(torch.bfloat16)
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+kw = {}
+if fold: kw = dict(ln_stats=ops.row_stats(a), ln_colsum=w.float().sum(1).contiguous(), ln_eps=1e-6)
+if epi == L.AG_EPI_BIAS_RESID: kw = dict(resid=r, stats_out=ops.new_row_stats(M, N, dev))
 for _ in range(20):
-    ops.gemm(a, w, b, epi, L.AG_BF16, resid=r if epi == L.AG_EPI_BIAS_RESID else None, out=out)
+    ops.gemm(a, w, b, epi, L.AG_BF16, out=out, **kw)
 torch.cuda.synchronize()
 ptr = int(open("/tmp/ag_dbg_ptr.txt").read().strip(), 16)
 nwg = ((M + 255) // 256) * ((N + 255) // 256)
