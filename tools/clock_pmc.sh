@@ -13,11 +13,11 @@ kt = glob.glob("$D/*/*kernel_trace.csv")[0]
 cc = glob.glob("$D/*/*counter_collection.csv")[0]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(kt)):
-    if "gemm_ring" in r["Kernel_Name"] or "gemm_line" in r["Kernel_Name"]:
+    if "gemm_ring" in r["Kernel_Name"] or "gemm_line" in r["Kernel_Name"] or "gemm_stream" in r["Kernel_Name"]:
         dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 cnt = collections.defaultdict(dict)
 for r in csv.DictReader(open(cc)):
-    if "gemm_ring" in r["Kernel_Name"] or "gemm_line" in r["Kernel_Name"]:
+    if "gemm_ring" in r["Kernel_Name"] or "gemm_line" in r["Kernel_Name"] or "gemm_stream" in r["Kernel_Name"]:
         cnt[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = [i for i in cnt if i in dur][3:]
 n = len(ids)

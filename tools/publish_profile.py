@@ -12,12 +12,12 @@ shutil.copy(stats, os.path.join(pr, f"{tag}_kernel_stats_{suffix}.csv"))
 summ = json.load(open(os.path.join(go, f"prof_{tag}_summary.json")))
 json.dump(summ, open(os.path.join(pr, f"{tag}_pmc_summary_{suffix}.json"), "w"), indent=1)
 # bench.py kernel labels <- profiled kernel names (bf16 ViT hot path: LN-folded QKV / fc1+GELU, residual GEMMs with row stats)
-names = {"gemm<bias>": "gemm_line_kernel<0, 1>", "gemm<bias+gelu>": "gemm_line_kernel<1, 1>",
-         "gemm<bias+residual>": "gemm_line_kernel<2, 2>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
-for lab, old in (("gemm<bias>", "gemm_ring_kernel<0, 1, false>"), ("gemm<bias+gelu>", "gemm_ring_kernel<1, 1, false>"),
-                 ("gemm<bias+residual>", "gemm_ring_kernel<2, 2, false>")):   # (builds before round 3's whole-line kernel)
-    if names[lab] not in summ and old in summ:
-        names[lab] = old
+names = {"gemm<bias>": "gemm_stream_kernel<0, 1>", "gemm<bias+gelu>": "gemm_stream_kernel<1, 1>",
+         "gemm<bias+residual>": "gemm_stream_kernel<2, 2>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
+for lab, var in (("gemm<bias>", "0, 1"), ("gemm<bias+gelu>", "1, 1"), ("gemm<bias+residual>", "2, 2")):
+    for old in (f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):   # (AG_GEMM_STREAM=0 / builds before round 3)
+        if names[lab] not in summ and old in summ:
+            names[lab] = old
 attn = [k for k in summ if k.startswith("attn_bf16_kernel")]
 if attn:
     names["masked_attention"] = attn[0]

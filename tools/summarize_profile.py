@@ -7,7 +7,7 @@ prof, out = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    m = re.search(r"(gemm_line_kernel<[^>]*>|gemm_ring_kernel<[^>]*>|gemm_kernel<[^>]*>|attn_[a-z0-9_]+(<[^>]*>)?|layernorm_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
+    m = re.search(r"(gemm_stream_kernel<[^>]*>|gemm_line_kernel<[^>]*>|gemm_ring_kernel<[^>]*>|gemm_kernel<[^>]*>|attn_[a-z0-9_]+(<[^>]*>)?|layernorm_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
     return m.group(1) if m else name[:60]
 
 
