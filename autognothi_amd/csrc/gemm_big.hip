@@ -1000,7 +1000,16 @@ constexpr int STREAM_TAIL = NSLOT * SLOT_BYTES;                  // + par * TAIL
 constexpr int STREAM_RAW = STREAM_TAIL + 2 * TAIL_BYTES;         // + par * 8192: 8 waves x 4 slabs x (32 sums | 32 sums of squares)
 constexpr int STREAM_SINK = STREAM_RAW + 2 * 8192;
 constexpr int STREAM_LDS_BYTES = STREAM_SINK + 256;
-template <int EPI, int VAR = 0>
+// RLDS (bias + residual epilogue with an identity residual row map, share == 1): the RESIDUAL tile comes through LDS.  Read on demand in
+// the epilogue (accumulator-layout or whole-line loads into registers) it costs 7 us of a 13 us epilogue with the matrix cores idle —
+// what one CU gets out of cold vector loads (profiles/HISTORY.md) — and no placement of those loads changes that.  LDS-DMA pieces do
+// twice that rate on cold lines, need no registers, and can start before the main loop ends: the last step requests rows [0, 64) of
+// each wave's 128 x 64 sub-tile of the residual into the wave's own 8 KiB piece area of ring slot 0 (where a normal step would put its
+// successor), the epilogue requests rows [64, 128) into its area of slot 1 once slot 1 has been read; a half is then added in place
+// (ds_read_b64 in the accumulator layout, chunk-swizzled image), read back as whole 128-byte rows and stored; the next tile's step 0
+// goes into the slot-0 area as soon as the first half has left it.  Everything is private to the wave.  (L2 touches of the residual lines
+// a step ahead of the pieces, from behind the waves' last wait: +6 % on the out-projection — one line per lane is the dearest request shape.)
+template <int EPI, int VAR = 0, bool RLDS = false>
 __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     BigArgs p = pin;
     p.M = __builtin_amdgcn_readfirstlane(ag_dyn_clamp(p.M, p.dyn));   // (a scalar: everything derived from it — tile counts, edges, has_next — stays in SGPRs)
@@ -1076,7 +1085,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         const uint32_t po = min((uint32_t)((gw * 64 + ln) * lx), om);
         l2_touch(t.x + (long)step * LROWB, po, lds0 + STREAM_SINK);
     };
-
+    // RLDS: four 8-row pieces (j = 4 q .. 4 q + 3) of half h (rows [64 h, 64 h + 64)) of this wave's residual sub-tile -> its piece
+    // area of ring slot h.  Lane l fetches the 16-byte chunk that belongs at chunk position l & 7 of row l >> 3 of the piece: logical
+    // chunk (l & 7) ^ (l >> 3) (rows of a piece: row & 7 == l >> 3), so that the accumulator-layout ds_read_b64 of 16 rows spread over
+    // the banks.  Rows past M / columns past N are clamped to valid addresses (never stored).
+    auto res4 = [&](const Tile& t, const int h, const int q) {
+        uint32_t ones = ~0u;
+        int ldr = (int)p.ldr, mlast = p.M - 1, nlast = p.N - 8;
+        asm volatile("" : "+s"(ones), "+s"(ldr), "+s"(mlast), "+s"(nlast));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const int col = min(t.n0 + wn * 64 + (((ln & 7) ^ (ln >> 3)) << 3), nlast);
+        const int row0 = t.m0 + wm * 128 + h * 64 + q * 32 + (ln >> 3);
+        const uint32_t ldsR = lds0 + (stA ? 0 : LW_BASE) + gw * 8192 + h * LOP_BYTES + q * 4096;
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)(min(row0 + 8 * i, mlast) * ldr + col) * 2u;
+        glds_x4(reinterpret_cast<const char*>(p.R), o[0], o[1], o[2], o[3], ldsR);
+    };
     // tile constants (bias | LayerNorm column sums or residual-LN gamma | residual-LN beta by column; row-statistics partials by row):
     // LDS-DMA dwords straight into the LDS tail / a raw-partials area, requested at the top of their tile and covered by the counted wait
     // that follows.  (gemm_line_kernel loads them into registers with asynchronous loads the compiler cannot see; in a persistent loop
@@ -1166,9 +1191,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
 
         // one K = 32 half of step `s` from ring slot SLOT (phases, request placement and waits: gemm_line_kernel).  `rt` / `rstep`:
         // the step image this step requests (its own tile's step s+1, or the next tile's step 0), `pt` / `pstep`: the one it touches.
-        auto half = [&](const int slot, const int kh, const bool refill, const Tile& rt, const int rstep, const Tile& pt, const int pstep, const bool zero) {
+        // (`last` && RLDS: the step's requests are the first half of the residual tile; nothing is waited for in it — the epilogue counts)
+        auto half = [&](const int slot, const int kh, const bool refill, const Tile& rt, const int rstep, const Tile& pt, const int pstep, const bool zero,
+                        const bool last) {
             asm volatile("s_barrier" ::: "memory");                        // "a"
-            if (refill) {
+            if (RLDS && last) {
+                if (grp == 0) res4(cur, 0, kh);
+                else if (kh == 0) { res4(cur, 0, 0); res4(cur, 0, 1); }
+            } else if (refill) {
                 if (grp == 0) refill4(rt, rstep, slot ^ 1, kh);
                 else if (kh == 0) { refill4(rt, rstep, slot ^ 1, 0); refill4(rt, rstep, slot ^ 1, 1); }
             }
@@ -1187,7 +1217,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             for (int i = 0; i < 8; ++i) fx[i] = *(lds_u4ptr)(pa + i * (16 * LROWB));
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0)
             asm volatile("" ::: "memory");
-            if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (grp == 1 && kh == 1 && !(RLDS && last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");                        // "b"
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
@@ -1199,31 +1229,123 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                                                                           zero ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[sn][sm], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (grp == 0 && kh == 1 && !(RLDS && last)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         };
         // step s of this tile: requests step s+1 (or the next tile's step 0), touches step s+2 (or the next tile's step s+2-ns)
-        auto step = [&](const int s, const int slot, const bool refill, const bool first) {
+        auto step = [&](const int s, const int slot, const bool refill, const bool first, const bool last) {
             const bool own_r = s + 1 < ns, own_p = s + 2 < ns;
             const Tile& rt = own_r ? cur : nxt;
             const Tile& pt = own_p ? cur : nxt;
             const int rstep = own_r ? s + 1 : 0, pstep = own_p ? s + 2 : s + 2 - ns;
-            half(slot, 0, refill, rt, rstep, pt, pstep, first);    // (first: the tile's accumulators start here, from a zero C operand)
-            half(slot, 1, refill, rt, rstep, pt, pstep, false);
+            half(slot, 0, refill, rt, rstep, pt, pstep, first, last);    // (first: the tile's accumulators start here, from a zero C operand)
+            half(slot, 1, refill, rt, rstep, pt, pstep, false, last);
         };
         if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 4] = t_; }
-        step(0, 0, false, true);                                           // step 1 was requested above
+        step(0, 0, false, true, false);                                    // step 1 was requested above
         int s = 1;
         for (; s + 1 < ns; s += 2) {
-            step(s, 1, true, false);
-            step(s + 1, 0, true, false);
+            step(s, 1, true, false, false);
+            step(s + 1, 0, true, false, false);
         }
-        step(s, 1, has_next, false);                                              // s == ns - 1: requests the NEXT tile's step 0 into slot 0
+        step(s, 1, has_next, false, true);                                              // s == ns - 1: requests the NEXT tile's step 0 into slot 0
         if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 5] = t_; }
         if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
 
         // (the next tile's step 0 has landed in slot 0: the last step's waits; the epilogue stages through slot 1.)  The next tile's constants
         // are requested now, into the other tail: they land under the epilogue
         if (has_next) request_constants(nxt, par ^ 1);
+        if constexpr (RLDS) {
+            constexpr bool STATS = (VAR == 2);
+            uint32_t ones = ~0u;
+            asm volatile("" : "+s"(ones));
+            const int le = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));   // (opaque lane id: see below)
+            const int frow = le & 15, fq = le >> 4;
+            const int mw0 = cur.m0 + wm * 128, nw0 = cur.n0 + wn * 64;
+            const bool full_cols = nw0 + 64 <= p.N;
+            char* const area = smem + (stA ? 0 : LW_BASE) + gw * 8192;          // this wave's piece area of slot 0; slot 1: + LOP_BYTES
+            char* const part = smem + STREAM_RAW + wave * 1024;                  // this wave's 128 x (sum, sumsq) partials (VAR 2 has no raw partials)
+            const char* const tail = smem + STREAM_TAIL + par * TAIL_BYTES;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading slot 1
+            res4(cur, 1, 0); res4(cur, 1, 1);                                   // rows [64, 128) of the residual sub-tile -> slot 1
+            float4 bv[4];
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn) bv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C0 + (wn * 64 + sn * 16 + fq * 4) * 4);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // all but the eight pieces just requested: rows [0, 64) are in LDS
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                char* const img = area + h * LOP_BYTES;
+#pragma unroll
+                for (int smh = 0; smh < 4; ++smh) {
+                    const int sm = 4 * h + smh;
+                    const int lrow = smh * 16 + frow;                            // row of the 64-row half image
+                    const int m = mw0 + sm * 16 + frow;
+                    float row_s = 0.f, row_q = 0.f;
+#pragma unroll
+                    for (int sn = 0; sn < 4; ++sn) {
+                        uint2* const at = reinterpret_cast<uint2*>(img + lrow * 128 + (((sn * 2 + (fq >> 1)) ^ (lrow & 7)) << 4) + (fq & 1) * 8);
+                        const uint2 rq = *at;
+                        // (acc + bias) + residual: the same sum in the same order as wave_epilogue
+                        const float v0 = (acc[sn][sm][0] + bv[sn].x) + __uint_as_float(rq.x << 16), v1 = (acc[sn][sm][1] + bv[sn].y) + __uint_as_float(rq.x & 0xFFFF0000u);
+                        const float v2 = (acc[sn][sm][2] + bv[sn].z) + __uint_as_float(rq.y << 16), v3 = (acc[sn][sm][3] + bv[sn].w) + __uint_as_float(rq.y & 0xFFFF0000u);
+                        const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        *at = pk;
+                        if (STATS) {
+                            const float keep = (m < p.M && nw0 + sn * 16 + fq * 4 < p.N) ? 1.f : 0.f;
+                            const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xFFFF0000u);
+                            const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xFFFF0000u);
+                            row_s = fmaf(keep, (r0 + r1) + (r2 + r3), row_s);
+                            row_q = fmaf(keep, (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3), row_q);
+                        }
+                    }
+                    if (STATS) {
+                        row_s = quad_rows_sum(row_s); row_q = quad_rows_sum(row_q);
+                        if (fq == 0) *reinterpret_cast<float2*>(part + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
+                    }
+                }
+                // the half image is now the OUTPUT: read it back as whole 128-byte rows (this wave's own LDS operations complete in order)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = i * 8 + (le >> 3), ch = le & 7;
+                    const uint4 val = *reinterpret_cast<const uint4*>(img + rr * 128 + ((ch ^ (rr & 7)) << 4));
+                    const int mm = mw0 + h * 64 + rr;
+                    if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+                        uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        if (p.nt_store) {
+                            __builtin_nontemporal_store(u32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4*>(dstp));
+                        } else *dstp = val;
+                    }
+                }
+                if (h == 0) {
+                    // the slot-0 area is free again (its rows are in registers / on their way out): the next tile's step 0 goes there now;
+                    // then everything older than those eight pieces — the residual's second half, the stores — is waited for
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (has_next) {
+                        refill4(nxt, 0, 0, 0); refill4(nxt, 0, 0, 1);
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+            }
+            if (STATS) {
+                // the four column waves (wn = 0..3) of this row half have each left 128 row partials: add them in wave order and store ONE
+                // (sum, sumsq) per row and column tile.  Wave wn finishes rows [32 wn, 32 wn + 32).
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (le < 32) {
+                    const int row = wn * 32 + le;
+                    const char* half_ = smem + STREAM_RAW + (wm * 4) * 1024 + row * 8;
+                    float2 t = *reinterpret_cast<const float2*>(half_);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) {
+                        const float2 u = *reinterpret_cast<const float2*>(half_ + w * 1024);
+                        t.x += u.x; t.y += u.y;
+                    }
+                    const int m = mw0 + row;
+                    if (m < p.M) *reinterpret_cast<float2*>(p.stats_out + (long)cur.tn * p.stats_slab + 2 * (long)m) = t;
+                }
+            }
+        } else
         {   // (the lane id re-made from an opaque value: the epilogue's per-lane addresses are tile-invariant, and hoisted out of the tile
             // loop they would be a dozen registers held across the main loop)
             uint32_t ones = ~0u;
@@ -1251,12 +1373,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     }
 }
 
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool RLDS = false>
 int launch_stream_var(const BigArgs& a, hipStream_t s) {
+    if constexpr (!RLDS && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2)) {
+        // residual through LDS: identity residual row map (share == 1: every layer but the first) and 32-bit byte offsets into R
+        static AgKnob k_rlds("AG_GEMM_RLDS");
+        if (a.R && a.share == 1 && (unsigned long long)a.M * (unsigned long long)a.ldr < 0x7FFFFFF0ull && (int)k_rlds.get(1) != 0)
+            return launch_stream_var<EPI, VAR, true>(a, s);
+    }
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream): %s", hipGetErrorString(e));
         int dev = 0;
@@ -1267,7 +1395,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }

@@ -351,13 +351,13 @@ def test_ring_random_shapes_all_variants(cuda_device, m, n, k):
     np.testing.assert_allclose(got2[:, 0], h2n.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
 
 
-@pytest.mark.parametrize("stream", [1, 0])
+@pytest.mark.parametrize("stream", ["stream+rlds", "stream", "line"])
 @pytest.mark.parametrize("m,n,k", [(1300, 2056, 768), (2048, 768, 3072), (1537, 776, 1024), (4096, 2304, 128), (70000, 768, 256),
                                    (66000, 520, 128)])
 def test_whole_line_kernel_equals_the_k32_ring_bit_for_bit(cuda_device, ag_knobs, m, n, k, stream):
-    """gemm_stream_kernel (stream = 1: one request stream per CU, tiles b, b + 256, ... with the next tile's first step image requested
-    by the last step; the last two cases give every workgroup 3-4 tiles of four / two steps each, the second with a ragged N edge),
-    gemm_line_kernel (stream = 0; both
+    """gemm_stream_kernel (one request stream per CU, tiles b, b + 256, ... with the next tile's first step image requested by the last
+    step; "+rlds": the residual tile of the bias + residual epilogues staged through LDS by LDS-DMA and added in place; the last two cases give every workgroup 3-4 tiles of four / two steps each, the second with a ragged N edge),
+    gemm_line_kernel ("line"; all
     K % 128 == 0: whole-line pieces, K = 64 steps, round 3) and gemm_ring_kernel (K = 32 half-steps) feed the same MFMAs the same
     fragments in the same order: every epilogue must give bit-identical outputs and row statistics — ragged M / N edge tiles (clamped
     request rows), LayerNorm-fold consumer, statistics producer, residual-LayerNorm variant."""
@@ -386,7 +386,7 @@ def test_whole_line_kernel_equals_the_k32_ring_bit_for_bit(cuda_device, ag_knobs
             out["rln"], out["rln_stats"] = o, s2
         return out
 
-    ag_knobs(AG_GEMM_LINE=1, AG_GEMM_STREAM=stream)
+    ag_knobs(AG_GEMM_LINE=1, AG_GEMM_STREAM=int(stream != "line"), AG_GEMM_RLDS=int(stream == "stream+rlds"))
     line = run_all()
     ag_knobs(AG_GEMM_LINE=0)
     ring = run_all()
