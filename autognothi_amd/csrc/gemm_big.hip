@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         // are requested now, into the other tail: they land under the epilogue
         if (has_next) request_constants(nxt, par ^ 1);
         if constexpr (RLDS) {
-            constexpr bool STATS = (VAR == 2);
+            constexpr bool STATS = (VAR == 2 || VAR == 3), RLN = (VAR == 3);
             uint32_t ones = ~0u;
             asm volatile("" : "+s"(ones));
             const int le = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));   // (opaque lane id: see below)
@@ -1263,13 +1263,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const int mw0 = cur.m0 + wm * 128, nw0 = cur.n0 + wn * 64;
             const bool full_cols = nw0 + 64 <= p.N;
             char* const area = smem + (stA ? 0 : LW_BASE) + gw * 8192;          // this wave's piece area of slot 0; slot 1: + LOP_BYTES
-            char* const part = smem + STREAM_RAW + wave * 1024;                  // this wave's 128 x (sum, sumsq) partials (VAR 2 has no raw partials)
+            // this wave's 128 x (sum, sumsq) partials: in the raw-partials area of THIS tile's parity (consumed at the top of the tile; the
+            // next tile's raw partials arrive in the other one)
+            char* const part = smem + STREAM_RAW + par * 8192 + wave * 1024;
             const char* const tail = smem + STREAM_TAIL + par * TAIL_BYTES;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading slot 1
             res4(cur, 1, 0); res4(cur, 1, 1);                                   // rows [64, 128) of the residual sub-tile -> slot 1
-            float4 bv[4];
+            float4 bv[4], gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
 #pragma unroll
-            for (int sn = 0; sn < 4; ++sn) bv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C0 + (wn * 64 + sn * 16 + fq * 4) * 4);
+            for (int sn = 0; sn < 4; ++sn) {
+                bv[sn] = *reinterpret_cast<const float4*>(tail + TAIL_C0 + (wn * 64 + sn * 16 + fq * 4) * 4);
+                if (RLN) {   // residual = LayerNorm of the stored pre-LN rows: gamma, beta by column; (mean, rstd) by row from the tail
+                    gv[RLN ? sn : 0] = *reinterpret_cast<const float4*>(tail + TAIL_C1 + (wn * 64 + sn * 16 + fq * 4) * 4);
+                    btv[RLN ? sn : 0] = *reinterpret_cast<const float4*>(tail + TAIL_C2 + (wn * 64 + sn * 16 + fq * 4) * 4);
+                }
+            }
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // all but the eight pieces just requested: rows [0, 64) are in LDS
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1280,13 +1288,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                     const int lrow = smh * 16 + frow;                            // row of the 64-row half image
                     const int m = mw0 + sm * 16 + frow;
                     float row_s = 0.f, row_q = 0.f;
+                    float nm = 0.f, ln_rstd = 1.f;
+                    if (RLN) {
+                        const float2 mr = *reinterpret_cast<const float2*>(tail + TAIL_STAT + (wm * 128 + sm * 16 + frow) * 8);
+                        nm = -mr.x; ln_rstd = mr.y;
+                    }
 #pragma unroll
                     for (int sn = 0; sn < 4; ++sn) {
                         uint2* const at = reinterpret_cast<uint2*>(img + lrow * 128 + (((sn * 2 + (fq >> 1)) ^ (lrow & 7)) << 4) + (fq & 1) * 8);
                         const uint2 rq = *at;
+                        float r0_ = __uint_as_float(rq.x << 16), r1_ = __uint_as_float(rq.x & 0xFFFF0000u);
+                        float r2_ = __uint_as_float(rq.y << 16), r3_ = __uint_as_float(rq.y & 0xFFFF0000u);
+                        if (RLN) {
+                            constexpr int SI = RLN ? 1 : 0;
+                            r0_ = fmaf((r0_ + nm) * ln_rstd, gv[sn * SI].x, btv[sn * SI].x); r1_ = fmaf((r1_ + nm) * ln_rstd, gv[sn * SI].y, btv[sn * SI].y);
+                            r2_ = fmaf((r2_ + nm) * ln_rstd, gv[sn * SI].z, btv[sn * SI].z); r3_ = fmaf((r3_ + nm) * ln_rstd, gv[sn * SI].w, btv[sn * SI].w);
+                        }
                         // (acc + bias) + residual: the same sum in the same order as wave_epilogue
-                        const float v0 = (acc[sn][sm][0] + bv[sn].x) + __uint_as_float(rq.x << 16), v1 = (acc[sn][sm][1] + bv[sn].y) + __uint_as_float(rq.x & 0xFFFF0000u);
-                        const float v2 = (acc[sn][sm][2] + bv[sn].z) + __uint_as_float(rq.y << 16), v3 = (acc[sn][sm][3] + bv[sn].w) + __uint_as_float(rq.y & 0xFFFF0000u);
+                        const float v0 = (acc[sn][sm][0] + bv[sn].x) + r0_, v1 = (acc[sn][sm][1] + bv[sn].y) + r1_;
+                        const float v2 = (acc[sn][sm][2] + bv[sn].z) + r2_, v3 = (acc[sn][sm][3] + bv[sn].w) + r3_;
                         const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                         *at = pk;
                         if (STATS) {
@@ -1334,7 +1354,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (le < 32) {
                     const int row = wn * 32 + le;
-                    const char* half_ = smem + STREAM_RAW + (wm * 4) * 1024 + row * 8;
+                    const char* half_ = smem + STREAM_RAW + par * 8192 + (wm * 4) * 1024 + row * 8;
                     float2 t = *reinterpret_cast<const float2*>(half_);
 #pragma unroll
                     for (int w = 1; w < 4; ++w) {
@@ -1375,7 +1395,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
 
 template <int EPI, int VAR, bool RLDS = false>
 int launch_stream_var(const BigArgs& a, hipStream_t s) {
-    if constexpr (!RLDS && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2)) {
+    if constexpr (!RLDS && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2 || VAR == 3)) {
         // residual through LDS: identity residual row map (share == 1: every layer but the first) and 32-bit byte offsets into R
         static AgKnob k_rlds("AG_GEMM_RLDS");
         if (a.R && a.share == 1 && (unsigned long long)a.M * (unsigned long long)a.ldr < 0x7FFFFFF0ull && (int)k_rlds.get(1) != 0)

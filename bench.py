@@ -660,9 +660,13 @@ def main():
             if traffic is not None and args.workload in ("vit_base", "vit_large") and EPI_NAMES[dom] == "gemm<bias+residual>":
                 # the counter average is over the full-size launches of the class (L-1 out-projections + L-1 fc2; the last layer's two
                 # CLS-only launches are another kernel): pair it with the algorithmic bytes of exactly those launches
+                # (and layer 0's out-projection, whose residual rows are shared by the K masks of an input, is a third: profiles/traffic.json
+                # holds the average of the residual-through-LDS kernel = L-2 out-projections + L-1 fc2)
                 hid, inter_, m_rows = params["hidden_size"], params["intermediate_size"], R * T
-                algo_full = 0.5 * sum((m_rows * k_ + hid * k_ + 2.0 * m_rows * hid) * 2.0 for k_ in (hid, inter_))
-                roofline["traffic_launches"] = "full-size launches only (out-proj + fc2 of layers 0..L-2)"
+                per = {k_: (m_rows * k_ + hid * k_ + 2.0 * m_rows * hid) * 2.0 for k_ in (hid, inter_)}
+                n_proj, n_fc2 = params["num_hidden_layers"] - 2, params["num_hidden_layers"] - 1
+                algo_full = (n_proj * per[hid] + n_fc2 * per[inter_]) / (n_proj + n_fc2)
+                roofline["traffic_launches"] = "full-size residual-through-LDS launches only (out-proj of layers 1..L-2 + fc2 of layers 0..L-2)"
                 roofline["algorithmic_bytes_per_traffic_launch"] = round(algo_full)
                 roofline["traffic_over_algorithmic"] = round(traffic / algo_full, 3)
         roofline["whole_step"] = {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),

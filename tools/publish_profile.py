@@ -12,10 +12,11 @@ shutil.copy(stats, os.path.join(pr, f"{tag}_kernel_stats_{suffix}.csv"))
 summ = json.load(open(os.path.join(go, f"prof_{tag}_summary.json")))
 json.dump(summ, open(os.path.join(pr, f"{tag}_pmc_summary_{suffix}.json"), "w"), indent=1)
 # bench.py kernel labels <- profiled kernel names (bf16 ViT hot path: LN-folded QKV / fc1+GELU, residual GEMMs with row stats)
-names = {"gemm<bias>": "gemm_stream_kernel<0, 1>", "gemm<bias+gelu>": "gemm_stream_kernel<1, 1>",
-         "gemm<bias+residual>": "gemm_stream_kernel<2, 2>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
+names = {"gemm<bias>": "gemm_stream_kernel<0, 1, false>", "gemm<bias+gelu>": "gemm_stream_kernel<1, 1, false>",
+         "gemm<bias+residual>": "gemm_stream_kernel<2, 2, true>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
 for lab, var in (("gemm<bias>", "0, 1"), ("gemm<bias+gelu>", "1, 1"), ("gemm<bias+residual>", "2, 2")):
-    for old in (f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):   # (AG_GEMM_STREAM=0 / builds before round 3)
+    # (AG_GEMM_RLDS=0 / AG_GEMM_STREAM=0 / builds before round 3)
+    for old in (f"gemm_stream_kernel<{var}, false>", f"gemm_stream_kernel<{var}>", f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):
         if names[lab] not in summ and old in summ:
             names[lab] = old
 attn = [k for k in summ if k.startswith("attn_bf16_kernel")]
