@@ -420,7 +420,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per explainer training step of the secondary block (0 = skip)")
     # 220 images x 197 tokens = 170 M-tiles: 510 / 1530 / 2040 tiles for N = 768 / 2304 / 3072 = 1.99 / 5.98 / 7.97 rounds of 256 CUs
     # (128 images leave 42 % of the second round of the N = 768 GEMMs idle: 6.3 k -> 7.6 k attributions/s)
-    ap.add_argument("--attr-batch", type=int, default=220, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
+    ap.add_argument("--attr-batch", type=int, default=660, help="images per GPU per fw_final pass of the secondary metric (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="the timed hot path only (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the timed step from a hipGraph (no in-library kernel timing then)")
     args = ap.parse_args()
