@@ -351,6 +351,45 @@ def test_ring_random_shapes_all_variants(cuda_device, m, n, k):
     np.testing.assert_allclose(got2[:, 0], h2n.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
 
 
+def test_stream_kernel_with_device_row_count(cuda_device):
+    """the persistent GEMM (several tiles per workgroup, tile count derived on the device from d_rows) on launches sized for 70 000 rows
+    of which 41 237 exist: every epilogue equals the exact-size launch bit for bit on the live rows and leaves the others untouched."""
+    from autognothi_amd import _lib as L, ops
+    upper, live, h = 70000, 41237, 768
+    g = np.random.default_rng(77)
+    dev = cuda_device
+    a = _dev(_r(g.standard_normal((upper, h)).astype(np.float32)), dev)
+    w = _dev(_r((g.standard_normal((h, h)) / np.sqrt(h)).astype(np.float32)), dev)
+    b = torch.from_numpy(g.standard_normal(h).astype(np.float32)).to(dev)
+    r = _dev(_r(g.standard_normal((upper, h)).astype(np.float32)), dev)
+    gam = torch.from_numpy((1 + 0.1 * g.standard_normal(h)).astype(np.float32)).to(dev)
+    bet = torch.from_numpy((0.1 * g.standard_normal(h)).astype(np.float32)).to(dev)
+    cnt = torch.tensor([live], dtype=torch.int32, device=dev)
+    colsum = w.float().sum(1).contiguous()
+
+    def run(rows, rows_dev):
+        st_a = ops.row_stats(a[:rows])
+        st = ops.new_row_stats(rows, h, dev)
+        out = {}
+        o = torch.full((rows, h), 3.0, dtype=torch.bfloat16, device=dev)
+        out["resid"] = ops.gemm(a[:rows], w, b, L.AG_EPI_BIAS_RESID, BF16, resid=r[:rows], stats_out=st, out=o, rows_dev=rows_dev)
+        out["stats"] = st[:, :live].clone()
+        o2 = torch.full((rows, h), 3.0, dtype=torch.bfloat16, device=dev)
+        out["fold"] = ops.gemm(a[:rows], w, b, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st_a, ln_colsum=colsum, ln_eps=1e-12, out=o2, rows_dev=rows_dev)
+        r_st = ops.row_stats(r[:rows])
+        o3, _ = ops.gemm_resid_ln(a[:rows], w, b, r[:rows], r_st, gam, bet, 1e-12, rows_dev=rows_dev)
+        out["rln"] = o3
+        return out
+
+    exact = run(live, None)
+    dyn = run(upper, cnt)
+    for key in ("resid", "fold", "rln"):
+        assert torch.equal(dyn[key][:live], exact[key]), key
+    assert torch.equal(dyn["stats"], exact["stats"])
+    for key in ("resid", "fold"):
+        assert bool((dyn[key][live:].float() == 3.0).all()), key
+
+
 @pytest.mark.parametrize("stream", ["stream+rlds", "stream", "line"])
 @pytest.mark.parametrize("m,n,k", [(1300, 2056, 768), (2048, 768, 3072), (1537, 776, 1024), (4096, 2304, 128), (70000, 768, 256),
                                    (66000, 520, 128)])
