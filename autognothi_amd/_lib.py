@@ -17,6 +17,7 @@ AG_OK = 0
 AG_F32, AG_BF16 = 0, 1
 AG_MASK_VIT_MUL, AG_MASK_BERT_ADD = 0, 1
 AG_EPI_BIAS, AG_EPI_BIAS_GELU, AG_EPI_BIAS_RESID, AG_EPI_BIAS_F32, AG_EPI_BIAS_TANH, AG_EPI_BIAS_GELU_ADD = 0, 1, 2, 3, 4, 5
+AG_EX_STORE, AG_EX_GELU_DUAL, AG_EX_GELU_BWD, AG_EX_SLABS = 0, 1, 2, 3
 AG_MT_STATE_BYTES = 2560
 
 vp, i32, i64, u32, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_float, C.c_size_t
@@ -52,6 +53,17 @@ SIGNATURES = {
     "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
     "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp]),
     "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
+    "ag_gemm_ex": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp]),
+    "ag_gemm_ex_splits": (i32, [i32, i32, i32]),
+    "ag_rows_finish": (i32, [vp, i32, i64, vp, f32, u32, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]),
+    "ag_rows_ln_bwd_scratch_floats": (sz, [i32, i32]),
+    "ag_rows_ln_bwd": (i32, [vp, i32, i64, vp, vp, vp, f32, vp, vp, vp, f32, u32, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "ag_slab_reduce": (i32, [vp, i32, i64, i64, vp, i32, vp]),
+    "ag_colsum_bf16_scratch_floats": (sz, [i32, i32]),
+    "ag_colsum_bf16": (i32, [vp, i32, i32, i64, vp, i32, vp, vp]),
+    "ag_cast_f32_many": (i32, [vp, vp, vp, vp, i32, vp]),
+    "ag_masked_attention_train_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
+    "ag_masked_attention_bwd_bf16": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
     "ag_gemm_resid_ln": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp]),
     "ag_gemm_resid_ln_supported": (i32, [i32, i32, i32, i64, i64, i64]),

@@ -290,6 +290,8 @@ struct AttnBwdArgs {
     const float* qkv; const uint32_t* mask; const float* ctx; const float* dctx;
     float* dqkv; float* stats;  // stats [R*heads*T][3] = (m, l, D)
     int R, T, H, heads, mode, Tw; float pdrop; uint32_t seed;
+    // bf16 I/O (ag_masked_attention_*_bf16): qkv / outputs as bf16, dctx = sum of `dslabs` fp32 slabs (a split-K GEMM's partials)
+    const bf16_t* qkv16; bf16_t* out16; int dslabs; long dslab_stride;
 };
 template <int AHD>
 __device__ __forceinline__ float dot_hd(const float* a, const float* b) {
@@ -475,7 +477,8 @@ __device__ __forceinline__ uint4 pack8_bf16(const float4 a, const float4 b) {
 }
 
 // FWD: only pass 1 runs and its O' (the training forward on bf16 operands, dropout included) is stored to p.dqkv as ctx [R,T,H].
-template <int MODE, bool FWD>
+// IO16: bf16 qkv in, bf16 ctx / dqkv out, dctx summed from fp32 slabs (the bf16-activation training step); else fp32 I/O.
+template <int MODE, bool FWD, bool IO16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -499,20 +502,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint64_t hbase = (uint64_t)blockIdx.x * T;
 
     // ---- images
+    const bf16_t* base16 = IO16 ? p.qkv16 + (long)row * T * ts + (long)head * 64 : nullptr;
     for (int c = tid; c < Tp * 8; c += blockDim.x) {
         const int t = c >> 3, ch = c & 7;
         const int tc = t < T ? t : T - 1;
-        const float* src = base + (long)tc * ts + ch * 8;
         const int dst = t * BROW + ((ch ^ bswz(t)) << 4);
-        *reinterpret_cast<uint4*>(iQ + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
-        uint4 kv = pack8_bf16(*reinterpret_cast<const float4*>(src + p.H), *reinterpret_cast<const float4*>(src + p.H + 4));
+        uint4 kv;
+        if (IO16) {
+            const bf16_t* src = base16 + (long)tc * ts + ch * 8;
+            *reinterpret_cast<uint4*>(iQ + dst) = *reinterpret_cast<const uint4*>(src);
+            kv = *reinterpret_cast<const uint4*>(src + p.H);
+            *reinterpret_cast<uint4*>(iV + dst) = *reinterpret_cast<const uint4*>(src + 2 * p.H);
+        } else {
+            const float* src = base + (long)tc * ts + ch * 8;
+            *reinterpret_cast<uint4*>(iQ + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
+            kv = pack8_bf16(*reinterpret_cast<const float4*>(src + p.H), *reinterpret_cast<const float4*>(src + p.H + 4));
+            *reinterpret_cast<uint4*>(iV + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src + 2 * p.H), *reinterpret_cast<const float4*>(src + 2 * p.H + 4));
+        }
         if (MODE == AG_MASK_VIT_MUL && !((mrow[tc >> 5] >> (tc & 31)) & 1u)) kv = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(iK + dst) = kv;
-        *reinterpret_cast<uint4*>(iV + dst) = pack8_bf16(*reinterpret_cast<const float4*>(src + 2 * p.H), *reinterpret_cast<const float4*>(src + 2 * p.H + 4));
         uint4 dv = make_uint4(0u, 0u, 0u, 0u);
         if (!FWD && t < T) {
             const float* ds_ = dob + (long)t * p.H + ch * 8;
-            dv = pack8_bf16(*reinterpret_cast<const float4*>(ds_), *reinterpret_cast<const float4*>(ds_ + 4));
+            float4 d0 = *reinterpret_cast<const float4*>(ds_), d1 = *reinterpret_cast<const float4*>(ds_ + 4);
+            if (IO16)
+                for (int sl = 1; sl < p.dslabs; ++sl) {   // slab order: bit-reproducible
+                    const float4 e0 = *reinterpret_cast<const float4*>(ds_ + sl * p.dslab_stride), e1 = *reinterpret_cast<const float4*>(ds_ + sl * p.dslab_stride + 4);
+                    d0.x += e0.x; d0.y += e0.y; d0.z += e0.z; d0.w += e0.w; d1.x += e1.x; d1.y += e1.y; d1.z += e1.z; d1.w += e1.w;
+                }
+            dv = pack8_bf16(d0, d1);
         }
         *reinterpret_cast<uint4*>(iO + dst) = dv;
     }
@@ -617,12 +635,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (FWD) {   // ctx = O' / l with the dropout scale, fp32
             if (q < T) {
                 const float sc = keep_sc / l;
-                float* out = p.dqkv + ((long)row * T + q) * p.H + (long)head * 64;
+                const long oo = ((long)row * T + q) * p.H + (long)head * 64;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int d = 8 * g4 + 4 * lh;
-                    *reinterpret_cast<float4*>(out + d) = make_float4(o0[4 * g4] * sc, o0[4 * g4 + 1] * sc, o0[4 * g4 + 2] * sc, o0[4 * g4 + 3] * sc);
-                    *reinterpret_cast<float4*>(out + 32 + d) = make_float4(o1[4 * g4] * sc, o1[4 * g4 + 1] * sc, o1[4 * g4 + 2] * sc, o1[4 * g4 + 3] * sc);
+                    if (IO16) {
+                        *reinterpret_cast<uint2*>(p.out16 + oo + d) = make_uint2(pack_bf16x2(o0[4 * g4] * sc, o0[4 * g4 + 1] * sc), pack_bf16x2(o0[4 * g4 + 2] * sc, o0[4 * g4 + 3] * sc));
+                        *reinterpret_cast<uint2*>(p.out16 + oo + 32 + d) = make_uint2(pack_bf16x2(o1[4 * g4] * sc, o1[4 * g4 + 1] * sc), pack_bf16x2(o1[4 * g4 + 2] * sc, o1[4 * g4 + 3] * sc));
+                    } else {
+                        float* out = p.dqkv + oo;
+                        *reinterpret_cast<float4*>(out + d) = make_float4(o0[4 * g4] * sc, o0[4 * g4 + 1] * sc, o0[4 * g4 + 2] * sc, o0[4 * g4 + 3] * sc);
+                        *reinterpret_cast<float4*>(out + 32 + d) = make_float4(o1[4 * g4] * sc, o1[4 * g4 + 1] * sc, o1[4 * g4 + 2] * sc, o1[4 * g4 + 3] * sc);
+                    }
                 }
             }
             continue;
@@ -670,12 +694,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (q < T) {   // accumulator regs 4g..4g+3 of lane (query, lh) are head-dim elements 8g + 4lh .. +3 (second tile: +32)
-            float* out = p.dqkv + ((long)row * T + q) * ts + (long)head * 64;
+            const long oo = ((long)row * T + q) * ts + (long)head * 64;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 8 * g4 + 4 * lh;
-                *reinterpret_cast<float4*>(out + d) = make_float4(dq0[4 * g4] * 0.125f, dq0[4 * g4 + 1] * 0.125f, dq0[4 * g4 + 2] * 0.125f, dq0[4 * g4 + 3] * 0.125f);
-                *reinterpret_cast<float4*>(out + 32 + d) = make_float4(dq1[4 * g4] * 0.125f, dq1[4 * g4 + 1] * 0.125f, dq1[4 * g4 + 2] * 0.125f, dq1[4 * g4 + 3] * 0.125f);
+                if (IO16) {
+                    *reinterpret_cast<uint2*>(p.out16 + oo + d) = make_uint2(pack_bf16x2(dq0[4 * g4] * 0.125f, dq0[4 * g4 + 1] * 0.125f), pack_bf16x2(dq0[4 * g4 + 2] * 0.125f, dq0[4 * g4 + 3] * 0.125f));
+                    *reinterpret_cast<uint2*>(p.out16 + oo + 32 + d) = make_uint2(pack_bf16x2(dq1[4 * g4] * 0.125f, dq1[4 * g4 + 1] * 0.125f), pack_bf16x2(dq1[4 * g4 + 2] * 0.125f, dq1[4 * g4 + 3] * 0.125f));
+                } else {
+                    float* out = p.dqkv + oo;
+                    *reinterpret_cast<float4*>(out + d) = make_float4(dq0[4 * g4] * 0.125f, dq0[4 * g4 + 1] * 0.125f, dq0[4 * g4 + 2] * 0.125f, dq0[4 * g4 + 3] * 0.125f);
+                    *reinterpret_cast<float4*>(out + 32 + d) = make_float4(dq1[4 * g4] * 0.125f, dq1[4 * g4 + 1] * 0.125f, dq1[4 * g4 + 2] * 0.125f, dq1[4 * g4 + 3] * 0.125f);
+                }
             }
         }
     }
@@ -736,15 +766,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (kvalid) {
-            float* outk = p.dqkv + ((long)row * T + key) * ts + p.H + (long)head * 64;
-            float* outv = outk + p.H;
+            const long ok_ = ((long)row * T + key) * ts + p.H + (long)head * 64, ov_ = ok_ + p.H;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 8 * g4 + 4 * lh;
-                *reinterpret_cast<float4*>(outk + d) = make_float4(dk0[4 * g4] * 0.125f, dk0[4 * g4 + 1] * 0.125f, dk0[4 * g4 + 2] * 0.125f, dk0[4 * g4 + 3] * 0.125f);
-                *reinterpret_cast<float4*>(outk + 32 + d) = make_float4(dk1[4 * g4] * 0.125f, dk1[4 * g4 + 1] * 0.125f, dk1[4 * g4 + 2] * 0.125f, dk1[4 * g4 + 3] * 0.125f);
-                *reinterpret_cast<float4*>(outv + d) = make_float4(dv0[4 * g4] * keep_sc, dv0[4 * g4 + 1] * keep_sc, dv0[4 * g4 + 2] * keep_sc, dv0[4 * g4 + 3] * keep_sc);
-                *reinterpret_cast<float4*>(outv + 32 + d) = make_float4(dv1[4 * g4] * keep_sc, dv1[4 * g4 + 1] * keep_sc, dv1[4 * g4 + 2] * keep_sc, dv1[4 * g4 + 3] * keep_sc);
+                if (IO16) {
+                    *reinterpret_cast<uint2*>(p.out16 + ok_ + d) = make_uint2(pack_bf16x2(dk0[4 * g4] * 0.125f, dk0[4 * g4 + 1] * 0.125f), pack_bf16x2(dk0[4 * g4 + 2] * 0.125f, dk0[4 * g4 + 3] * 0.125f));
+                    *reinterpret_cast<uint2*>(p.out16 + ok_ + 32 + d) = make_uint2(pack_bf16x2(dk1[4 * g4] * 0.125f, dk1[4 * g4 + 1] * 0.125f), pack_bf16x2(dk1[4 * g4 + 2] * 0.125f, dk1[4 * g4 + 3] * 0.125f));
+                    *reinterpret_cast<uint2*>(p.out16 + ov_ + d) = make_uint2(pack_bf16x2(dv0[4 * g4] * keep_sc, dv0[4 * g4 + 1] * keep_sc), pack_bf16x2(dv0[4 * g4 + 2] * keep_sc, dv0[4 * g4 + 3] * keep_sc));
+                    *reinterpret_cast<uint2*>(p.out16 + ov_ + 32 + d) = make_uint2(pack_bf16x2(dv1[4 * g4] * keep_sc, dv1[4 * g4 + 1] * keep_sc), pack_bf16x2(dv1[4 * g4 + 2] * keep_sc, dv1[4 * g4 + 3] * keep_sc));
+                } else {
+                    float* outk = p.dqkv + ok_;
+                    float* outv = p.dqkv + ov_;
+                    *reinterpret_cast<float4*>(outk + d) = make_float4(dk0[4 * g4] * 0.125f, dk0[4 * g4 + 1] * 0.125f, dk0[4 * g4 + 2] * 0.125f, dk0[4 * g4 + 3] * 0.125f);
+                    *reinterpret_cast<float4*>(outk + 32 + d) = make_float4(dk1[4 * g4] * 0.125f, dk1[4 * g4 + 1] * 0.125f, dk1[4 * g4 + 2] * 0.125f, dk1[4 * g4 + 3] * 0.125f);
+                    *reinterpret_cast<float4*>(outv + d) = make_float4(dv0[4 * g4] * keep_sc, dv0[4 * g4 + 1] * keep_sc, dv0[4 * g4 + 2] * keep_sc, dv0[4 * g4 + 3] * keep_sc);
+                    *reinterpret_cast<float4*>(outv + 32 + d) = make_float4(dv1[4 * g4] * keep_sc, dv1[4 * g4 + 1] * keep_sc, dv1[4 * g4 + 2] * keep_sc, dv1[4 * g4 + 3] * keep_sc);
+                }
             }
         }
     }
@@ -891,6 +929,7 @@ extern "C" int ag_masked_attention_train_mixed(const float* d_qkv, const uint32_
     if (R == 0) return AG_OK;
     AttnBwdArgs a;
     a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = nullptr; a.dctx = nullptr; a.dqkv = d_ctx; a.stats = nullptr;
+    a.qkv16 = nullptr; a.out16 = nullptr; a.dslabs = 1; a.dslab_stride = 0;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
     const int Tp = (T + 31) & ~31;
     const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
@@ -911,6 +950,7 @@ extern "C" int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t*
     if (R == 0) return AG_OK;
     AttnBwdArgs a;
     a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = d_ctx; a.dctx = d_dctx; a.dqkv = d_dqkv; a.stats = nullptr;
+    a.qkv16 = nullptr; a.out16 = nullptr; a.dslabs = 1; a.dslab_stride = 0;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
     const int Tp = (T + 31) & ~31;
     const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
@@ -921,6 +961,39 @@ extern "C" int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t*
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
+// bf16-activation training step: qkv [R,T,3H] bf16 -> ctx [R,T,H] bf16 (forward), and dqkv [R,T,3H] bf16 from dctx given as
+// `dslabs` fp32 partial slabs [dslabs][R*T][H] (the split-K out-projection dX of ag_gemm_ex), summed in slab order on load.
+static int attn_mixed16(bool fwd, const void* d_qkv, const uint32_t* d_mask_bits, const float* d_dctx, int dslabs, int64_t dslab_stride,
+                        void* d_out, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed, void* stream) {
+    AG_REQUIRE(d_qkv && d_mask_bits && d_out && (fwd || (d_dctx && dslabs >= 1)), "ag_masked_attention_*_bf16: null pointer");
+    AG_REQUIRE(heads > 0 && H == heads * 64 && R >= 0 && T >= 1 && T <= 256 && p_drop >= 0.f && p_drop < 1.f,
+               "ag_masked_attention_*_bf16: needs head_dim 64 and T <= 256 (T=%d, H=%d, heads=%d)", T, H, heads);
+    AG_REQUIRE(mask_mode == AG_MASK_VIT_MUL || mask_mode == AG_MASK_BERT_ADD, "ag_masked_attention_*_bf16: bad mask mode %d", mask_mode);
+    if (R == 0) return AG_OK;
+    AttnBwdArgs a;
+    a.qkv = nullptr; a.mask = d_mask_bits; a.ctx = nullptr; a.dctx = d_dctx; a.dqkv = nullptr; a.stats = nullptr;
+    a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
+    a.qkv16 = (const bf16_t*)d_qkv; a.out16 = (bf16_t*)d_out; a.dslabs = dslabs; a.dslab_stride = (long)dslab_stride;
+    const int Tp = (T + 31) & ~31;
+    const size_t lds = (size_t)4 * Tp * BROW + (size_t)2 * Tp * sizeof(float);
+    void (*kern)(AttnBwdArgs);
+    if (fwd) kern = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL, true, true> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD, true, true>;
+    else kern = mask_mode == AG_MASK_VIT_MUL ? attn_bwd_mfma_kernel<AG_MASK_VIT_MUL, false, true> : attn_bwd_mfma_kernel<AG_MASK_BERT_ADD, false, true>;
+    if (lds > 64 * 1024)
+        AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(R * heads), dim3(512), lds, (hipStream_t)stream, a);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+extern "C" int ag_masked_attention_train_bf16(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H, int heads,
+                                              int mask_mode, float p_drop, uint32_t seed, void* stream) {
+    return attn_mixed16(true, d_qkv, d_mask_bits, nullptr, 0, 0, d_ctx, R, T, H, heads, mask_mode, p_drop, seed, stream);
+}
+extern "C" int ag_masked_attention_bwd_bf16(const void* d_qkv, const uint32_t* d_mask_bits, const float* d_dctx, int dslabs,
+                                            int64_t dslab_stride, void* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop,
+                                            uint32_t seed, void* stream) {
+    return attn_mixed16(false, d_qkv, d_mask_bits, d_dctx, dslabs, dslab_stride, d_dqkv, R, T, H, heads, mask_mode, p_drop, seed, stream);
+}
 extern "C" int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mask_bits, const float* d_ctx, const float* d_dctx,
                                        float* d_dqkv, float* d_stats, int R, int T, int H, int heads, int mask_mode,
                                        float p_drop, uint32_t seed, void* stream) {
@@ -929,6 +1002,7 @@ extern "C" int ag_masked_attention_bwd(const float* d_qkv, const uint32_t* d_mas
     if (R == 0) return AG_OK;
     AttnBwdArgs a;
     a.qkv = d_qkv; a.mask = d_mask_bits; a.ctx = d_ctx; a.dctx = d_dctx; a.dqkv = d_dqkv; a.stats = d_stats;
+    a.qkv16 = nullptr; a.out16 = nullptr; a.dslabs = 1; a.dslab_stride = 0;
     a.R = R; a.T = T; a.H = H; a.heads = heads; a.mode = mask_mode; a.Tw = (T + 31) / 32; a.pdrop = p_drop; a.seed = seed;
     const dim3 grid(R * heads), block(256);
     hipStream_t hs = (hipStream_t)stream;

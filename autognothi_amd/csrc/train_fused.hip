@@ -1,0 +1,470 @@
+// train_fused.hip — the row kernels between the GEMMs of the bf16 training step (round 4).
+//
+// Every Linear of the step runs on ag_gemm_ex (gemm_tn.hip); where that GEMM is split over the contraction its result arrives as
+// `splits` fp32 partial slabs [splits][M][H].  The kernels here are the consumers: they add the slabs in slab order (bit-reproducible)
+// and do, in the same pass over the row, everything the reference's autograd graph does between two Linear layers
+// (reference models/vanilla_vit.py:364-377 pre-LN block, models/vanilla_bert.py:410-427 post-LN block; backward: torch.autograd in
+// scripts/train_explainer.py:183-198):
+//   ag_rows_finish   t = resid + dropout(x + bias);  z = LayerNorm(t)          -> t fp32 (residual stream), z fp32 and / or bf16
+//   ag_rows_ln_bwd   dy = x_slabs (+ dy_add);  dx = LayerNorm'(dy) (+ add)      -> dx fp32, bf16(dropout'(dx)) = the dY operand of the
+//                    Linear below, column partials of dgamma / dbeta / that Linear's bias gradient
+//   ag_slab_reduce   dst (+)= sum of slabs (a dW product split over the rows)
+//   ag_colsum_bf16   bias gradient of a bf16 dY that a GEMM or attention epilogue produced
+//   ag_cast_f32_many every trainable weight fp32 -> bf16 after the optimiser step, ONE launch (q | k | v land fused)
+// One wave per row, the row in registers (H <= 1024), fp32 arithmetic throughout.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 4;   // float4 vectors per lane: H <= 1024
+
+struct RowsArgs {
+    const float* slabs; int splits; long slab_stride;
+    const float* bias;
+    float pdrop; uint32_t seed;
+    const float* resid;
+    float* t_out;
+    const float* gamma; const float* beta; float eps;
+    float* z_f32; bf16_t* z_bf16;
+    int M, H;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void rows_finish_kernel(RowsArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.M) return;
+    const long base = (long)row * p.H;
+    float4 v[NV];
+    bool on[NV];
+    const float sc = 1.0f / (1.0f - p.pdrop);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        on[i] = c < p.H;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!on[i]) continue;
+        float4 x = *reinterpret_cast<const float4*>(p.slabs + base + c);
+        for (int s = 1; s < p.splits; ++s) {
+            const float4 y = *reinterpret_cast<const float4*>(p.slabs + (long)s * p.slab_stride + base + c);
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
+            x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
+        }
+        if (p.pdrop > 0.f) {
+            const uint64_t i0 = (uint64_t)(base + c);
+            x.x = keep_elem(p.seed, i0, p.pdrop) ? x.x * sc : 0.f;
+            x.y = keep_elem(p.seed, i0 + 1, p.pdrop) ? x.y * sc : 0.f;
+            x.z = keep_elem(p.seed, i0 + 2, p.pdrop) ? x.z * sc : 0.f;
+            x.w = keep_elem(p.seed, i0 + 3, p.pdrop) ? x.w * sc : 0.f;
+        }
+        if (p.resid) {
+            const float4 r = *reinterpret_cast<const float4*>(p.resid + base + c);
+            x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+        }
+        if (p.t_out) *reinterpret_cast<float4*>(p.t_out + base + c) = x;
+        v[i] = x;
+    }
+    if (p.gamma) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) / (float)p.H;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (on[i]) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)p.H + p.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (on[i]) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 g = *reinterpret_cast<const float4*>(p.gamma + c), b = *reinterpret_cast<const float4*>(p.beta + c);
+                v[i].x = fmaf(v[i].x * rstd, g.x, b.x); v[i].y = fmaf(v[i].y * rstd, g.y, b.y);
+                v[i].z = fmaf(v[i].z * rstd, g.z, b.z); v[i].w = fmaf(v[i].w * rstd, g.w, b.w);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (on[i]) {
+            const int c = (i * 64 + lane) * 4;
+            if (p.z_f32) *reinterpret_cast<float4*>(p.z_f32 + base + c) = v[i];
+            if (p.z_bf16) *reinterpret_cast<uint2*>(p.z_bf16 + base + c) = make_uint2(pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w));
+        }
+}
+
+struct LnBwdArgs {
+    const float* slabs; int splits; long slab_stride;
+    const float* dy_add;     // joins dy BEFORE the LayerNorm backward (post-LN blocks)
+    const float* x;          // the LayerNorm's input rows; NULL: no LayerNorm (dx = dy)
+    const float* gamma; float eps;
+    const float* add;        // joins dx AFTER it (pre-LN blocks: the residual branch)
+    float* dx;
+    bf16_t* dx_bf16; float pdrop; uint32_t seed;
+    float* part;             // [blocks][3][H]: dgamma, dbeta, colsum(dropout'(dx)) partials of the block's rows
+    int M, H;
+};
+
+// blocks of 4 waves; a wave walks rows blockIdx*4 + wave, + gridDim*4, ...; column partials are carried in registers over the wave's
+// rows, folded through LDS in wave order and stored per block (no atomics: the reduce kernel adds blocks in order)
+template <int NV>
+__global__ __launch_bounds__(256) void rows_ln_bwd_kernel(LnBwdArgs p) {
+    __shared__ float4 sacc[4][3][MAXV * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 ag[NV], ab[NV], ac[NV], gv[NV];
+    bool on[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        on[i] = c < p.H;
+        ag[i] = ab[i] = ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[i] = (on[i] && p.gamma) ? *reinterpret_cast<const float4*>(p.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    const float sc = 1.0f / (1.0f - p.pdrop);
+    const float invH = 1.0f / (float)p.H;
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+        const long base = (long)row * p.H;
+        float4 dv[NV], xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            dv[i] = xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!on[i]) continue;
+            float4 d = *reinterpret_cast<const float4*>(p.slabs + base + c);
+            for (int k = 1; k < p.splits; ++k) {
+                const float4 y = *reinterpret_cast<const float4*>(p.slabs + (long)k * p.slab_stride + base + c);
+                d.x += y.x; d.y += y.y; d.z += y.z; d.w += y.w;
+            }
+            if (p.dy_add) {
+                const float4 y = *reinterpret_cast<const float4*>(p.dy_add + base + c);
+                d.x += y.x; d.y += y.y; d.z += y.z; d.w += y.w;
+            }
+            dv[i] = d;
+            if (p.x) {
+                xv[i] = *reinterpret_cast<const float4*>(p.x + base + c);
+                s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+            }
+        }
+        float4 r[NV];
+        if (p.x) {
+            const float mean = wave_sum(s) * invH;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (on[i]) {
+                    xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+                    sq += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+                }
+            const float rstd = rsqrtf(wave_sum(sq) * invH + p.eps);
+            float a = 0.f, b = 0.f;   // mean(dy g), mean(dy g xhat)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;
+                const float g0 = dv[i].x * gv[i].x, g1 = dv[i].y * gv[i].y, g2 = dv[i].z * gv[i].z, g3 = dv[i].w * gv[i].w;
+                if (on[i]) {
+                    a += (g0 + g1) + (g2 + g3);
+                    b += (g0 * xv[i].x + g1 * xv[i].y) + (g2 * xv[i].z + g3 * xv[i].w);
+                }
+            }
+            a = wave_sum(a) * invH; b = wave_sum(b) * invH;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                r[i].x = rstd * (dv[i].x * gv[i].x - a - xv[i].x * b); r[i].y = rstd * (dv[i].y * gv[i].y - a - xv[i].y * b);
+                r[i].z = rstd * (dv[i].z * gv[i].z - a - xv[i].z * b); r[i].w = rstd * (dv[i].w * gv[i].w - a - xv[i].w * b);
+                ag[i].x = fmaf(dv[i].x, xv[i].x, ag[i].x); ag[i].y = fmaf(dv[i].y, xv[i].y, ag[i].y);
+                ag[i].z = fmaf(dv[i].z, xv[i].z, ag[i].z); ag[i].w = fmaf(dv[i].w, xv[i].w, ag[i].w);
+                ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r[i] = dv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (!on[i]) continue;
+            const int c = (i * 64 + lane) * 4;
+            if (p.add) {
+                const float4 y = *reinterpret_cast<const float4*>(p.add + base + c);
+                r[i].x += y.x; r[i].y += y.y; r[i].z += y.z; r[i].w += y.w;
+            }
+            if (p.dx) *reinterpret_cast<float4*>(p.dx + base + c) = r[i];
+            float4 d = r[i];
+            if (p.pdrop > 0.f) {
+                const uint64_t i0 = (uint64_t)(base + c);
+                d.x = keep_elem(p.seed, i0, p.pdrop) ? d.x * sc : 0.f;
+                d.y = keep_elem(p.seed, i0 + 1, p.pdrop) ? d.y * sc : 0.f;
+                d.z = keep_elem(p.seed, i0 + 2, p.pdrop) ? d.z * sc : 0.f;
+                d.w = keep_elem(p.seed, i0 + 3, p.pdrop) ? d.w * sc : 0.f;
+            }
+            if (p.dx_bf16) *reinterpret_cast<uint2*>(p.dx_bf16 + base + c) = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
+            ac[i].x += d.x; ac[i].y += d.y; ac[i].z += d.z; ac[i].w += d.w;
+        }
+    }
+    if (!p.part) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        sacc[wave][0][i * 64 + lane] = ag[i];
+        sacc[wave][1][i * 64 + lane] = ab[i];
+        sacc[wave][2][i * 64 + lane] = ac[i];
+    }
+    __syncthreads();
+    // 256 threads fold the four waves' partials in wave order: thread -> (kind, vector) pairs
+    for (int idx = threadIdx.x; idx < 3 * NV * 64; idx += 256) {
+        const int kind = idx / (NV * 64), vi = idx - kind * (NV * 64);
+        const int c = vi * 4;
+        if (c >= p.H) continue;
+        float4 t = sacc[0][kind][vi];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 o = sacc[w][kind][vi];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        *reinterpret_cast<float4*>(p.part + ((long)blockIdx.x * 3 + kind) * p.H + c) = t;
+    }
+}
+
+// out_k[c] (+)= sum over blocks of part[b][k][c], k = 0..2 (any out may be NULL); 64 columns x 4 partial lanes per block
+__global__ __launch_bounds__(256) void part3_reduce_kernel(const float* __restrict__ part, int nblocks, int H, float* o0, float* o1, float* o2,
+                                                           int accumulate) {
+    __shared__ float sa[3][4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float a[3] = {0.f, 0.f, 0.f};
+    if (c < H)
+        for (int i = q; i < nblocks; i += 4)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] += part[((long)i * 3 + k) * H + c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sa[k][q][cl] = a[k];
+    __syncthreads();
+    if (q == 0 && c < H) {
+        float* outs[3] = {o0, o1, o2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!outs[k]) continue;
+            const float t = (sa[k][0][cl] + sa[k][1][cl]) + (sa[k][2][cl] + sa[k][3][cl]);
+            outs[k][c] = accumulate ? outs[k][c] + t : t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, long stride, long n4, float* __restrict__ dst,
+                                                          int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 x = reinterpret_cast<const float4*>(slabs)[i];
+        for (int s = 1; s < splits; ++s) {
+            const float4 y = *reinterpret_cast<const float4*>(slabs + (long)s * stride + i * 4);
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+        if (accumulate) {
+            const float4 y = reinterpret_cast<const float4*>(dst)[i];
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = x;
+    }
+}
+
+// column sums of a bf16 [M, N] matrix (N % 8 == 0): a block owns 64 x 8 = 512... columns [512 b, +512) as 64 lanes x 8 columns, its 4 waves
+// walk rows w, w + 4, ...; the waves' partials are folded through LDS in wave order (fixed tree: bit-reproducible)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int M, int N, long ldx, float* __restrict__ out, int accumulate,
+                                                          int rows_per_block, float* __restrict__ part) {
+    __shared__ float sacc[4][64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < N)
+        for (int m = r0 + wave; m < r1; m += 4) {
+            const uint4 u = *reinterpret_cast<const uint4*>(x + (long)m * ldx + c);
+            a[0] += __uint_as_float(u.x << 16); a[1] += __uint_as_float(u.x & 0xFFFF0000u);
+            a[2] += __uint_as_float(u.y << 16); a[3] += __uint_as_float(u.y & 0xFFFF0000u);
+            a[4] += __uint_as_float(u.z << 16); a[5] += __uint_as_float(u.z & 0xFFFF0000u);
+            a[6] += __uint_as_float(u.w << 16); a[7] += __uint_as_float(u.w & 0xFFFF0000u);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sacc[wave][lane][j] = a[j];
+    __syncthreads();
+    if (wave == 0 && c < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = (sacc[0][lane][j] + sacc[1][lane][j]) + (sacc[2][lane][j] + sacc[3][lane][j]);
+            if (part) part[(long)blockIdx.y * N + c + j] = t;
+            else out[c + j] = accumulate ? out[c + j] + t : t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float t = 0.f;
+    for (int i = 0; i < nparts; ++i) t += part[(long)i * N + c];
+    out[c] = accumulate ? out[c] + t : t;
+}
+
+constexpr int CAST_MAX = 96;
+struct CastTable {
+    const float* src[CAST_MAX];
+    void* dst[CAST_MAX];
+    int first_block[CAST_MAX + 1];   // segment s owns blocks [first_block[s], first_block[s+1]); a block converts 4096 elements
+    int64_t n[CAST_MAX];
+    unsigned char f32[CAST_MAX];     // destination dtype: 0 bf16, 1 fp32 (a plain copy: fused q | k | v biases)
+    int count;
+};
+__global__ __launch_bounds__(256) void cast_many_kernel(const CastTable t) {
+    int lo = 0, hi = t.count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x >= t.first_block[mid]) lo = mid; else hi = mid;
+    }
+    const float* src = t.src[lo];
+    const int64_t n = t.n[lo];
+    const int64_t i0 = ((int64_t)(blockIdx.x - t.first_block[lo]) * 256 + threadIdx.x) * 16;
+    if (t.f32[lo]) {
+        float* dstf = reinterpret_cast<float*>(t.dst[lo]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + 4 * j;
+            if (i + 4 <= n) *reinterpret_cast<float4*>(dstf + i) = *reinterpret_cast<const float4*>(src + i);
+            else for (int64_t k = i; k < n && k < i + 4; ++k) dstf[k] = src[k];
+        }
+        return;
+    }
+    bf16_t* dst = reinterpret_cast<bf16_t*>(t.dst[lo]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t i = i0 + 8 * j;
+        if (i + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+            *reinterpret_cast<uint4*>(dst + i) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+        } else {
+            for (int64_t k = i; k < n && k < i + 8; ++k) dst[k] = f32_to_bf16(src[k]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ag_rows_finish(const float* d_x, int splits, int64_t slab_stride, const float* d_bias, float p_drop, uint32_t seed,
+                              const float* d_resid, float* d_t_out, const float* d_gamma, const float* d_beta, float eps,
+                              float* d_z_f32, void* d_z_bf16, int M, int H, void* stream) {
+    if (M == 0) return AG_OK;
+    AG_REQUIRE(d_x && splits >= 1 && M > 0 && H > 0, "ag_rows_finish: bad arguments");
+    AG_REQUIRE(H % 4 == 0 && H <= 256 * MAXV, "ag_rows_finish: H=%d must be a multiple of 4 and <= %d", H, 256 * MAXV);
+    AG_REQUIRE(splits == 1 || slab_stride % 4 == 0, "ag_rows_finish: slab stride must be a multiple of 4 floats");
+    AG_REQUIRE(!d_gamma || d_beta, "ag_rows_finish: gamma without beta");
+    AG_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "ag_rows_finish: p_drop=%f", (double)p_drop);
+    RowsArgs a{d_x, splits, (long)slab_stride, d_bias, p_drop, seed, d_resid, d_t_out, d_gamma, d_beta, eps, d_z_f32, (bf16_t*)d_z_bf16, M, H};
+    const dim3 grid(ceil_div(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (ceil_div(H, 256)) {
+        case 1: hipLaunchKernelGGL(rows_finish_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(rows_finish_kernel<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(rows_finish_kernel<3>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(rows_finish_kernel<4>, grid, block, 0, s, a); break;
+    }
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" size_t ag_rows_ln_bwd_scratch_floats(int M, int H) {
+    const int blocks = M < 4 * 256 ? ceil_div(M, 4) : 256;
+    return (size_t)(blocks > 0 ? blocks : 1) * 3 * (size_t)H;
+}
+
+extern "C" int ag_rows_ln_bwd(const float* d_dy, int splits, int64_t slab_stride, const float* d_dy_add, const float* d_x,
+                              const float* d_gamma, float eps, const float* d_add, float* d_dx, void* d_dx_bf16, float p_drop,
+                              uint32_t seed, float* d_dgamma, float* d_dbeta, float* d_dbias, int accumulate, float* d_scratch, int M,
+                              int H, void* stream) {
+    if (M == 0) return AG_OK;
+    AG_REQUIRE(d_dy && splits >= 1 && M > 0 && H > 0, "ag_rows_ln_bwd: bad arguments");
+    AG_REQUIRE(H % 4 == 0 && H <= 256 * MAXV, "ag_rows_ln_bwd: H=%d must be a multiple of 4 and <= %d", H, 256 * MAXV);
+    AG_REQUIRE(splits == 1 || slab_stride % 4 == 0, "ag_rows_ln_bwd: slab stride must be a multiple of 4 floats");
+    AG_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "ag_rows_ln_bwd: p_drop=%f", (double)p_drop);
+    const bool want_part = d_dgamma || d_dbeta || d_dbias;
+    AG_REQUIRE(!want_part || d_scratch, "ag_rows_ln_bwd: column sums need d_scratch (ag_rows_ln_bwd_scratch_floats)");
+    AG_REQUIRE(!(d_dgamma || d_dbeta) || d_x, "ag_rows_ln_bwd: dgamma / dbeta without a LayerNorm (d_x == NULL)");
+    const int blocks = M < 4 * 256 ? ceil_div(M, 4) : 256;
+    LnBwdArgs a{d_dy, splits, (long)slab_stride, d_dy_add, d_x, d_gamma, eps, d_add, d_dx, (bf16_t*)d_dx_bf16, p_drop, seed,
+                want_part ? d_scratch : nullptr, M, H};
+    hipStream_t s = (hipStream_t)stream;
+    switch (ceil_div(H, 256)) {
+        case 1: hipLaunchKernelGGL(rows_ln_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(rows_ln_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(rows_ln_bwd_kernel<3>, dim3(blocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(rows_ln_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, a); break;
+    }
+    AG_LAUNCH_CHECK();
+    if (want_part) {
+        hipLaunchKernelGGL(part3_reduce_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, d_scratch, blocks, H, d_dgamma, d_dbeta, d_dbias, accumulate);
+        AG_LAUNCH_CHECK();
+    }
+    return AG_OK;
+}
+
+extern "C" int ag_slab_reduce(const float* d_slabs, int splits, int64_t slab_stride, int64_t n, float* d_dst, int accumulate, void* stream) {
+    if (n == 0) return AG_OK;
+    AG_REQUIRE(d_slabs && d_dst && splits >= 1 && n > 0, "ag_slab_reduce: bad arguments");
+    AG_REQUIRE(n % 4 == 0 && slab_stride % 4 == 0 && ((uintptr_t)d_dst % 16) == 0 && ((uintptr_t)d_slabs % 16) == 0,
+               "ag_slab_reduce: n and the slab stride must be multiples of 4 floats, pointers 16-byte aligned");
+    const long n4 = n / 4;
+    const int blocks = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_slabs, splits, (long)slab_stride, n4, d_dst, accumulate);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" size_t ag_colsum_bf16_scratch_floats(int M, int N) { return (size_t)ceil_div(M > 0 ? M : 1, 64) * (size_t)N; }
+
+extern "C" int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, float* d_scratch, void* stream) {
+    AG_REQUIRE(d_x && d_out && M >= 0 && N > 0, "ag_colsum_bf16: bad arguments");
+    AG_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)d_x % 16) == 0, "ag_colsum_bf16: N and ldx must be multiples of 8, x 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    // enough blocks to cover the chip: columns x row groups of >= 64 rows (partials folded by a second small launch when needed)
+    const int cb = ceil_div(N, 512);
+    int rg = 1;
+    if (d_scratch && M > 128) {
+        rg = ceil_div(256, cb);
+        const int rg_max = ceil_div(M, 64);
+        rg = rg < rg_max ? rg : rg_max;
+    }
+    const int rpb = ceil_div(M > 0 ? M : 1, rg);
+    rg = ceil_div(M > 0 ? M : 1, rpb);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cb, rg), dim3(256), 0, s, (const bf16_t*)d_x, M, N, (long)ldx, d_out, accumulate, rpb,
+                       rg > 1 ? d_scratch : nullptr);
+    AG_LAUNCH_CHECK();
+    if (rg > 1) {
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, d_scratch, rg, N, d_out, accumulate);
+        AG_LAUNCH_CHECK();
+    }
+    return AG_OK;
+}
+
+extern "C" int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count,
+                                void* stream) {
+    AG_REQUIRE(count >= 0 && (count == 0 || (h_src && h_dst && h_n && h_dst_dtype)), "ag_cast_f32_many: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < count; base += CAST_MAX) {
+        CastTable t;
+        t.count = count - base < CAST_MAX ? count - base : CAST_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            AG_REQUIRE(h_src[base + i] && h_dst[base + i] && h_n[base + i] >= 0, "ag_cast_f32_many: null segment %d", base + i);
+            AG_REQUIRE(((uintptr_t)h_src[base + i] % 16) == 0 && ((uintptr_t)h_dst[base + i] % 16) == 0,
+                       "ag_cast_f32_many: segment %d is not 16-byte aligned", base + i);
+            AG_REQUIRE(h_dst_dtype[base + i] == AG_BF16 || h_dst_dtype[base + i] == AG_F32, "ag_cast_f32_many: segment %d: bad dtype", base + i);
+            t.src[i] = h_src[base + i]; t.dst[i] = h_dst[base + i]; t.n[i] = h_n[base + i]; t.f32[i] = h_dst_dtype[base + i] == AG_F32;
+            t.first_block[i] = blocks;
+            blocks += (int)((h_n[base + i] + 4095) / 4096);
+        }
+        t.first_block[t.count] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(cast_many_kernel, dim3(blocks), dim3(256), 0, s, t);
+        AG_LAUNCH_CHECK();
+    }
+    return AG_OK;
+}

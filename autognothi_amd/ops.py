@@ -254,6 +254,51 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, dtype: int
     return out
 
 
+NT, NN, TN = (0, 0), (0, 1), (1, 1)   # ag_gemm_ex operand orders: Linear forward / dX / dW
+
+
+def gemm_ex_splits(m: int, n: int, kc: int) -> int:
+    return int(L.lib().ag_gemm_ex_splits(m, n, kc))
+
+
+def gemm_ex(a: Tensor, b: Tensor, order: Tuple[int, int] = NT, epilogue: int = L.AG_EX_STORE, bias: Optional[Tensor] = None,
+            out_dtype: int = BF16, aux: Optional[Tensor] = None, splits: Optional[int] = None, out: Optional[Tensor] = None):
+    """ag_gemm_ex on bf16 operands read in place.  order NT: a [M,Kc], b [N,Kc]; NN: a [M,Kc], b [Kc,N]; TN: a [Kc,M], b [Kc,N].
+    -> AG_EX_STORE: C [M,N] (out_dtype); AG_EX_GELU_DUAL: (pre bf16, gelu(pre) bf16); AG_EX_GELU_BWD: bf16 acc * gelu'(aux);
+    AG_EX_SLABS: fp32 [splits, M, N] partial sums (splits None: the library's recommendation)."""
+    L.require_gpu(a, b, bias, aux, out)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise TypeError("gemm_ex: operands must be bf16")
+    a_col, b_col = order
+    (kc, m) = a.shape if a_col else a.shape[::-1]
+    (kc2, n) = b.shape if b_col else b.shape[::-1]
+    if kc != kc2:
+        raise ValueError(f"gemm_ex: contraction lengths differ ({kc} vs {kc2})")
+    lda, ldb = a.stride(0), b.stride(0)
+    dev = a.device
+    out2 = None
+    slabs = None
+    if epilogue == L.AG_EX_SLABS:
+        splits = gemm_ex_splits(m, n, kc) if splits is None else splits
+        slabs = out if out is not None else torch.empty((splits, m, n), dtype=torch.float32, device=dev)
+        c, ldc = None, n
+    else:
+        splits = 1
+        c = out if out is not None else torch.empty((m, n), dtype=storage_dtype(out_dtype), device=dev)
+        ldc = c.stride(0)
+        if epilogue == L.AG_EX_GELU_DUAL:
+            out2 = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with L.on(dev):
+        L.check(L.lib().ag_gemm_ex(L.ptr(a), lda, a_col, L.ptr(b), ldb, b_col, m, n, kc, epilogue, L.ptr(bias), L.ptr(c), ldc,
+                                   out_dtype, L.ptr(aux), aux.stride(0) if aux is not None else 0, L.ptr(out2), n, splits,
+                                   L.ptr(slabs), L.stream()))
+    if epilogue == L.AG_EX_SLABS:
+        return slabs
+    if epilogue == L.AG_EX_GELU_DUAL:
+        return c, out2
+    return c
+
+
 def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r_stats: Tensor, ln_g: Tensor, ln_b: Tensor,
                   ln_eps: float, stats_out: Optional[Tensor] = None, rows_dev: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """A @ W^T + bias + LayerNorm(r_pre) with the LayerNorm recomputed in the epilogue from r_pre's slab statistics

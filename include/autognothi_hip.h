@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define AG_ABI_VERSION 2   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows) */
+#define AG_ABI_VERSION 3   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
+                            * 3: ag_gemm_ex + the fused training kernels (additions only) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
@@ -355,13 +356,81 @@ int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bit
                                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * GEMM for under-filled launches (round 4): the training step's Linear forward / dX / dW on B*T ~ 1-1.6 k rows (what torch.autograd
+ * runs for every nn.Linear in scripts/train_explainer.py:183-198, scripts/train_duo_explainer.py:180-198) and the masked forward
+ * at the reference's own batch sizes.  bf16 operands, fp32 accumulation:
+ *     C[M,N] = sum_kc A(m,kc) * B(n,kc)        Kc = contraction length
+ * with each operand read IN PLACE in either storage order (no transposed or re-cast copies):
+ *     a_col = 0: A stored [M, Kc], row stride lda       a_col = 1: A stored [Kc, M], row stride lda
+ *     b_col = 0: B stored [N, Kc] (torch [out,in])      b_col = 1: B stored [Kc, N]
+ *   Linear forward  Y  = X . W^T :  (A, B) = (X [M,K],  W [N,K]),  (a_col, b_col) = (0, 0)
+ *   Linear dX       dX = dY . W  :  (A, B) = (dY [M,N], W [N,K] read as [Kc=N, K]),  (0, 1)
+ *   Linear dW       dW = dY^T . X:  (A, B) = (dY [M,N] read as [Kc=M, N], X [M,K] read as [Kc=M, K]),  (1, 1); the result is [N, K]
+ * Work = 128 x 128 output tiles x `splits` contraction ranges, one workgroup each, so that a product with few tiles still covers
+ * the chip.  splits > 1 (epilogue AG_EX_SLABS only): unit s stores its fp32 partial tile into d_slabs [splits][M][N] (dense) with
+ * plain stores; the consumer (ag_rows_finish, ag_rows_ln_bwd, ag_slab_reduce, ...) adds the slabs in slab order — no atomics, no
+ * zero fill, bit-reproducible.  ag_gemm_ex_splits() is the split count the launch heuristics recommend for a shape.
+ * Epilogues with splits == 1:
+ *   AG_EX_STORE      C = acc + bias                     -> c_dtype (AG_BF16 / AG_F32), row stride ldc
+ *   AG_EX_GELU_DUAL  C = bf16(acc + bias), out2 = gelu(C)   (fc1: the backward needs the pre-activation, fc2 the activation)
+ *   AG_EX_GELU_BWD   C = bf16(acc * gelu'(aux))         aux = bf16 pre-activation [M, ld_aux]   (fc2's dX feeding fc1's backward)
+ * (bf16 GELU forms: |gelu - erf form| <= 1.7e-5, as ag_gemm's bf16 mode.)  Requirements: N, Kc, lda, ldb multiples of 8; M % 8 == 0
+ * when a_col; ldc % 4 == 0; 16-byte aligned pointers. */
+enum { AG_EX_STORE = 0, AG_EX_GELU_DUAL = 1, AG_EX_GELU_BWD = 2, AG_EX_SLABS = 3 };
+int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d_B, int64_t ldb, int b_col, int M, int N, int Kc,
+               int epilogue, const float* d_bias, void* d_C, int64_t ldc, int c_dtype, const void* d_aux, int64_t ld_aux,
+               void* d_out2, int64_t ld_out2, int splits, float* d_slabs, void* stream);
+int ag_gemm_ex_splits(int M, int N, int Kc);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels of the bf16 training step (round 4, csrc/train_fused.hip): the consumers of ag_gemm_ex's split-K slabs.  Each adds
+ * `splits` fp32 slabs [splits][M][H] (slab stride in floats; splits = 1: a plain fp32 [M,H] tensor) in slab order and does, in the
+ * same pass over the row, what the reference's autograd graph does between two Linear layers (models/vanilla_vit.py:364-377,
+ * models/vanilla_bert.py:410-427, :556-560, :600-604).  One wave per row, H % 4 == 0, H <= 1024, fp32 arithmetic.  The dropout keep
+ * decision is the counter hash of ag_dropout_f32 on the element index m*H + c.
+ * ---------------------------------------------------------------------------------------------- */
+/* t = resid + dropout(x + bias);  z = LayerNorm(t) (gamma NULL: z = t).  Outputs (each optional): d_t_out fp32 (the residual
+ * stream / the LayerNorm input the backward needs), d_z_f32, d_z_bf16 (the next GEMM's operand). */
+int ag_rows_finish(const float* d_x, int splits, int64_t slab_stride, const float* d_bias, float p_drop, uint32_t seed,
+                   const float* d_resid, float* d_t_out, const float* d_gamma, const float* d_beta, float eps,
+                   float* d_z_f32, void* d_z_bf16, int M, int H, void* stream);
+/* dy = x_slabs (+ d_dy_add);  dx = LayerNorm backward of dy at input rows d_x (d_x NULL: dx = dy)  (+ d_add: the gradient arriving
+ * over the residual branch).  Outputs (each optional): d_dx fp32; d_dx_bf16 = bf16(dropout'(dx; p_drop, seed)) — the dY operand of
+ * the Linear below; d_dgamma / d_dbeta [H]; d_dbias [H] = column sums of dropout'(dx) (that Linear's bias gradient); `accumulate`
+ * adds to the three instead of storing.  d_scratch: ag_rows_ln_bwd_scratch_floats(M, H) floats (per-block partials, folded in block
+ * order: bit-reproducible). */
+size_t ag_rows_ln_bwd_scratch_floats(int M, int H);
+int ag_rows_ln_bwd(const float* d_dy, int splits, int64_t slab_stride, const float* d_dy_add, const float* d_x, const float* d_gamma,
+                   float eps, const float* d_add, float* d_dx, void* d_dx_bf16, float p_drop, uint32_t seed, float* d_dgamma,
+                   float* d_dbeta, float* d_dbias, int accumulate, float* d_scratch, int M, int H, void* stream);
+/* dst[n] (+)= sum of slabs (a dW product split over the rows); n, slab_stride multiples of 4. */
+int ag_slab_reduce(const float* d_slabs, int splits, int64_t slab_stride, int64_t n, float* d_dst, int accumulate, void* stream);
+/* out[N] (+)= column sums of a bf16 [M,N] matrix (the bias gradient of a dY that a GEMM / attention epilogue produced);
+ * N, ldx multiples of 8; d_scratch (optional, ag_colsum_bf16_scratch_floats) lets the launch spread rows over the chip. */
+size_t ag_colsum_bf16_scratch_floats(int M, int N);
+int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, float* d_scratch, void* stream);
+/* `count` fp32 -> bf16 conversions (h_dst_dtype[i] = AG_BF16) or fp32 copies (AG_F32) in ONE launch per 96 segments: every
+ * weight of a model after the optimiser step, q | k | v landing side by side in their fused buffer.  HOST arrays of DEVICE pointers
+ * (passed to the kernel by value: no table copy, graph-capturable); segments 16-byte aligned. */
+int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, void* stream);
+/* Masked attention of the bf16 training step on the matrix cores (the kernel of ag_masked_attention_*_mixed with bf16 I/O):
+ * qkv [R,T,3H] bf16 -> ctx [R,T,H] bf16, attention-probability dropout (p_drop, seed) as ag_masked_attention_train; backward:
+ * dqkv [R,T,3H] bf16 from d_dctx given as `dslabs` fp32 slabs [dslabs][R*T][H] (ag_gemm_ex's split-K partials of the
+ * out-projection dX), added in slab order on load.  head_dim 64, T <= 256. */
+int ag_masked_attention_train_bf16(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H, int heads,
+                                   int mask_mode, float p_drop, uint32_t seed, void* stream);
+int ag_masked_attention_bwd_bf16(const void* d_qkv, const uint32_t* d_mask_bits, const float* d_dctx, int dslabs, int64_t dslab_stride,
+                                 void* d_dqkv, int R, int T, int H, int heads, int mask_mode, float p_drop, uint32_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * In-library kernel timing (used by bench.py for the roofline block): when enabled, every launch of
  * an instrumented kernel class is bracketed by hipEvents on the launch stream.  ag_profile_collect
  * synchronises those events, returns the totals of one class since the last collect and clears it.
- * Classes: 0..4 = ag_gemm by epilogue (AG_EPI_*), 8 = ag_masked_attention, 9 = ag_layernorm.
+ * Classes: 0..4 = ag_gemm by epilogue (AG_EPI_*), 8 = ag_masked_attention, 9 = ag_layernorm, 10 = ag_gemm_ex.
  * ---------------------------------------------------------------------------------------------- */
 #define AG_PROF_ATTENTION 8
 #define AG_PROF_LAYERNORM 9
+#define AG_PROF_GEMM_EX 10   /* ag_gemm_ex */
 int ag_profile_enable(int on);
 int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 
