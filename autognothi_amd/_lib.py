@@ -62,6 +62,7 @@ SIGNATURES = {
     "ag_colsum_bf16_scratch_floats": (sz, [i32, i32]),
     "ag_colsum_bf16": (i32, [vp, i32, i32, i64, vp, i32, vp, vp]),
     "ag_cast_f32_many": (i32, [vp, vp, vp, vp, i32, vp]),
+    "ag_pad_cols_f32": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, vp]),
     "ag_masked_attention_train_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_masked_attention_bwd_bf16": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ag_probe_mfma": (i32, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_probe_dma": (i32, [i32, i32, i32, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_probe_store": (i32, [i32, i32, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
+    "ag_launch_count": (i64, []),
     "ag_profile_enable": (i32, [i32]),
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),

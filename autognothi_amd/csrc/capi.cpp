@@ -20,6 +20,9 @@ int ag_fail(int code, const char* fmt, ...) {
 
 extern "C" int ag_abi_version(void) { return AG_ABI_VERSION; }
 
+long long g_ag_launch_count = 0;
+extern "C" int64_t ag_launch_count(void) { return (int64_t)g_ag_launch_count; }
+
 int g_ag_knob_epoch = 1;
 extern "C" int ag_reload_knobs(void) {
     ++g_ag_knob_epoch;

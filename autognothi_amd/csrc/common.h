@@ -22,7 +22,12 @@ int ag_fail(int code, const char* fmt, ...);
         if (_e != hipSuccess)                                                                      \
             return ag_fail(AG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
-#define AG_LAUNCH_CHECK() AG_HIP_CHECK(hipGetLastError())
+extern long long g_ag_launch_count;   // capi.cpp: kernels this library has launched (ag_launch_count)
+#define AG_LAUNCH_CHECK()                      \
+    do {                                       \
+        ++g_ag_launch_count;                   \
+        AG_HIP_CHECK(hipGetLastError());       \
+    } while (0)
 #define AG_REQUIRE(cond, ...)                                                                      \
     do {                                                                                           \
         if (!(cond)) return ag_fail(AG_ERR_INVALID, __VA_ARGS__);                                  \

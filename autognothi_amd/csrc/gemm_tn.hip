@@ -302,8 +302,10 @@ extern "C" int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d
     if (M == 0 || N == 0) return AG_OK;
     AG_REQUIRE(d_A && d_B, "ag_gemm_ex: null operand");
     AG_REQUIRE(M > 0 && N > 0 && Kc > 0, "ag_gemm_ex: bad shape M=%d N=%d Kc=%d", M, N, Kc);
-    AG_REQUIRE(N % 8 == 0 && Kc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "ag_gemm_ex: N, Kc and the operand row strides must be multiples of 8 "
+    AG_REQUIRE(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "ag_gemm_ex: N and the operand row strides must be multiples of 8 "
                "(M=%d N=%d Kc=%d lda=%ld ldb=%ld)", M, N, Kc, (long)lda, (long)ldb);
+    // (a row-stored operand is staged in 16-byte chunks along the contraction; a column-stored one row by row: any Kc)
+    AG_REQUIRE((a_col && b_col) || Kc % 8 == 0, "ag_gemm_ex: Kc=%d must be a multiple of 8 unless both operands are stored [Kc, .]", Kc);
     AG_REQUIRE(!a_col || M % 8 == 0, "ag_gemm_ex: a transposed A needs M %% 8 == 0 (M=%d)", M);
     AG_REQUIRE((a_col == 0 || a_col == 1) && (b_col == 0 || b_col == 1) && !(a_col && !b_col),
                "ag_gemm_ex: operand orders (a_col, b_col) in {(0,0), (0,1), (1,1)}");

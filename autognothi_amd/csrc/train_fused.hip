@@ -229,27 +229,30 @@ __global__ __launch_bounds__(256) void rows_ln_bwd_kernel(LnBwdArgs p) {
     }
 }
 
-// out_k[c] (+)= sum over blocks of part[b][k][c], k = 0..2 (any out may be NULL); 64 columns x 4 partial lanes per block
+// out_k[c] (+)= sum over blocks of part[b][k][c], k = 0..2 (any out may be NULL).  grid = (ceil(H / 32), 3 kinds); a block = 32 columns x 8
+// partial lanes, each lane walks every 8th partial with four loads in flight; the eight lanes are folded in a fixed order
 __global__ __launch_bounds__(256) void part3_reduce_kernel(const float* __restrict__ part, int nblocks, int H, float* o0, float* o1, float* o2,
                                                            int accumulate) {
-    __shared__ float sa[3][4][64];
-    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    float a[3] = {0.f, 0.f, 0.f};
-    if (c < H)
-        for (int i = q; i < nblocks; i += 4)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a[k] += part[((long)i * 3 + k) * H + c];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sa[k][q][cl] = a[k];
+    __shared__ float sa[8][32];
+    const int kind = blockIdx.y;
+    float* out = kind == 0 ? o0 : (kind == 1 ? o1 : o2);
+    if (!out) return;
+    const int cl = threadIdx.x & 31, q = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < H) {
+        const float* base = part + (long)kind * H + c;
+        const long st = (long)3 * H;
+        int i = q;
+        for (; i + 24 < nblocks; i += 32) {
+            a0 += base[(long)i * st]; a1 += base[(long)(i + 8) * st]; a2 += base[(long)(i + 16) * st]; a3 += base[(long)(i + 24) * st];
+        }
+        for (; i < nblocks; i += 8) a0 += base[(long)i * st];
+    }
+    sa[q][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (q == 0 && c < H) {
-        float* outs[3] = {o0, o1, o2};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (!outs[k]) continue;
-            const float t = (sa[k][0][cl] + sa[k][1][cl]) + (sa[k][2][cl] + sa[k][3][cl]);
-            outs[k][c] = accumulate ? outs[k][c] + t : t;
-        }
+        const float t = ((sa[0][cl] + sa[1][cl]) + (sa[2][cl] + sa[3][cl])) + ((sa[4][cl] + sa[5][cl]) + (sa[6][cl] + sa[7][cl]));
+        out[c] = accumulate ? out[c] + t : t;
     }
 }
 
@@ -347,7 +350,35 @@ __global__ __launch_bounds__(256) void cast_many_kernel(const CastTable t) {
     }
 }
 
+// dst[m][c] = c < cols_src ? src[m][c] : 0 for c < cols_dst (fp32 or bf16 destination): pads the C-wide head output / gradient
+// (C = 10 or 2 classes) to the 16 columns the GEMM wants, or strips the padding again
+template <typename TD>
+__global__ void pad_cols_kernel(const float* __restrict__ src, long ld_s, int cols_src, TD* __restrict__ dst, long ld_d, int cols_dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cols_dst;
+        const int c = (int)(i - m * cols_dst);
+        const float v = c < cols_src ? src[m * ld_s + c] : 0.f;
+        Store<TD>::store(dst + m * ld_d + c, v);
+    }
+}
+
 }  // namespace
+
+extern "C" int ag_pad_cols_f32(const float* d_src, int64_t ld_src, int cols_src, void* d_dst, int64_t ld_dst, int cols_dst, int dst_dtype,
+                               int M, void* stream) {
+    AG_REQUIRE(d_src && d_dst && M >= 0 && cols_src > 0 && cols_dst > 0 && ld_src >= cols_src && ld_dst >= cols_dst, "ag_pad_cols_f32: bad arguments");
+    AG_REQUIRE(dst_dtype == AG_F32 || dst_dtype == AG_BF16, "ag_pad_cols_f32: bad dtype %d", dst_dtype);
+    if (M == 0) return AG_OK;
+    const long n = (long)M * cols_dst;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const int cs = cols_src < cols_dst ? cols_src : cols_dst;
+    if (dst_dtype == AG_F32)
+        hipLaunchKernelGGL(pad_cols_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_src, (long)ld_src, cs, (float*)d_dst, (long)ld_dst, cols_dst, n);
+    else
+        hipLaunchKernelGGL(pad_cols_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_src, (long)ld_src, cs, (bf16_t*)d_dst, (long)ld_dst, cols_dst, n);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
 
 extern "C" int ag_rows_finish(const float* d_x, int splits, int64_t slab_stride, const float* d_bias, float p_drop, uint32_t seed,
                               const float* d_resid, float* d_t_out, const float* d_gamma, const float* d_beta, float eps,
@@ -371,8 +402,9 @@ extern "C" int ag_rows_finish(const float* d_x, int splits, int64_t slab_stride,
     return AG_OK;
 }
 
+static int ln_bwd_blocks(int M) { return M < 4 * 256 ? ceil_div(M, 4) : 256; }
 extern "C" size_t ag_rows_ln_bwd_scratch_floats(int M, int H) {
-    const int blocks = M < 4 * 256 ? ceil_div(M, 4) : 256;
+    const int blocks = ln_bwd_blocks(M);
     return (size_t)(blocks > 0 ? blocks : 1) * 3 * (size_t)H;
 }
 
@@ -388,7 +420,7 @@ extern "C" int ag_rows_ln_bwd(const float* d_dy, int splits, int64_t slab_stride
     const bool want_part = d_dgamma || d_dbeta || d_dbias;
     AG_REQUIRE(!want_part || d_scratch, "ag_rows_ln_bwd: column sums need d_scratch (ag_rows_ln_bwd_scratch_floats)");
     AG_REQUIRE(!(d_dgamma || d_dbeta) || d_x, "ag_rows_ln_bwd: dgamma / dbeta without a LayerNorm (d_x == NULL)");
-    const int blocks = M < 4 * 256 ? ceil_div(M, 4) : 256;
+    const int blocks = ln_bwd_blocks(M);
     LnBwdArgs a{d_dy, splits, (long)slab_stride, d_dy_add, d_x, d_gamma, eps, d_add, d_dx, (bf16_t*)d_dx_bf16, p_drop, seed,
                 want_part ? d_scratch : nullptr, M, H};
     hipStream_t s = (hipStream_t)stream;
@@ -400,7 +432,7 @@ extern "C" int ag_rows_ln_bwd(const float* d_dy, int splits, int64_t slab_stride
     }
     AG_LAUNCH_CHECK();
     if (want_part) {
-        hipLaunchKernelGGL(part3_reduce_kernel, dim3(ceil_div(H, 64)), dim3(256), 0, s, d_scratch, blocks, H, d_dgamma, d_dbeta, d_dbias, accumulate);
+        hipLaunchKernelGGL(part3_reduce_kernel, dim3(ceil_div(H, 32), 3), dim3(256), 0, s, d_scratch, blocks, H, d_dgamma, d_dbeta, d_dbias, accumulate);
         AG_LAUNCH_CHECK();
     }
     return AG_OK;

@@ -96,9 +96,13 @@ def watch_optimizer(optimizer) -> None:
         return
 
     def bump(opt, *args, **kwargs):
+        # only what the step UPDATED: torch's optimisers skip parameters whose .grad is None, and the entry points hand
+        # `m_explainer.parameters()` — frozen froyo / LTT backbones included — to AdamW; bumping those would rebuild every pack
+        # of the frozen weights (and re-capture every GraphedStep) after each step
         for group in opt.param_groups:
             for q in group["params"]:
-                q.__dict__["_ag_step"] = q.__dict__.get("_ag_step", 0) + 1
+                if q.grad is not None:
+                    q.__dict__["_ag_step"] = q.__dict__.get("_ag_step", 0) + 1
     optimizer.register_step_post_hook(bump)
     optimizer._ag_watched = True
 

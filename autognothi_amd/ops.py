@@ -299,6 +299,135 @@ def gemm_ex(a: Tensor, b: Tensor, order: Tuple[int, int] = NT, epilogue: int = L
     return c
 
 
+_SCRATCH = {}
+
+
+def _scratch(dev, floats: int) -> Tensor:
+    """a grow-only fp32 scratch buffer per device (per-block partials of the row kernels; consumed inside the call that fills it)."""
+    key = str(dev)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=dev)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def rows_finish(x: Tensor, bias: Optional[Tensor] = None, p_drop: float = 0.0, seed: int = 0, resid: Optional[Tensor] = None,
+                ln: Optional[Tuple[Tensor, Tensor, float]] = None, want_t: bool = False, want_f32: bool = False,
+                want_bf16: bool = True):
+    """ag_rows_finish.  x: fp32 [M,H] or split-K slabs [S,M,H].  t = resid + dropout(x + bias); z = LayerNorm(t) (ln None: z = t).
+    -> (t fp32 or None, z fp32 or None, z bf16 or None)."""
+    L.require_gpu(x, bias, resid)
+    splits = x.shape[0] if x.dim() == 3 else 1
+    m, h = x.shape[-2], x.shape[-1]
+    dev = x.device
+    t = torch.empty((m, h), dtype=torch.float32, device=dev) if want_t else None
+    zf = torch.empty((m, h), dtype=torch.float32, device=dev) if want_f32 else None
+    zb = torch.empty((m, h), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    with L.on(dev):
+        L.check(L.lib().ag_rows_finish(L.ptr(x), splits, m * h, L.ptr(bias), float(p_drop), seed & 0xFFFFFFFF, L.ptr(resid), L.ptr(t),
+                                       L.ptr(g), L.ptr(b), float(eps), L.ptr(zf), L.ptr(zb), m, h, L.stream()))
+    return t, zf, zb
+
+
+def rows_ln_bwd(dy: Tensor, x: Optional[Tensor] = None, gamma: Optional[Tensor] = None, eps: float = 0.0,
+                dy_add: Optional[Tensor] = None, add: Optional[Tensor] = None, want_dx: bool = True, want_bf16: bool = False,
+                p_drop: float = 0.0, seed: int = 0, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+                dbias: Optional[Tensor] = None, accumulate: bool = False):
+    """ag_rows_ln_bwd.  dy: fp32 [M,H] or slabs [S,M,H] (+ dy_add); dx = LayerNorm backward at rows x (x None: dx = dy) (+ add).
+    -> (dx fp32 or None, bf16(dropout'(dx)) or None); dgamma / dbeta / dbias [H] are written (or accumulated) when given."""
+    L.require_gpu(dy, x, gamma, dy_add, add)
+    splits = dy.shape[0] if dy.dim() == 3 else 1
+    m, h = dy.shape[-2], dy.shape[-1]
+    dev = dy.device
+    dx = torch.empty((m, h), dtype=torch.float32, device=dev) if want_dx else None
+    dxb = torch.empty((m, h), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    need = dgamma is not None or dbeta is not None or dbias is not None
+    scratch = _scratch(dev, int(L.lib().ag_rows_ln_bwd_scratch_floats(m, h))) if need else None
+    with L.on(dev):
+        L.check(L.lib().ag_rows_ln_bwd(L.ptr(dy), splits, m * h, L.ptr(dy_add), L.ptr(x), L.ptr(gamma), float(eps), L.ptr(add), L.ptr(dx),
+                                       L.ptr(dxb), float(p_drop), seed & 0xFFFFFFFF, L.ptr(dgamma), L.ptr(dbeta), L.ptr(dbias),
+                                       1 if accumulate else 0, L.ptr(scratch), m, h, L.stream()))
+    return dx, dxb
+
+
+def slab_reduce(slabs: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """sum of split-K slabs [S, ...] -> fp32 [...] (written into ``out`` / added to it)."""
+    L.require_gpu(slabs, out)
+    splits = slabs.shape[0]
+    n = slabs[0].numel()
+    if out is None:
+        out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    with L.on(slabs.device):
+        L.check(L.lib().ag_slab_reduce(L.ptr(slabs), splits, n, n, L.ptr(out), 1 if accumulate else 0, L.stream()))
+    return out
+
+
+def colsum_bf16(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """column sums of a bf16 [M,N] matrix -> fp32 [N]."""
+    L.require_gpu(x, out)
+    m, n = x.shape
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+    scratch = _scratch(x.device, int(L.lib().ag_colsum_bf16_scratch_floats(m, n)))
+    with L.on(x.device):
+        L.check(L.lib().ag_colsum_bf16(L.ptr(x), m, n, x.stride(0), L.ptr(out), 1 if accumulate else 0, L.ptr(scratch), L.stream()))
+    return out
+
+
+def cast_many(pairs) -> None:
+    """[(src fp32 tensor, dst bf16 or fp32 tensor of the same numel)] -> one ag_cast_f32_many launch (per 96 segments)."""
+    import ctypes as C
+    pairs = [(s_, d_) for s_, d_ in pairs if s_.numel() > 0]
+    if not pairs:
+        return
+    n = len(pairs)
+    L.require_gpu(*[t_ for pr in pairs for t_ in pr])
+    src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
+    dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
+    cnt = (C.c_int64 * n)(*[s_.numel() for s_, _ in pairs])
+    dty = (C.c_int * n)(*[(F32 if d_.dtype == torch.float32 else BF16) for _, d_ in pairs])
+    for s_, d_ in pairs:
+        if s_.dtype != torch.float32 or not s_.is_contiguous() or not d_.is_contiguous() or d_.numel() != s_.numel():
+            raise ValueError("cast_many: sources must be contiguous fp32, destinations contiguous with the same element count")
+    with L.on(pairs[0][0].device):
+        L.check(L.lib().ag_cast_f32_many(src, dst, cnt, dty, n, L.stream()))
+
+
+def pad_cols(src: Tensor, cols_dst: int, dtype: int = F32) -> Tensor:
+    """fp32 [M, ld >= C] (first C columns) -> dense [M, cols_dst] fp32 / bf16, zero-filled beyond C (or cut to cols_dst < C)."""
+    L.require_gpu(src)
+    m = src.shape[0]
+    out = torch.empty((m, cols_dst), dtype=storage_dtype(dtype), device=src.device)
+    with L.on(src.device):
+        L.check(L.lib().ag_pad_cols_f32(L.ptr(src), src.stride(0), src.shape[1], L.ptr(out), cols_dst, cols_dst, dtype, m, L.stream()))
+    return out
+
+
+def masked_attention_train_bf16(qkv: Tensor, mask_bits: Tensor, rows: int, t: int, h: int, heads: int, mask_mode: int,
+                                p_drop: float = 0.0, seed: int = 0) -> Tensor:
+    """bf16 qkv [rows*t, 3h] -> bf16 ctx [rows*t, h] (MFMA attention of the bf16 training step; head dim 64, t <= 256)."""
+    L.require_gpu(qkv, mask_bits)
+    ctx = torch.empty((rows * t, h), dtype=torch.bfloat16, device=qkv.device)
+    with L.on(qkv.device):
+        L.check(L.lib().ag_masked_attention_train_bf16(L.ptr(qkv), L.ptr(mask_bits), L.ptr(ctx), rows, t, h, heads, mask_mode,
+                                                       float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+    return ctx
+
+
+def masked_attention_bwd_bf16(qkv: Tensor, mask_bits: Tensor, dctx: Tensor, rows: int, t: int, h: int, heads: int, mask_mode: int,
+                              p_drop: float = 0.0, seed: int = 0) -> Tensor:
+    """dqkv bf16 [rows*t, 3h] from dctx fp32 [rows*t, h] or split-K slabs [S, rows*t, h]."""
+    L.require_gpu(qkv, mask_bits, dctx)
+    splits = dctx.shape[0] if dctx.dim() == 3 else 1
+    dqkv = torch.empty((rows * t, 3 * h), dtype=torch.bfloat16, device=qkv.device)
+    with L.on(qkv.device):
+        L.check(L.lib().ag_masked_attention_bwd_bf16(L.ptr(qkv), L.ptr(mask_bits), L.ptr(dctx), splits, rows * t * h, L.ptr(dqkv), rows, t, h,
+                                                     heads, mask_mode, float(p_drop), seed & 0xFFFFFFFF, L.stream()))
+    return dqkv
+
+
 def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r_stats: Tensor, ln_g: Tensor, ln_b: Tensor,
                   ln_eps: float, stats_out: Optional[Tensor] = None, rows_dev: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """A @ W^T + bias + LayerNorm(r_pre) with the LayerNorm recomputed in the epilogue from r_pre's slab statistics

@@ -53,6 +53,38 @@ class MaskSource:
         return ops.mask_purely_uniform_rows(self.rng, n_inputs_total, lo, hi, n_players, want_i64=False, want_bits=True)[1]
 
 
+class Span:
+    """This rank's part of one global batch of ``n_tot`` inputs x ``k`` masks.
+    mode "input": inputs [lo, hi) with all k masks each (the default: layer-0 sharing, normalisation and the loss stay
+    rank-local).  mode "mask" — fewer inputs than ranks (the ragged tail of an epoch, BASELINE config 4 at one input per step):
+    EVERY input, masks [k_lo, k_hi) of each; lo, hi = 0, n_tot."""
+    __slots__ = ("n_tot", "lo", "hi", "mode", "k", "k_lo", "k_hi")
+
+    def __init__(self, n_tot: int, lo: int, hi: int, mode: str = "input", k: int = 1, k_lo: int = 0, k_hi: int = 0):
+        self.n_tot, self.lo, self.hi, self.mode, self.k, self.k_lo, self.k_hi = n_tot, lo, hi, mode, k, k_lo, k_hi
+
+    @property
+    def by_mask(self) -> bool:
+        return self.mode == "mask"
+
+    def astuple(self):
+        return (self.n_tot, self.lo, self.hi)
+
+
+def shard_auto(xs, zs, k: int):
+    """``shard`` with the fall-back of SURVEY §8e: a batch with fewer inputs than ranks is split by MASK inside every input
+    (every rank keeps all inputs and takes a slice of the k masks of each), so that no rank idles; needs k >= ranks.
+    -> (xs_local, zs_local, Span)."""
+    from .. import distributed
+    n = xs.shape[0]
+    _, w = distributed.world()
+    if w > 1 and 0 < n < w and k >= w:
+        k_lo, k_hi = distributed.shard_range(k)
+        return xs, zs, Span(n, 0, n, "mask", k, k_lo, k_hi)
+    xs_l, zs_l, n_tot, lo, hi = shard(xs, zs)
+    return xs_l, zs_l, Span(n_tot, lo, hi, "input", k)
+
+
 def mask_source(holder: Any, device: torch.device, seed: Optional[int]) -> MaskSource:
     """the epoch's MaskSource on the (holder, device) generator of ``device_rng`` (reseeded when `seed` is given)."""
     return MaskSource(device_rng(holder, device, seed))

@@ -33,9 +33,13 @@ def explain(recipe: ModelRecipe, m_final, xs: Tensor) -> Tensor:
     return attr
 
 
-def infer_perturbed(recipe: ModelRecipe, m_surrogate, xs: Tensor, explanation: Tensor, steps: int) -> Tuple[CurvePoint, CurvePoint]:
+def infer_perturbed(recipe: ModelRecipe, m_surrogate, xs: Tensor, explanation: Tensor, steps: int,
+                    shard_rows: bool = False) -> Tuple[CurvePoint, CurvePoint]:
     """reference _infer (:183-221) for mask_base 0 (insertion) and 1 (deletion) at once.
-    xs [1, ...]; explanation [1, C, P] -> (insertion curves, deletion curves)."""
+    xs [1, ...]; explanation [1, C, P] -> (insertion curves, deletion curves).
+    ``shard_rows`` (N > 1 ranks, every rank calling with the SAME sample: fewer samples than ranks): this rank evaluates its
+    contiguous slice of the 2*C*S perturbation rows of the one input — the K-within-image split of SURVEY §8e — and the rows are
+    all-gathered (C floats each), so every rank returns the full curves."""
     _, n_classes, n_players = explanation.shape
     attr = explanation[0].contiguous().float()                       # [C, P]
     stops, m_ins = ops.perturbed_masks(attr, steps, 0)               # [S], [C, S, P]
@@ -43,8 +47,15 @@ def infer_perturbed(recipe: ModelRecipe, m_surrogate, xs: Tensor, explanation: T
     s = stops.shape[0]
     masks = torch.cat([m_ins.reshape(n_classes * s, n_players), m_del.reshape(n_classes * s, n_players)], dim=0)
     m_surrogate.eval()
+    _, n_ranks = distributed.world()
     with torch.no_grad():
-        ys, _ = recipe.fw_surrogate(m_surrogate, xs, masks)          # one input, 2*C*S mask rows
+        if shard_rows and n_ranks > 1:
+            spans = [distributed.shard_range(masks.shape[0], q, n_ranks) for q in range(n_ranks)]
+            lo, hi = spans[distributed.world()[0]]
+            ys_loc, _ = recipe.fw_surrogate(m_surrogate, xs, masks[lo:hi].contiguous())
+            ys = distributed.gather_rows(ys_loc.contiguous(), [h_ - l_ for l_, h_ in spans])
+        else:
+            ys, _ = recipe.fw_surrogate(m_surrogate, xs, masks)      # one input, 2*C*S mask rows
     ys = ys.reshape(2, n_classes, s, -1).cpu().numpy()
     stops_l = stops.cpu().numpy().tolist()
     out: List[CurvePoint] = []
@@ -92,22 +103,40 @@ def measure_faithfulness_loaded(env: Any, device: torch.device, recipe: ModelRec
                                 resolution: int) -> Dict[str, Any]:
     """reference measure_faithfulness (:41-140) given loaded models and a test iterator of single samples.
     Returns the report fields (insertion / deletion AUC for target and non-target classes + raw curves).
-    N > 1 ranks (the per-image loop :195-218 shards by image): every rank walks the same iterator, evaluates
-    sample i iff i % world == rank, and the per-sample curves are gathered (host objects, a few KB each) and re-ordered by
-    sample index, so every rank returns the single-process report."""
+    N > 1 ranks (the per-image loop :195-218): every rank walks the same iterator in groups of `ranks` samples and
+    evaluates sample `rank` of each full group (sharding by image: no collective per sample); a last group with FEWER samples
+    than ranks is sharded inside the image instead — every rank runs its slice of the 2*C*S perturbation rows of every remaining
+    sample and the rows are all-gathered — so no rank idles on the tail.  The per-sample curves are gathered (host objects, a
+    few KB each) and re-ordered by sample index: every rank returns the single-process report."""
     env = distributed.main_only(env) or Log()
     rank, n_ranks = distributed.world()
     mine: List[Tuple[int, int, CurvePoint, CurvePoint]] = []
-    for i, (_inputs, _targets) in enumerate(samples):
-        if i % n_ranks != rank:
-            continue
-        xs, zs = gen_input(_inputs, _targets)
-        ok_cls = int(zs.item())
-        explanation = explain(recipe, m_final, xs)
-        ins_curve, del_curve = infer_perturbed(recipe, m_surrogate, xs, explanation, resolution)
-        mine.append((i, ok_cls, ins_curve, del_curve))
-        if n_ranks == 1:
-            env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
+
+    def groups(it):
+        """the sample stream in groups of `ranks` samples (one per rank); the last group may be short"""
+        buf = []
+        for item in enumerate(it):
+            buf.append(item)
+            if len(buf) == n_ranks:
+                yield buf
+                buf = []
+        if buf:
+            yield buf
+
+    for group in groups(samples):
+        if len(group) == n_ranks:       # one sample per rank (by image: no collective per sample)
+            todo, split = [group[rank]], False
+        else:                           # fewer samples than ranks (the tail): every rank works on every sample, rows split
+            todo, split = group, True
+        for i, (_inputs, _targets) in todo:
+            xs, zs = gen_input(_inputs, _targets)
+            ok_cls = int(zs.item())
+            explanation = explain(recipe, m_final, xs)
+            ins_curve, del_curve = infer_perturbed(recipe, m_surrogate, xs, explanation, resolution, shard_rows=split)
+            if not split or rank == 0:
+                mine.append((i, ok_cls, ins_curve, del_curve))
+            if n_ranks == 1:
+                env.log(f"> sample {i}: ok_cls {ok_cls}, ins^ {auc(ins_curve[ok_cls]):.6f}, del^ {auc(del_curve[ok_cls]):.6f}")
     everything = sorted((item for part in distributed.gather_objects(mine) for item in part), key=lambda it: it[0])
     ok_cls_l: List[int] = [it[1] for it in everything]
     ins_curves: List[CurvePoint] = [it[2] for it in everything]

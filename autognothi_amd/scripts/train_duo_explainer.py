@@ -12,7 +12,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, MaskSource, mask_source as common_mask_source, shard
+from .common import Log, MaskSource, mask_source as common_mask_source, shard_auto
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -51,9 +51,9 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
         group, rows = [], 0
         for idx, (_inputs, _targets) in enumerate(items):
             xs_, zs_ = gen_input(_inputs, _targets)
-            xs_, zs_, n_tot, lo, hi = shard(xs_, zs_)
-            group.append((idx, xs_, zs_, (n_tot, lo, hi)))
-            rows += xs_.shape[0] * n_mask_samples
+            xs_, zs_, sp_ = shard_auto(xs_, zs_, n_mask_samples)
+            group.append((idx, xs_, zs_, sp_))
+            rows += xs_.shape[0] * ((sp_.k_hi - sp_.k_lo) if sp_.by_mask else n_mask_samples)
             if rows >= target_rows:
                 yield group
                 group, rows = [], 0
@@ -63,8 +63,19 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
     for group in grouped(d_items):
         tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
                                          spans=[g_[3] for g_ in group])
-        for (batch_idx, xs, zs, (n_tot, lo, hi)), (bits, v_s, v_1) in zip(group, tg):
+        for (batch_idx, xs, zs, sp), (bits, v_s, v_1) in zip(group, tg):
             optimizer.zero_grad()
+            n_tot, lo, hi = sp.astuple()
+            if sp.by_mask:
+                # fewer inputs than ranks (common.shard_auto): targets sharded by mask and gathered; every rank takes the same
+                # step on the whole batch — no gradient exchange, no idle rank; each rank reports 1 / ranks of the batch
+                trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True, seed=(seed or 0) + epoch)
+                optimizer.step()
+                l_shap, l_cls, base = trainer.last_parts
+                hits = base.argmax(dim=1).eq(zs.to(base.device)).sum().float()
+                parts.append(torch.stack([l_cls.reshape(()).float(), l_shap.reshape(()).float(), hits]) / n_ranks)
+                total += n_tot / float(n_ranks)
+                continue
             weight = (hi - lo) / float(n_tot)
             ragged = n_tot < n_ranks
             if reducer is not None:
@@ -91,7 +102,7 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
                         f"tot {(c_ + s_) / xs.shape[0]:.6f}")
     sums = [float(v) for v in torch.stack(parts).sum(0).tolist()] if parts else [0.0, 0.0, 0.0]
     cls_loss, reg_loss, correct, total = distributed.reduce_scalars(sums + [total], device)
-    total = int(total)
+    total = int(round(total))
     if total == 0:
         return 0.0, 0.0, 0.0, 0.0
     env.log(f"  > epoch {epoch} :train // loss: cls {cls_loss / total:.6f} shap {reg_loss / total:.6f} "
@@ -113,21 +124,24 @@ def duo_explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int
     total = 0
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, zs = gen_input(_inputs, _targets)
-        xs, zs, n_tot, lo, hi = shard(xs, zs)
-        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=(n_tot, lo, hi))
+        xs, zs, sp = shard_auto(xs, zs, n_mask_samples)
+        n_tot, lo, hi = sp.astuple()
+        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=sp)
         if hi == lo:
             continue
-        wl = 1.0 if n_ranks == 1 else (hi - lo) / float(n_tot)
+        wl = 1.0 if n_ranks == 1 else ((1.0 / n_ranks) if sp.by_mask else (hi - lo) / float(n_tot))
         l_shap, _, _, base = explainer_batch_loss(m_recipe, m_explainer, xs, bits, v_0, v_s, v_1, n_mask_samples, n_players)
         if base is None:
             raise ValueError("duo_explainer_epoch_eval: fw_explainer returned no class output (not a duo recipe)")
         l_cls = _cross_entropy_value(base, zs.to(base.device))
         hits = base.argmax(dim=1).eq(zs.to(base.device)).sum().float()
+        if sp.by_mask:      # every rank evaluated the whole batch: each reports 1 / ranks of its hits and samples
+            hits = hits / n_ranks
         parts.append(torch.stack([l_cls.reshape(()).float() * wl, l_shap.reshape(()).float() * wl, hits]))
-        total += xs.shape[0]
+        total += (n_tot / float(n_ranks)) if sp.by_mask else xs.shape[0]
     sums = [float(v) for v in torch.stack(parts).sum(0).tolist()] if parts else [0.0, 0.0, 0.0]
     cls_loss, reg_loss, correct, total = distributed.reduce_scalars(sums + [total], device)
-    total = int(total)
+    total = int(round(total))
     if total == 0:
         return 0.0, 0.0, 0.0, 0.0, []
     env.log(f"  > epoch {epoch} :test // loss: cls {cls_loss / total:.6f} shap {reg_loss / total:.6f} "

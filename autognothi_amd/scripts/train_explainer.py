@@ -17,7 +17,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, MaskSource, device_rng, shard
+from .common import Log, MaskSource, Span, device_rng, shard, shard_auto
 from .common import mask_source as common_mask_source
 
 
@@ -35,15 +35,44 @@ def _source(rng_or_source) -> MaskSource:
     return rng_or_source if hasattr(rng_or_source, "shapley") else MaskSource(rng_or_source)
 
 
-def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_samples: int, n_players: int, rng,
-                      span: Optional[Tuple[int, int, int]] = None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
-    """-> (mask key bits [B*K, Tw], v_s [B*K, C], v_1 [B, C]); row order [b0 s0, b0 s1, b1 s0, ...].  ``xs`` are THIS rank's
-    inputs; ``span`` = (inputs of the global batch, lo, hi) names them inside the global batch (default: xs is the batch) — the
-    masks are this rank's rows of the global ``mask_shapley_new`` call (scripts/common.MaskSource).  ``rng``: a device
-    generator or a MaskSource.  An empty shard returns (bits [0, Tw], None, None)."""
-    b = xs.shape[0]
+def _as_span(span, b: int, k: int) -> Span:
+    if isinstance(span, Span):
+        return span
     n_total, lo, hi = span if span is not None else (b, 0, b)
-    bits = _source(rng).shapley(n_total, lo, hi, n_mask_samples, n_players)
+    return Span(n_total, lo, hi, "input", k)
+
+
+def _targets_by_mask(recipe: ModelRecipe, m_surrogate, xs: Tensor, k: int, n_players: int, src: MaskSource, sp: Span, bits=None):
+    """Fewer inputs than ranks (the per-image loop of scripts/measure_faithfulness.py:195-218 and BASELINE config 4 at
+    one input per step): every rank holds ALL ``sp.n_tot`` inputs and runs masks [k_lo, k_hi) of each — its share of the hot
+    path — then the rows are all-gathered back into the reference's input-major order (``gather_masks_within_inputs``: a few
+    KB).  -> (mask bits of the WHOLE batch, v_s of the whole batch, v_1): every rank continues with the complete targets, so the
+    explainer step that follows is the same on all ranks and needs no gradient exchange."""
+    bits = src.shapley(sp.n_tot, 0, sp.n_tot, k, n_players) if bits is None else bits    # the whole global call: the one mask stream
+    width = bits.shape[-1]
+    local = bits.view(sp.n_tot, k, width)[:, sp.k_lo:sp.k_hi].reshape(-1, width).contiguous()
+    m_surrogate.eval()
+    with torch.no_grad():
+        v_loc, _ = recipe.fw_surrogate(m_surrogate, xs, local)       # n_tot inputs x (k_hi - k_lo) masks: shared layer 0
+        ones = torch.ones((xs.shape[0], n_players), dtype=torch.long, device=xs.device)
+        v_1, _ = recipe.fw_surrogate(m_surrogate, xs, ones)
+    v_s = distributed.gather_masks_within_inputs(v_loc.contiguous(), sp.n_tot, k)
+    return bits, v_s, v_1
+
+
+def surrogate_targets(recipe: ModelRecipe, m_surrogate, xs: Tensor, n_mask_samples: int, n_players: int, rng,
+                      span=None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """-> (mask key bits [B*K, Tw], v_s [B*K, C], v_1 [B, C]); row order [b0 s0, b0 s1, b1 s0, ...].  ``xs`` are THIS rank's
+    inputs; ``span`` = (inputs of the global batch, lo, hi) or a ``common.Span`` names them inside the global batch (default: xs
+    is the batch) — the masks are this rank's rows of the global ``mask_shapley_new`` call (scripts/common.MaskSource).  A span
+    in mask mode (``common.shard_auto``: fewer inputs than ranks) shards the K masks of every input instead and returns the
+    gathered targets of the whole batch.  ``rng``: a device generator or a MaskSource.  An empty shard returns
+    (bits [0, Tw], None, None)."""
+    b = xs.shape[0]
+    sp = _as_span(span, b, n_mask_samples)
+    if sp.by_mask:
+        return _targets_by_mask(recipe, m_surrogate, xs, n_mask_samples, n_players, _source(rng), sp)
+    bits = _source(rng).shapley(sp.n_tot, sp.lo, sp.hi, n_mask_samples, n_players)
     if b == 0:
         return bits, None, None
     m_surrogate.eval()
@@ -60,13 +89,20 @@ def surrogate_targets_lookahead(recipe: ModelRecipe, m_surrogate, xs_list, n_mas
     concatenated inputs — the hot path then always works on a few thousand rows, whatever the training batch size is (the
     reference trains on 2-4 inputs per step: 64-128 rows, a fraction of one round of GEMM tiles).  Masks are drawn per
     batch, in batch order, from the same stream, so every batch gets exactly the masks (and values) it would get
-    from ``surrogate_targets`` called batch by batch.  ``spans[i]`` = (global inputs, lo, hi) of batch i for row-sharded
-    ranks (xs_list holds the local slices).  -> list of (bits, v_s, v_1) per batch."""
+    from ``surrogate_targets`` called batch by batch.  ``spans[i]`` = (global inputs, lo, hi) or a ``common.Span`` of batch i for
+    row-sharded ranks (xs_list holds the local slices); batches in mask mode (fewer inputs than ranks) run on their own —
+    their rows per input differ from the others' — and come back with the gathered targets of the whole batch.
+    -> list of (bits, v_s, v_1) per batch."""
     src = _source(rng)
     spans = spans if spans is not None else [(x.shape[0], 0, x.shape[0]) for x in xs_list]
-    bits_l = [src.shapley(n_tot, lo, hi, n_mask_samples, n_players) for (n_tot, lo, hi) in spans]
-    live = [i for i, x in enumerate(xs_list) if x.shape[0] > 0]
+    spans = [_as_span(sp, x.shape[0], n_mask_samples) for sp, x in zip(spans, xs_list)]
+    # every batch's masks first, in batch order: ONE stream (a mask-mode batch takes the whole global call)
+    bits_l = [src.shapley(sp.n_tot, 0 if sp.by_mask else sp.lo, sp.n_tot if sp.by_mask else sp.hi, n_mask_samples, n_players) for sp in spans]
     out = [(bits_l[i], None, None) for i in range(len(xs_list))]
+    for i, sp in enumerate(spans):
+        if sp.by_mask:
+            out[i] = _targets_by_mask(recipe, m_surrogate, xs_list[i], n_mask_samples, n_players, src, sp, bits=bits_l[i])
+    live = [i for i, x in enumerate(xs_list) if x.shape[0] > 0 and not spans[i].by_mask]
     if not live:
         return out
     xs_all = torch.cat([xs_list[i] for i in live], dim=0) if len(live) > 1 else xs_list[live[0]]
@@ -107,19 +143,24 @@ def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_
     src = mask_source or common_mask_source(m_surrogate, device, seed)
     reg_loss, total = 0.0, 0
     m_explainer.eval()
+    _, n_ranks = distributed.world()
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, _zs = gen_input(_inputs, _targets)
-        xs, _zs, n_tot, lo, hi = shard(xs, _zs)
-        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=(n_tot, lo, hi))
+        xs, _zs, sp = shard_auto(xs, _zs, n_mask_samples)
+        n_tot, lo, hi = sp.astuple()
+        bits, v_s, v_1 = surrogate_targets(m_recipe, m_surrogate, xs, n_mask_samples, n_players, src, span=sp)
         if hi == lo:
             continue
         loss, _, _, _ = explainer_batch_loss(m_recipe, m_explainer, xs, bits, v_0, v_s, v_1, n_mask_samples, n_players)
-        lv = float(loss.item()) * ((hi - lo) / n_tot)      # this rank's share of the global batch-mean loss
+        # this rank's share of the global batch-mean loss (mask mode: every rank computed the whole batch's loss)
+        share = (1.0 / n_ranks) if sp.by_mask else ((hi - lo) / n_tot)
+        lv = float(loss.item()) * share
         reg_loss += lv
-        total += hi - lo
+        total += (n_tot / n_ranks) if sp.by_mask else (hi - lo)
         if distributed.world()[1] == 1:
             env.log(f"  > epoch {epoch} :{batch_idx}:test // loss: shap {lv / xs.shape[0]:.6f}, fin {total}")
     reg_loss, total = distributed.reduce_scalars([reg_loss, total], device)
+    total = int(round(total))
     return reg_loss / max(total, 1)
 
 
@@ -138,9 +179,11 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
     bit-identical to the single-process stream) — runs targets, forward and backward on them, and the gradients are summed
     over the ranks weighted by B_r / B (``GradBucketReducer``: 64 MiB buckets, each all-reduce in flight while the backward
     below it still runs), which is exactly the gradient of the reference's batch-mean loss over the B inputs.  The epoch loss
-    is reduced ONCE at the end.  A batch with fewer inputs than ranks (the ragged tail of an epoch) leaves some ranks without
-    inputs: they enter the same collectives with zero gradients, and that step's exchange runs in parameter order on all
-    ranks.  With one rank this is the reference loop, step for step."""
+    is reduced ONCE at the end.  A batch with fewer inputs than ranks (the ragged tail of an epoch; a one-input step of BASELINE
+    config 4) is sharded by MASK instead (``common.shard_auto``): every rank runs masks [k_lo, k_hi) of every input through the
+    surrogate, the targets are all-gathered (a few KB) and every rank takes the same explainer step on the whole batch — no
+    rank idles and no gradient travels.  (Only when K < ranks do ranks go without work: they then enter the collectives with
+    zero gradients, in parameter order.)  With one rank this is the reference loop, step for step."""
     from ..training import make_explainer_trainer
     env = distributed.main_only(env) or Log()
     src = mask_source or common_mask_source(m_surrogate, device, seed)
@@ -161,9 +204,9 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         group, rows = [], 0
         for idx, (_inputs, _targets) in enumerate(items):
             xs_, zs_ = gen_input(_inputs, _targets)
-            xs_, zs_, n_tot, lo, hi = shard(xs_, zs_)
-            group.append((idx, xs_, zs_, (n_tot, lo, hi)))
-            rows += xs_.shape[0] * n_mask_samples
+            xs_, zs_, sp_ = shard_auto(xs_, zs_, n_mask_samples)
+            group.append((idx, xs_, zs_, sp_))
+            rows += xs_.shape[0] * ((sp_.k_hi - sp_.k_lo) if sp_.by_mask else n_mask_samples)
             if rows >= target_rows:
                 yield group
                 group, rows = [], 0
@@ -177,8 +220,17 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
             for (idx, xs_, zs_, span), t_ in zip(group, tg):
                 yield idx, xs_, zs_, span, t_
 
-    for batch_idx, xs, zs, (n_tot, lo, hi), (bits, v_s, v_1) in batches():
+    for batch_idx, xs, zs, sp, (bits, v_s, v_1) in batches():
         optimizer.zero_grad()
+        n_tot, lo, hi = sp.astuple()
+        if sp.by_mask:
+            # fewer inputs than ranks: the K-mask targets were sharded by mask and gathered, every rank holds the whole batch —
+            # the same explainer step on all ranks (same inputs, targets, dropout keys), so no gradient exchange and no idle rank
+            loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True, seed=(seed or 0) + epoch)
+            optimizer.step()
+            losses.append(loss.reshape(()) / n_ranks)
+            total += n_tot / float(n_ranks)
+            continue
         weight = (hi - lo) / float(n_tot)
         ragged = n_tot < n_ranks                  # some rank holds no input of this batch: un-instrumented exchange for all
         if reducer is not None:
@@ -202,7 +254,7 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
             env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {float(loss.item()) / xs.shape[0]:.6f}, fin {total}")
     reg_loss = float(torch.stack(losses).sum().item()) if losses else 0.0
     reg_loss, total = distributed.reduce_scalars([reg_loss, total], device)
-    total = int(total)
+    total = int(round(total))
     env.log(f"  > epoch {epoch} :train // loss: shap {reg_loss / max(total, 1):.6f}, fin {total}")
     return reg_loss / max(total, 1)
 

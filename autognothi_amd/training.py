@@ -533,8 +533,23 @@ def _cross_entropy(logits: Tensor, labels: Tensor) -> Tuple[Tensor, Tensor]:
     return loss, g / b
 
 
+def _bf16_step(module: nn.Module) -> bool:
+    """MIXED_BF16 and a model the bf16-activation step of training16.py covers (vanilla / duo / froyo, head dim 64)."""
+    if not MIXED_BF16 or type(module).__name__.startswith("Ltt"):
+        return False
+    from . import training16
+    return training16.supported(module)
+
+
 class ExplainerTrainer:
-    """fw_explainer + loss_shapley_new with gradients (vanilla / froyo / duo; ViT or BERT)."""
+    """fw_explainer + loss_shapley_new with gradients (vanilla / froyo / duo; ViT or BERT).  With MIXED_BF16 on, constructing
+    one returns the bf16-activation trainer of training16.py (same interface) for the models it covers."""
+
+    def __new__(cls, recipe, m_explainer: nn.Module):
+        if cls is ExplainerTrainer and _bf16_step(m_explainer):
+            from . import training16
+            return training16.ExplainerTrainer16(recipe, m_explainer)
+        return super().__new__(cls)
 
     def __init__(self, recipe, m_explainer: nn.Module):
         """``recipe`` may be None (the autograd bridge builds trainers from the module alone)."""
@@ -641,7 +656,14 @@ class ExplainerTrainer:
 
 
 class SurrogateTrainer:
-    """fw_surrogate on masked inputs + loss_logits_kl_divergence with gradients (scripts/train_surrogate.py:133-147)."""
+    """fw_surrogate on masked inputs + loss_logits_kl_divergence with gradients (scripts/train_surrogate.py:133-147).  With
+    MIXED_BF16 on: the bf16-activation trainer of training16.py for the models it covers."""
+
+    def __new__(cls, recipe, m_surrogate: nn.Module):
+        if cls is SurrogateTrainer and _bf16_step(m_surrogate):
+            from . import training16
+            return training16.SurrogateTrainer16(recipe, m_surrogate)
+        return super().__new__(cls)
 
     def __init__(self, recipe, m_surrogate: nn.Module):
         self.recipe, self.m = recipe, m_surrogate

@@ -293,6 +293,9 @@ def timed(fn, steps, warmup, dist, dev):
     return elapsed, out
 
 
+LAST_TRAIN_LAUNCHES = [0.0]   # kernels of this library per training step in the last train_step_rate call (targets + grand + fwd/bwd)
+
+
 def train_step_rate(job, dist, n_train, tb, precision):
     """One reference _explainer_epoch_train body per step (scripts/train_explainer.py:128-207) = K-mask surrogate targets
     (inference path) + the all-ones grand forward + explainer forward/backward + AdamW.  -> (images/s, flops per step)."""
@@ -315,9 +318,11 @@ def train_step_rate(job, dist, n_train, tb, precision):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    launches0 = int(L.lib().ag_launch_count())
     tt = time.perf_counter()
     te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * n_train, recipe, job.surrogate, m_exp, opt, 2, gen, seed=7)
     torch.cuda.synchronize()
+    LAST_TRAIN_LAUNCHES[0] = (int(L.lib().ag_launch_count()) - launches0) / float(n_train)
     if dist is not None:
         dist.barrier()
     el = time.perf_counter() - tt
@@ -611,13 +616,14 @@ def main():
         rate, f_step, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision)
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                       "steps": 12,
+                       "steps": 12, "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
                        "sharding": "global batch = images_per_gpu_per_step x ranks; rank r trains on its input slice with its rows of the one "
                                    "global mask call; gradients summed over RCCL in 64 MiB buckets from inside the backward "
                                    "(scripts/train_explainer.explainer_epoch_train)",
                        "body": "K-mask surrogate targets (bf16; computed for groups of consecutive batches at once: the surrogate is frozen) + "
-                               "explainer fwd/bwd (bf16 GEMM and attention operands on the matrix cores, fp32 accumulate / activations / "
-                               "optimizer state) + AdamW, as scripts/train_explainer.py:128-207",
+                               "explainer fwd/bwd (bf16 operands and saved activations, every Linear one in-place NT/NN/TN ag_gemm_ex launch, "
+                               "fp32 accumulate / residual stream / gradients / optimizer state, dW products on a second stream) + AdamW, "
+                               "as scripts/train_explainer.py:128-207",
                        "roofline": {"bound": "mfma", "gflop_per_step": round(f_step / 1e9, 1), "achieved": round(tf, 1), "peak": peak,
                                     "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "flops": "K-mask targets (F_exec) + grand forward + explainer forward + 2x forward for the backward"}}
@@ -629,6 +635,7 @@ def main():
                 tf5 = r5 / world / args.train_batch * f5 / 1e12
                 c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
                           "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,
+                          "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
                           "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
                                        "frac": round(tf5 / peak, 4)}}
                 del j5

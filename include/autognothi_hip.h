@@ -374,8 +374,8 @@ int ag_masked_attention_bwd_mixed(const float* d_qkv, const uint32_t* d_mask_bit
  *   AG_EX_STORE      C = acc + bias                     -> c_dtype (AG_BF16 / AG_F32), row stride ldc
  *   AG_EX_GELU_DUAL  C = bf16(acc + bias), out2 = gelu(C)   (fc1: the backward needs the pre-activation, fc2 the activation)
  *   AG_EX_GELU_BWD   C = bf16(acc * gelu'(aux))         aux = bf16 pre-activation [M, ld_aux]   (fc2's dX feeding fc1's backward)
- * (bf16 GELU forms: |gelu - erf form| <= 1.7e-5, as ag_gemm's bf16 mode.)  Requirements: N, Kc, lda, ldb multiples of 8; M % 8 == 0
- * when a_col; ldc % 4 == 0; 16-byte aligned pointers. */
+ * (bf16 GELU forms: |gelu - erf form| <= 1.7e-5, as ag_gemm's bf16 mode.)  Requirements: N, lda, ldb multiples of 8; Kc % 8 == 0 unless
+ * both operands are stored [Kc, .]; M % 8 == 0 when a_col; ldc % 4 == 0; 16-byte aligned pointers. */
 enum { AG_EX_STORE = 0, AG_EX_GELU_DUAL = 1, AG_EX_GELU_BWD = 2, AG_EX_SLABS = 3 };
 int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d_B, int64_t ldb, int b_col, int M, int N, int Kc,
                int epilogue, const float* d_bias, void* d_C, int64_t ldc, int c_dtype, const void* d_aux, int64_t ld_aux,
@@ -413,6 +413,10 @@ int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int
  * weight of a model after the optimiser step, q | k | v landing side by side in their fused buffer.  HOST arrays of DEVICE pointers
  * (passed to the kernel by value: no table copy, graph-capturable); segments 16-byte aligned. */
 int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, void* stream);
+/* dst[m, c] = c < cols_src ? src[m, c] : 0 for c < cols_dst; dst fp32 or bf16 (dst_dtype).  Pads the C-wide output / gradient of the
+ * explainer's last Linear (C = 10 / 2 classes, models/vanilla_vit.py:92-100) to the 16 columns ag_gemm_ex wants, or strips them. */
+int ag_pad_cols_f32(const float* d_src, int64_t ld_src, int cols_src, void* d_dst, int64_t ld_dst, int cols_dst, int dst_dtype, int M,
+                    void* stream);
 /* Masked attention of the bf16 training step on the matrix cores (the kernel of ag_masked_attention_*_mixed with bf16 I/O):
  * qkv [R,T,3H] bf16 -> ctx [R,T,H] bf16, attention-probability dropout (p_drop, seed) as ag_masked_attention_train; backward:
  * dqkv [R,T,3H] bf16 from d_dctx given as `dslabs` fp32 slabs [dslabs][R*T][H] (ag_gemm_ex's split-K partials of the
@@ -431,6 +435,8 @@ int ag_masked_attention_bwd_bf16(const void* d_qkv, const uint32_t* d_mask_bits,
 #define AG_PROF_ATTENTION 8
 #define AG_PROF_LAYERNORM 9
 #define AG_PROF_GEMM_EX 10   /* ag_gemm_ex */
+/* number of kernels this library has launched in this process (diagnostics: launches per training step in bench.py). */
+int64_t ag_launch_count(void);
 int ag_profile_enable(int on);
 int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 

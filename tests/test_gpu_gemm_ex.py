@@ -44,7 +44,7 @@ def _operands(order, m, n, kc, seed, dev):
 SHAPES = {
     NT: [(1024, 768, 768), (1576, 2304, 768), (1576, 768, 3072), (6304, 768, 768), (1061, 200, 456)],
     NN: [(1024, 768, 3072), (1576, 3072, 768), (1576, 768, 2304), (6304, 768, 3072), (1061, 264, 200)],
-    TN: [(768, 768, 1024), (2304, 768, 1576), (768, 3072, 1576), (3072, 768, 6304), (200, 264, 1061 - 5)],
+    TN: [(768, 768, 1024), (2304, 768, 1576), (768, 3072, 1576), (3072, 768, 6304), (200, 264, 1061 - 5), (16, 192, 394)],
 }
 
 
