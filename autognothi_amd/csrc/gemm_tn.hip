@@ -41,6 +41,7 @@ struct ExArgs {
     bf16_t* out2; long ld_out2;       // GELU_DUAL: gelu(pre) [M, ld_out2]
     float* slabs;                     // [splits][M][N]
     int splits;
+    int lds_epilogue;                 // 1: the tile leaves through LDS as whole row segments; 0: direct stores from the accumulator layout
 };
 
 // source of every staged 16-byte chunk that lies outside the matrix (contraction tail, ragged columns)
@@ -214,47 +215,110 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_kernel(ExA
     // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15) per sub-tile (N % 4 == 0) ----
     const int frow = lane & 15, fq = lane >> 4;
     float* slab = EPI == E_SLABS ? p.slabs + (long)sp * p.M * p.N : nullptr;
+    // the values of one sub-tile after the epilogue's arithmetic (bias, gelu'): v[4]; E_GELU_DUAL also gives the activation
+    auto finish4 = [&](int sm, int sn, int m, int n, float (&v)[4]) {
+        v[0] = acc[sn][sm][0]; v[1] = acc[sn][sm][1]; v[2] = acc[sn][sm][2]; v[3] = acc[sn][sm][3];
+        if (EPI == E_SLABS) return;
+        if (p.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (EPI == E_GELU_BWD) {
+            const float4 u = load4_as_f32(p.aux + (long)m * p.ld_aux + n);
+            v[0] *= fast_gelu_grad(u.x); v[1] *= fast_gelu_grad(u.y); v[2] *= fast_gelu_grad(u.z); v[3] *= fast_gelu_grad(u.w);
+        }
+    };
+    // the activation of the bf16-ROUNDED pre-activation: what the backward (which only has the rounded one) differentiates
+    auto act_of = [](const uint2 pk) {
+        const float u0 = __uint_as_float(pk.x << 16), u1 = __uint_as_float(pk.x & 0xFFFF0000u);
+        const float u2 = __uint_as_float(pk.y << 16), u3 = __uint_as_float(pk.y & 0xFFFF0000u);
+        return make_uint2(pack_bf16x2(fast_gelu(u0), fast_gelu(u1)), pack_bf16x2(fast_gelu(u2), fast_gelu(u3)));
+    };
+    constexpr bool F32_OUT = EPI == E_SLABS || EPI == E_STORE_F32;
+    if (!p.lds_epilogue) {
+        // direct stores from the accumulator layout: 16 rows x 32 B (bf16) / 64 B (fp32) per instruction (the parity reference of the
+        // staged form below, AG_GEMM_EX_EPI=0)
 #pragma unroll
-    for (int sm = 0; sm < 4; ++sm) {
-        const int m = m0 + wm * 64 + sm * 16 + frow;
-        if (m >= p.M) continue;
+        for (int sm = 0; sm < 4; ++sm) {
+            const int m = m0 + wm * 64 + sm * 16 + frow;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-            const int n = n0 + wn * 64 + sn * 16 + fq * 4;
-            if (n >= p.N) continue;
-            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
-            if (EPI == E_SLABS) {
-                *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                continue;
+            for (int sn = 0; sn < 4; ++sn) {
+                const int n = n0 + wn * 64 + sn * 16 + fq * 4;
+                if (n >= p.N) continue;
+                float v[4];
+                finish4(sm, sn, m, n, v);
+                if (EPI == E_SLABS) {
+                    *reinterpret_cast<float4*>(slab + (long)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (EPI == E_STORE_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+                    if (EPI == E_GELU_DUAL) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.ld_out2 + n) = act_of(pk);
+                }
             }
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        return;
+    }
+    // Staged form: the tile goes through the (now idle) ring in two rounds of 64 rows — round r holds rows
+    // {wm*64 + r*32 + [0, 32)} of both wave rows as a row-major plane with padded rows — and leaves as whole 256 B (bf16) / 512 B
+    // (fp32) row segments, 16 B per lane: full cache lines instead of 32 / 64 B pieces of them.
+    constexpr int ES = F32_OUT ? 4 : 2;
+    constexpr int RB = BT * ES + 16;             // plane row stride in bytes (padding: the 16 rows of a store land on different banks)
+    constexpr int PLANE = 64 * RB;
+    constexpr int CPR = BT * ES / 16;            // 16-byte chunks per row
+    constexpr int RPP = NTHREADS / CPR;          // rows per copy-out pass
+    char* out_base = F32_OUT ? (EPI == E_SLABS ? reinterpret_cast<char*>(slab) : p.C) : p.C;
+    const long out_ld_b = (EPI == E_SLABS ? (long)p.N : p.ldc) * ES;
+    __syncthreads();                             // every wave has read its last fragments: the ring is free
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r) __syncthreads();                  // round 0 has been copied out
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int sm = 2 * r + s2;
+            const int lrow = wm * 32 + s2 * 16 + frow;
+            const int m = m0 + wm * 64 + sm * 16 + frow;
+            const int mc = m < p.M ? m : p.M - 1;          // (rows beyond M are never copied out; clamp what the epilogue may read)
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn) {
+                const int nl = wn * 64 + sn * 16 + fq * 4;
+                const int n = n0 + nl < p.N ? n0 + nl : p.N - 4;
+                float v[4];
+                finish4(sm, sn, mc, n, v);
+                char* dst = smem + lrow * RB + nl * ES;
+                if (F32_OUT) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                    if (EPI == E_GELU_DUAL) *reinterpret_cast<uint2*>(dst + PLANE) = act_of(pk);
+                }
             }
-            if (EPI == E_STORE_F32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                continue;
-            }
-            if (EPI == E_GELU_BWD) {
-                const float4 u = load4_as_f32(p.aux + (long)m * p.ld_aux + n);
-                v[0] *= fast_gelu_grad(u.x); v[1] *= fast_gelu_grad(u.y); v[2] *= fast_gelu_grad(u.z); v[3] *= fast_gelu_grad(u.w);
-            }
-            const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
-            if (EPI == E_GELU_DUAL) {
-                // the activation of the bf16-ROUNDED pre-activation: what the backward (which only has the rounded one) differentiates
-                const float u0 = __uint_as_float(pk.x << 16), u1 = __uint_as_float(pk.x & 0xFFFF0000u);
-                const float u2 = __uint_as_float(pk.y << 16), u3 = __uint_as_float(pk.y & 0xFFFF0000u);
-                *reinterpret_cast<uint2*>(p.out2 + (long)m * p.ld_out2 + n) =
-                    make_uint2(pack_bf16x2(fast_gelu(u0), fast_gelu(u1)), pack_bf16x2(fast_gelu(u2), fast_gelu(u3)));
+        }
+        __syncthreads();
+        const int chunk = tid % CPR, r0 = tid / CPR;
+        const int ncol = n0 + chunk * (16 / ES);
+        if (ncol < p.N) {
+#pragma unroll
+            for (int ps = 0; ps < 64 / RPP; ++ps) {
+                const int lrow = ps * RPP + r0;
+                const int m = m0 + (lrow >> 5) * 64 + r * 32 + (lrow & 31);
+                if (m >= p.M) continue;
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + lrow * RB + chunk * 16);
+                *reinterpret_cast<uint4*>(out_base + (long)m * out_ld_b + (long)n0 * ES + chunk * 16) = val;
+                if (EPI == E_GELU_DUAL) {
+                    const uint4 v2 = *reinterpret_cast<const uint4*>(smem + PLANE + lrow * RB + chunk * 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out2) + ((long)m * p.ld_out2 + n0) * 2 + chunk * 16) = v2;
+                }
             }
         }
     }
 }
 
-template <bool AC, bool BC, int EPI>
-int launch_ex(const ExArgs& a, hipStream_t s) {
-    constexpr int NST = 2;
+template <bool AC, bool BC, int EPI, int NST>
+int launch_nst(const ExArgs& a, hipStream_t s) {
     constexpr int LDS = NST * 2 * TILE_BYTES;
     static bool attr_set[16] = {};
     int dev = 0;
@@ -268,6 +332,13 @@ int launch_ex(const ExArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_ex_kernel<AC, BC, EPI, NST>), dim3(units), dim3(NTHREADS), LDS, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
+}
+
+// Ring depth: two slots of 32 KiB, two workgroups per CU.  Measured against one workgroup per CU with three / four slots (two / three
+// contraction steps in flight) on the 12 Linear products of a ViT-base block at 1 576 rows: 179 us against 201 / 209 us.
+template <bool AC, bool BC, int EPI>
+int launch_ex(const ExArgs& a, hipStream_t s) {
+    return launch_nst<AC, BC, EPI, 2>(a, s);
 }
 
 template <bool AC, bool BC>
@@ -284,12 +355,14 @@ int dispatch_epi(int e, const ExArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int ag_gemm_ex_splits(int M, int N, int Kc) {
-    // Units = tiles x splits should cover the 256 CUs (two workgroups each) once: more splits than that only add slab
-    // traffic.  A unit keeps at least four contraction steps (256 elements), so that its prologue and epilogue stay the minor part.
+    // Units = tiles x splits should cover the 256 CUs (two workgroups each) about once: measured on the Linear products of a
+    // ViT-base / BERT-base block at 1 576 / 1 024 rows the best split puts 430-470 units in flight (78 tiles x 6, 108 x 4, 144 x 3,
+    // 36 x 6 of 24 steps); more only adds slab traffic.  A unit keeps at least four contraction steps (256 elements), so that its
+    // prologue and epilogue stay the minor part.
     if (M <= 0 || N <= 0 || Kc <= 0) return 1;
     const int tiles = ceil_div(M, BT) * ceil_div(N, BT);
     const int nk = ceil_div(Kc, KS);
-    int s = (320 + tiles / 2) / tiles;
+    int s = (448 + tiles / 2) / tiles;
     const int smax = nk / 4 > 0 ? nk / 4 : 1;
     s = s < smax ? s : smax;
     s = s > 8 ? 8 : s;
@@ -340,6 +413,9 @@ extern "C" int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d
     a.aux = (const bf16_t*)d_aux; a.ld_aux = ld_aux;
     a.out2 = (bf16_t*)d_out2; a.ld_out2 = ld_out2;
     a.slabs = d_slabs; a.splits = splits;
+    static AgKnob epi_knob("AG_GEMM_EX_EPI");
+    // (the staged epilogue stores 16-byte chunks: 8 bf16 / 4 fp32 columns; row strides must keep them aligned)
+    a.lds_epilogue = epi_knob.get(1) != 0 && (epi == E_SLABS || ldc % 8 == 0) && (epi != E_GELU_DUAL || ld_out2 % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
     const double out_b = epi == E_SLABS ? 4.0 * splits : (epi == E_STORE_F32 ? 4.0 : (epi == E_GELU_DUAL ? 4.0 : 2.0));
     AgProfScope prof(AG_PROF_GEMM_EX, 2.0 * M * (double)N * Kc,

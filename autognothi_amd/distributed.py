@@ -100,20 +100,19 @@ def shard_masks_within_inputs(masks: Tensor, n_inputs: int, k: int, rank: Option
 
 
 def gather_masks_within_inputs(local: Tensor, n_inputs: int, k: int) -> Tensor:
-    """Inverse exchange of shard_masks_within_inputs: all-gather the per-rank [n_inputs*kl_r, ...] row blocks and interleave
-    them back into the global [n_inputs*k, ...] input-major order."""
+    """Inverse exchange of shard_masks_within_inputs: the per-rank [n_inputs*kl_r, ...] row blocks back in the global
+    [n_inputs*k, ...] input-major order on every rank.  Each rank writes its block into a zero buffer of the global shape and the
+    buffers are summed (one all-reduce of a few KB: v_s is C floats per mask row; x + 0 is exact, so the result carries every
+    rank's bits unchanged) — no variable-length gather lists, one collective whatever the split."""
     r, w = world()
     if w == 1:
         return local
-    spans = [shard_range(k, q, w) for q in range(w)]
-    width = max(hi - lo for lo, hi in spans)
+    lo, hi = shard_range(k, r, w)
     tail = tuple(local.shape[1:])
-    pad = torch.zeros((n_inputs, width) + tail, dtype=local.dtype, device=local.device)
-    lo, hi = spans[r]
-    pad[:, :hi - lo] = local.reshape(n_inputs, hi - lo, *tail)
-    out = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(out, pad)
-    return torch.cat([o[:, :h - l] for o, (l, h) in zip(out, spans)], dim=1).reshape(n_inputs * k, *tail)
+    full = torch.zeros((n_inputs, k) + tail, dtype=local.dtype, device=local.device)
+    full[:, lo:hi] = local.reshape(n_inputs, hi - lo, *tail)
+    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    return full.reshape(n_inputs * k, *tail)
 
 
 def shard_auto(masks: Tensor, n_inputs: int, k: int):

@@ -34,6 +34,7 @@ from . import training as T
 BF16, F32 = L.AG_BF16, L.AG_F32
 VIT, BERT = L.AG_MASK_VIT_MUL, L.AG_MASK_BERT_ADD
 SIDE_STREAM = os.environ.get("AG_TRAIN_SIDE", "1") != "0"
+N_SIDE = max(1, int(os.environ.get("AG_TRAIN_SIDE", "1") or 1))     # number of side streams (AG_TRAIN_SIDE=0: none)
 
 
 def supported(module: nn.Module) -> bool:
@@ -46,14 +47,16 @@ def supported(module: nn.Module) -> bool:
 
 # ------------------------------------------------------------------------------------------------ side stream
 class _Side:
-    """The second stream of the backward.  ``run(fn, keep)`` forks from the current stream (everything issued so far is visible to
-    fn), ``join()`` makes the current stream wait for all forked work.  ``keep``: tensors allocated on the main stream that fn
-    reads — held until the join so that the caching allocator cannot hand their memory to a later main-stream kernel."""
+    """The side streams of the backward.  ``run(fn, keep)`` forks from the current stream (everything issued so far is visible to
+    fn) onto the next of ``N_SIDE`` streams (round robin: the dW products of one layer are independent of each other as well),
+    ``join()`` makes the current stream wait for all forked work.  ``keep``: tensors allocated on the main stream that fn reads —
+    held until the join so that the caching allocator cannot hand their memory to a later main-stream kernel."""
 
     _per_device = {}
 
     def __init__(self, device):
-        self.stream = torch.cuda.Stream(device) if SIDE_STREAM else None
+        self.streams = [torch.cuda.Stream(device) for _ in range(N_SIDE)] if SIDE_STREAM else []
+        self.turn = 0
         self.keep: List[Tensor] = []
         self.finals: List[Tensor] = []     # parameters whose gradient was produced on the MAIN stream since the last fork
         self.dirty = False
@@ -66,20 +69,25 @@ class _Side:
         return cls._per_device[key]
 
     def run(self, fn, *keep: Tensor) -> None:
-        if self.stream is None:
+        if not self.streams:
             fn()
             self._report()
             return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        # (N > 1 ranks: the gradient sink buckets what it is told in report order and reduces a bucket on the reporting stream —
+        # all gradients then come from ONE side stream, so a bucket never reads a gradient another side stream is still writing)
+        st = self.streams[0] if T.GRAD_SINK is not None else self.streams[self.turn]
+        self.turn = (self.turn + 1) % len(self.streams)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
             fn()
-            self._report()      # (gradients finished on the main stream before this fork are ordered before it too)
+            if st is self.streams[0]:
+                self._report()      # (gradients finished on the main stream before this fork are ordered before it too)
         self.keep.extend(keep)
         self.dirty = True
 
     def final_on_main(self, *params: Tensor) -> None:
-        """a gradient that a main-stream kernel wrote: reported to training.GRAD_SINK at the next fork (or at the join), on a
-        stream that is ordered behind it AND behind every side-stream gradient the sink may bucket with it."""
+        """a gradient that a main-stream kernel wrote: reported to training.GRAD_SINK at a later fork (or at the join), on a
+        stream that is ordered behind it."""
         self.finals.extend(p for p in params if p.requires_grad)
 
     def _report(self) -> None:
@@ -88,10 +96,13 @@ class _Side:
             T._final(*fin)
 
     def join(self) -> None:
-        if self.stream is not None and self.dirty:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.dirty:
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)
         self.keep.clear()
         self.dirty = False
+        self.turn = 0
         self._report()
 
 

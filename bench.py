@@ -352,11 +352,11 @@ FIXTURE_TAG = {"vit_base": "vit_base_l12", "bert_base": "bert_base_l12", "vit_la
                "duo_bert_base": "duo_bert_base_l12", "froyo_vit_base": "froyo_vit_base_l12"}
 
 
-def bf16_vs_reference(workload, dev):
+def bf16_vs_reference(workload, dev, tag=None):
     """Deviation of the throughput mode from the fp32 reference, from the committed full-depth fixture of this workload (one
     input x K masks made by the reference itself, tests/golden/model_<tag>.npz), next to the reference's OWN deviation under
     torch.autocast(bf16) on the same case (model_<tag>_bf16ref.npz).  Same code path as tests/test_gpu_fulldepth.py."""
-    tag = FIXTURE_TAG.get(workload)
+    tag = tag or FIXTURE_TAG.get(workload)
     if tag is None:
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -570,12 +570,21 @@ def main():
             blk = bf16_vs_reference(wl, dev)
             if blk is not None:
                 dev_blocks[WORKLOAD_LABEL[wl]] = blk
+        if args.workload == "vit_base":
+            blk = bf16_vs_reference("bert_base", dev, tag="bert_base_l12_phi")
+            if blk is not None:
+                blk["note"] = ("the same BERT-base with the explainer's attention output projections scaled by 0.3 (tokens stay distinct, as in a "
+                               "trained model): max|phi| ~ max|pred| instead of a tenth of it — the usable-case companion of the bert_base "
+                               "line above, whose phi is a small difference of pred-sized numbers (random-weight post-LN BERT averages its "
+                               "tokens together)")
+                dev_blocks["bert_base_tayp_vanilla seq_len=128, explainer with distinct tokens (bert_base_l12_phi)"] = blk
         if dev_blocks:
             secondary["bf16_vs_reference"] = {
                 "what": "max / rms deviation of this library's bf16 mode from the fp32 reference outputs on the reference-made full-depth "
                         "fixture (1 input x K masks): v_s = K-mask surrogate probabilities, phi = Shapley values relative to max|phi|; "
-                        "reference_autocast_bf16 = the reference itself under torch.autocast(bf16) against its fp32 self (the yardstick); "
-                        "fp32 mode meets 1e-4 (tests/test_gpu_fulldepth.py)",
+                        "reference_autocast_bf16 = the reference itself under torch.autocast(bf16) against its fp32 self (the yardstick). "
+                        "fp32 mode: |phi - reference| <= 1e-4 |phi| + 4 x the reference's own fp32-vs-fp64 rounding noise at that depth "
+                        "(measured 1.8-3 x that noise; tests/test_gpu_fulldepth.py)",
                 "workloads": dev_blocks}
 
     # ---- secondary metric of BASELINE.json: Shapley attributions per second through fw_final (classifier +

@@ -6,7 +6,9 @@ scripts/train_explainer.py:128-207, scripts/train_surrogate.py:112-160, scripts/
 The kernels are stubbed (plain torch on the CPU: a stub trainer behind ``module._ag_trainer``, a stub ``fw_surrogate`` /
 ``fw_classifier``, the numpy oracle's bit-exact sampler behind the MaskSource contract) — what runs for real is the control
 flow under test: input slices per rank, this rank's rows of the ONE global mask call, weighted bucketed gradient exchange
-from inside the backward, empty shards on ragged tail batches, the once-per-epoch loss reduction, rank-0-only logging.
+from inside the backward, batches with FEWER inputs than ranks sharded by mask inside every input (no rank idles, the
+targets are gathered, no gradient travels), empty shards where that is impossible (the surrogate's one mask per input), the
+once-per-epoch loss reduction, rank-0-only logging.
 Asserted: masks (bit-exact, union of the ranks == the single-process stream), per-batch losses, the epoch figure and the
 post-step parameters equal the world-1 run."""
 import os
@@ -20,7 +22,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 K, P, C, DFEAT = 4, 6, 3, 8
-BATCHES = [4, 4, 3, 1, 2]          # 3 -> ragged shards (2 + 1); 1 -> one rank without inputs
+BATCHES = [4, 4, 3, 1, 2, 1]       # 3 -> ragged shards (2 + 1); 1 -> fewer inputs than ranks: K-within-image sharding (explainer) /
+                                   #      one rank without inputs (surrogate: a single mask per input cannot be split)
 SEED = 1234
 
 
@@ -69,9 +72,11 @@ class _Recipe:
         g = torch.Generator().manual_seed(6)
         self.w_srg = torch.randn(DFEAT + P, C, generator=g)
         self.w_cls = torch.randn(DFEAT, C, generator=g)
+        self.rows = []         # (inputs, mask rows) of every masked forward this rank ran
 
     def fw_surrogate(self, model, xs, masks):
         kk = masks.shape[0] // xs.shape[0]
+        self.rows.append((int(xs.shape[0]), int(masks.shape[0])))
         return torch.softmax(torch.cat([xs.repeat_interleave(kk, 0), masks.float()], 1) @ self.w_srg, -1), None
 
     def fw_classifier(self, model, xs, masks):
@@ -146,7 +151,7 @@ def _run_explainer_epochs():
         epoch_loss.append(te.explainer_epoch_train(env, torch.device("cpu"), K, P, v_0, _data(), recipe, srg, model, opt, epoch,
                                                    lambda a, b: (a, b), seed=None, target_rows=16, mask_source=src))
     return dict(params=[q.detach().clone() for q in model.parameters()], epoch_loss=epoch_loss, losses=trainer.losses,
-                masks=[(kind, n, rows) for kind, n, rows in src.log], log=env.lines)
+                masks=[(kind, n, rows) for kind, n, rows in src.log], log=env.lines, fw_rows=list(recipe.rows))
 
 
 def _run_surrogate_epoch():
@@ -164,29 +169,43 @@ def _run_surrogate_epoch():
                 masks=[(kind, n, rows) for kind, n, rows in src.log], log=env.lines)
 
 
+class _FaithRecipe:
+    """fw_final / fw_surrogate stand-ins for measure_faithfulness: deterministic functions of the sample and the mask row."""
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(21)
+        self.w = torch.randn(2 * P, C, generator=g)
+        self.rows = []
+
+    def fw_final(self, m_final, xs):
+        return None, torch.stack([xs.view(-1) * (c + 1) + 0.01 * torch.arange(P) for c in range(C)]).view(1, C, P)
+
+    def fw_surrogate(self, model, xs, masks):
+        self.rows.append(int(masks.shape[0]))
+        return torch.softmax(torch.cat([xs.expand(masks.shape[0], -1), masks.float()], 1) @ self.w, -1), None
+
+
+def _perturbed_masks_oracle(attr, steps, mask_base):
+    """ops.perturbed_masks on the numpy oracle (oracle/shapley.py: reference scripts/measure_faithfulness.py:225-251)."""
+    from oracle import shapley as osh
+    a = attr.numpy()
+    outs = [osh.get_perturbed_samples(a[c], a.shape[1], steps, mask_base) for c in range(a.shape[0])]
+    return torch.from_numpy(outs[0][0]), torch.from_numpy(np.stack([m for _, m in outs]))
+
+
 def _run_faithfulness():
+    """the REAL measure_faithfulness_loaded + infer_perturbed (row split of the tail samples, gather) on stub kernels."""
     from autognothi_amd.scripts import measure_faithfulness as mf
-    calls = []
-
-    def explain(recipe, m_final, xs):
-        return xs.view(1, 1, -1)
-
-    def infer(recipe, m_srg, xs, explanation, steps):
-        v = float(xs.sum())
-        calls.append(v)
-        cur = {c: {0: v + c, 3: 2 * v - c, 6: v * v} for c in range(C)}
-        return cur, {c: {s: -x for s, x in d.items()} for c, d in cur.items()}
-
-    keep = mf.explain, mf.infer_perturbed
-    mf.explain, mf.infer_perturbed = explain, infer
+    keep = mf.ops.perturbed_masks
+    mf.ops.perturbed_masks = _perturbed_masks_oracle
     try:
         g = torch.Generator().manual_seed(9)
         samples = [(torch.randn(1, P, generator=g), torch.tensor([i % C])) for i in range(7)]
-        env = _Env()
-        rep = mf.measure_faithfulness_loaded(env, torch.device("cpu"), None, None, None, samples, lambda a, b: (a, b), 3)
+        env, recipe = _Env(), _FaithRecipe()
+        rep = mf.measure_faithfulness_loaded(env, torch.device("cpu"), recipe, _Frozen(), _Frozen(), samples, lambda a, b: (a, b), 4)
     finally:
-        mf.explain, mf.infer_perturbed = keep
-    return dict(report=rep, evaluated=len(calls), log=env.lines)
+        mf.ops.perturbed_masks = keep
+    return dict(report=rep, fw_rows=recipe.rows, log=env.lines)
 
 
 def _baseline(path):
@@ -195,14 +214,20 @@ def _baseline(path):
     torch.save(dict(exp=_run_explainer_epochs(), srg=_run_surrogate_epoch(), faith=_run_faithfulness()), path)
 
 
-def _merge_masks(mine, world, rank):
-    """[(kind, n_total, local rows)] of every rank -> the global rows of every call (rank order = input order)."""
+def _merge_masks(mine, world, rank, by_mask):
+    """[(kind, n_total, local rows)] of every rank -> the global rows of every call (rank order = input order).  A call in mask
+    mode was drawn WHOLE by every rank (identically): one copy of it."""
     parts = [None] * world
     dist.all_gather_object(parts, mine)
     out = []
     for calls in zip(*parts):
         assert len({(c[0], c[1]) for c in calls}) == 1
-        out.append((calls[0][0], calls[0][1], np.concatenate([c[2] for c in calls], axis=0)))
+        if by_mask(calls[0][0], calls[0][1]):
+            for c in calls[1:]:
+                assert np.array_equal(c[2], calls[0][2])
+            out.append(calls[0])
+        else:
+            out.append((calls[0][0], calls[0][1], np.concatenate([c[2] for c in calls], axis=0)))
     return out
 
 
@@ -219,15 +244,28 @@ def _worker(rank, world, port, path, out):
         for key, run in (("exp", _run_explainer_epochs), ("srg", _run_surrogate_epoch)):
             got, ref = run(), want[key]
             # masks: every call is the same global call on every rank, and the union of the ranks' rows is the world-1 stream
-            merged = _merge_masks(got["masks"], world, rank)
+            by_mask = lambda kind, n: kind == "shapley" and n < world    # noqa: E731  (mask mode: every rank draws the whole call)
+            merged = _merge_masks(got["masks"], world, rank, by_mask)
             assert len(merged) == len(ref["masks"])
             for (kind, n, rows), (kind1, n1, rows1) in zip(merged, ref["masks"]):
                 assert (kind, n) == (kind1, n1) and np.array_equal(rows, rows1)
-            # per-batch losses: sum_r (B_r / B) * loss_r == the world-1 batch loss
-            spans = [D.shard_range(b) for b in BATCHES] * (2 if key == "exp" else 1)
-            sizes = BATCHES * (2 if key == "exp" else 1)
+            if key == "exp":
+                # NO RANK IDLES on the one-input batches: each rank ran K / world of that input's masks through the surrogate
+                # (plus the all-ones forward); two epochs
+                assert got["fw_rows"].count((1, K // world)) == 2 * BATCHES.count(1), got["fw_rows"]
+            # per-batch losses: sum_r (B_r / B) * loss_r == the world-1 batch loss; a batch with fewer inputs than ranks runs in
+            # mask mode where that is possible (explainer: K >= ranks): EVERY rank then computes the whole batch's loss
+            reps = 2 if key == "exp" else 1
+            spans = [D.shard_range(b) for b in BATCHES] * reps
+            sizes = BATCHES * reps
             it = iter(got["losses"])
-            mine = [((hi - lo) / n_) * next(it) if hi > lo else 0.0 for (lo, hi), n_ in zip(spans, sizes)]
+            mine = []
+            for (lo, hi), n_ in zip(spans, sizes):
+                if key == "exp" and n_ < world:
+                    mine.append(next(it) / world)
+                else:
+                    mine.append(((hi - lo) / n_) * next(it) if hi > lo else 0.0)
+            assert next(it, None) is None
             tot = torch.tensor(mine, dtype=torch.float64)
             dist.all_reduce(tot)
             np.testing.assert_allclose(tot.numpy(), np.asarray(ref["losses"]), rtol=1e-5, atol=1e-7)
@@ -240,7 +278,11 @@ def _worker(rank, world, port, path, out):
                 assert torch.equal(both[0], both[1])
             assert (len(got["log"]) > 0) == (rank == 0)            # rank 0 is the only writer
         got, ref = _run_faithfulness(), want["faith"]
-        assert got["evaluated"] == len(range(rank, 7, world))       # samples sharded by image
+        # samples 0..5 sharded by image (three whole forwards of 2*C*S rows per rank); sample 6 — fewer samples than ranks — is
+        # sharded INSIDE the image: both ranks run half of its rows and gather them
+        full = ref["fw_rows"][0]
+        assert ref["fw_rows"] == [full] * 7 and full == 2 * C * 4
+        assert got["fw_rows"] == [full] * 3 + [full // world], got["fw_rows"]
         assert got["report"]["data_cls"] == ref["report"]["data_cls"]
         assert got["report"]["data_ins"] == ref["report"]["data_ins"] and got["report"]["data_del"] == ref["report"]["data_del"]
         for k_ in ("insertion", "deletion", "insertion_non_ok", "deletion_non_ok"):

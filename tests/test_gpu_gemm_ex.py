@@ -123,3 +123,29 @@ def test_gemm_ex_rejects_bad_arguments(cuda_device):
         ops.gemm_ex(a.float(), a, NT, EX_STORE)
     with pytest.raises(RuntimeError):
         ops.gemm_ex(a.cpu(), a.cpu(), NT, EX_STORE)                                                       # no CPU fallback
+
+
+@pytest.mark.parametrize("order", [NT, NN, TN], ids=["NT", "NN", "TN"])
+def test_gemm_ex_staged_epilogue_equals_direct_stores(cuda_device, ag_knobs, order):
+    """the shipped epilogue sends the tile through LDS and stores whole row segments; AG_GEMM_EX_EPI=0 stores straight from the
+    accumulator layout: the same bits, every epilogue, ragged M / N edges included."""
+    from autognothi_amd import ops
+    shapes = {NT: [(1061, 200, 456), (1576, 768, 768)], NN: [(1061, 264, 200), (1576, 768, 768)], TN: [(200, 264, 1056), (768, 768, 1576)]}[order]
+
+    def run_all(da, db, dbias, du, m, n, kc):
+        outs = [ops.gemm_ex(da, db, order, EX_STORE, bias=dbias, out_dtype=ops.F32), ops.gemm_ex(da, db, order, EX_STORE, bias=dbias, out_dtype=ops.BF16),
+                ops.gemm_ex(da, db, order, EX_SLABS, splits=3)]
+        if order != TN:
+            outs += list(ops.gemm_ex(da, db, order, EX_GELU_DUAL, bias=dbias)) + [ops.gemm_ex(da, db, order, EX_GELU_BWD, aux=du)]
+        return outs
+
+    for i, (m, n, kc) in enumerate(shapes):
+        g, da, db, a, b = _operands(order, m, n, kc, 70 + i, cuda_device)
+        dbias = torch.from_numpy(g.standard_normal(n).astype(np.float32)).to(cuda_device)
+        du = _dev((g.standard_normal((m, n)) * 1.5).astype(np.float32), cuda_device)
+        ag_knobs(AG_GEMM_EX_EPI=1)
+        staged = run_all(da, db, dbias, du, m, n, kc)
+        ag_knobs(AG_GEMM_EX_EPI=0)
+        direct = run_all(da, db, dbias, du, m, n, kc)
+        for x, y in zip(staged, direct):
+            assert torch.equal(x, y)

@@ -123,6 +123,51 @@ def test_sharded_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
         torch.testing.assert_close(q0 - q.detach(), 0.5 * 0.5 * w, rtol=1e-4, atol=1e-6 * gscale)
 
 
+def test_mask_mode_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
+    """A global batch with FEWER inputs than ranks (one input, pretending rank 0 of 2): explainer_epoch_train shards the K masks
+    inside the input (common.shard_auto) — this rank draws the WHOLE global mask call, runs masks [0, K/2) through the surrogate,
+    the targets are exchanged through RCCL (gather_masks_within_inputs: here the absent peer's half stays zero) and the explainer
+    takes a whole-batch step with no gradient exchange.  Expected, from the plain pieces: that step on (all K mask rows,
+    v_s = [this rank's half | zeros])."""
+    from autognothi_amd import distributed as D, engine, ops, training as T
+    from autognothi_amd.scripts import train_explainer as te
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    engine.set_precision("fp32")
+    srg = c["surrogate"].to(dev).eval()
+    exp = c["explainer"].to(dev)
+    k, p = c["K"], c["P"]
+    xs1 = torch.from_numpy(c["xs"][:1]).to(dev)
+    zs1 = torch.zeros(1, dtype=torch.long, device=dev)
+    v_0 = torch.full((1, c["g"]["v_0"].shape[1]), 1.0 / c["g"]["v_0"].shape[1], device=dev)
+    seed, epoch = 41, 1
+    bits = ops.mask_shapley_new(ops.DeviceMT19937(dev, seed), k, p, want_i64=False, want_bits=True)[1]
+    with torch.no_grad():
+        v_half, _ = recipe.fw_surrogate(srg, xs1, bits[:k // 2].contiguous())
+        v_1, _ = recipe.fw_surrogate(srg, xs1, torch.ones((1, p), dtype=torch.int64, device=dev))
+    v_s = torch.cat([v_half, torch.zeros_like(v_half)], 0)
+    trainer = T.make_explainer_trainer(recipe, exp)
+    exp.__dict__["_ag_trainer"] = trainer
+    params = [q for q in exp.parameters() if q.requires_grad]
+    exp.train()
+    for q in params:
+        q.grad = None
+    step0 = trainer.step
+    loss, _ = trainer.loss_and_grads(xs1, bits, v_0, v_s, v_1, k, labels=zs1, train=True, seed=seed + epoch)
+    trainer.step = step0
+    want_grad = [q.grad.clone() for q in params]
+    before = [q.detach().clone() for q in params]
+    monkeypatch.setattr(D, "world", lambda: (0, 2))
+    opt = torch.optim.SGD(params, lr=0.5)
+    got = te.explainer_epoch_train(None, dev, k, p, v_0, [(None, None)], recipe, srg, exp, opt, epoch, lambda a, b_: (xs1, zs1), seed=seed)
+    torch.cuda.synchronize()
+    gscale = max(float(w.abs().max()) for w in want_grad)
+    for q, q0, w in zip(params, before, want_grad):     # the whole-batch step, un-weighted, nothing exchanged
+        torch.testing.assert_close(q0 - q.detach(), 0.5 * w, rtol=1e-4, atol=1e-6 * gscale)
+    # epoch figure: this rank reports 1/2 of the batch loss and 1/2 of the sample; the peer's half is absent here: 0.5 L / max(round(0.5), 1)
+    assert got == pytest.approx(0.5 * float(loss), rel=1e-5)
+
+
 def test_bench_under_launcher_runs_rccl_barriers():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py`: the driver's N > 1 launch line with one rank."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -65,6 +65,13 @@ def build_case(tag):
     srg, exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
     synth.load_synth_weights(srg, seed=meta["weights"]["surrogate_seed"])
     synth.load_synth_weights(exp, seed=meta["weights"]["explainer_seed"])
+    tweak = meta.get("explainer_head")      # make_golden.apply_head_tweak: scaled explainer parameters (bert_base_l12_phi)
+    if tweak:
+        with torch.no_grad():
+            for name, prm_ in exp.named_parameters():
+                for key, factor in tweak.get("scale", {}).items():
+                    if key in name:
+                        prm_.mul_(float(factor))
     srg.eval(); exp.eval()
     b, k, p = [int(x) for x in g["dims"]]
     prm = meta["params"]

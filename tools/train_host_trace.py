@@ -23,14 +23,31 @@ v0 = torch.full((1, cfg.num_labels), 0.1, device=dev)
 gen = lambda a, b: (xs, torch.zeros(B, dtype=torch.long, device=dev))
 te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)] * 2, recipe, srg, exp, opt, 1, gen, seed=7)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=False) as prof:
-    te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)] * 2, recipe, srg, exp, opt, 2, gen, seed=7)
-    torch.cuda.synchronize()
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
 cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::clone", "aten::zeros", "aten::ones", "aten::cat", "aten::index", "aten::_to_copy"):
-        st = [s for s in (ev.stack or []) if "autognothi_amd" in s or "bench" in s or "torch/optim" in s]
-        cnt[(ev.name, st[0] if st else "?")] += 1
-for (name, site), n in cnt.most_common(40):
-    print(f"{n:5d} {name:14s} {site}")
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        site = "?"
+        for fr in reversed(traceback.extract_stack()):
+            if ("autognothi_amd" in fr.filename or "torch/optim" in fr.filename) and "train_host_trace" not in fr.filename:
+                site = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
+                break
+        cnt[(name, site)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+STEPS = 2
+with Log():
+    te.explainer_epoch_train(None, dev, K, P, v0, [(None, None)] * STEPS, recipe, srg, exp, opt, 2, gen, seed=7)
+    torch.cuda.synchronize()
+print("aten ops per step by call site (views / metadata ops excluded):")
+skip = ("view", "detach", "reshape", "slice", "select", "t.default", "transpose", "unsqueeze", "expand", "alias", "_unsafe_view", "as_strided",
+        "empty", "size", "stride", "is_", "permute", "squeeze", "_local_scalar", "split", "unbind", "record_stream", "lift_fresh", "numel")
+for (name, site), n in cnt.most_common(200):
+    if any(k in name for k in skip):
+        continue
+    print(f"{n / STEPS:7.1f} {name:40s} {site}")
