@@ -62,6 +62,7 @@ SIGNATURES = {
     "ag_colsum_bf16_scratch_floats": (sz, [i32, i32]),
     "ag_colsum_bf16": (i32, [vp, i32, i32, i64, vp, i32, vp, vp]),
     "ag_cast_f32_many": (i32, [vp, vp, vp, vp, i32, vp]),
+    "ag_set_dropout_salt": (i32, [u32, vp]),
     "ag_pad_cols_f32": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, vp]),
     "ag_masked_attention_train_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_masked_attention_bwd_bf16": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, i32, i32, i32, f32, u32, vp]),

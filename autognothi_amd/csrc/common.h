@@ -72,6 +72,22 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, uint64_t idx, float p) 
     return (float)(h >> 8) * 5.9604644775390625e-08f >= p;
 }
 
+// Dropout salt of the bf16 training step (ag_set_dropout_salt): mixed into the seed of every dropout decision its kernels make, so
+// that a hipGraph-captured step — whose per-site seeds are frozen into the kernel arguments — draws fresh keep patterns at every
+// replay.  0 (the value in eager runs) leaves the seeds as given.  One copy per translation unit that defines the setter below.
+#define AG_DEFINE_DROPOUT_SALT(setter)                                                                                \
+    __device__ uint32_t g_ag_drop_salt = 0u;                                                                          \
+    __device__ __forceinline__ uint32_t ag_salted(uint32_t seed) { return seed ^ (g_ag_drop_salt * 0x9E3779B1u); }    \
+    int setter(uint32_t salt, hipStream_t s) {                                                                        \
+        static uint32_t* pinned = nullptr;                                                                            \
+        static int slot = 0;                                                                                          \
+        if (!pinned && hipHostMalloc((void**)&pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return AG_ERR_HIP; \
+        slot = (slot + 1) & 63;                                                                                       \
+        pinned[slot] = salt;                                                                                          \
+        return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ag_drop_salt), pinned + slot, sizeof(uint32_t), 0, hipMemcpyHostToDevice, s) == hipSuccess \
+                   ? AG_OK : AG_ERR_HIP;                                                                              \
+    }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // bf16-mode GELU with ONE transcendental:  with a = min(|x|, 9) and Q(a) = 1 - Phi(a),

@@ -8,7 +8,10 @@
 // backward (two recompute passes, no atomics, deterministic).
 #include "common.h"
 
+int ag_set_salt_train(uint32_t salt, hipStream_t s);
+
 namespace {
+AG_DEFINE_DROPOUT_SALT(set_salt_here)
 
 // ---- 2-D transpose: dst[c][r] = src[r][c]; dst row stride ldd >= R (caller zero-fills padding) ----
 __global__ void transpose_kernel(const float* __restrict__ src, int R, int Cc, int64_t lds_, float* __restrict__ dst, int64_t ldd) {
@@ -169,6 +172,7 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 
 // inverted dropout (torch.nn.Dropout semantics): y = keep ? x/(1-p) : 0 ; applying it to dy gives dx
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, uint32_t seed) {
+    seed = ag_salted(seed);
     const float sc = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = keep_elem(seed, (uint64_t)i, p) ? x[i] * sc : 0.f;
@@ -176,6 +180,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 // y = resid + dropout(x): the transformer block's "hidden = residual + dropout(dense(...))" in one pass (p = 0: a plain add)
 __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ resid, float* __restrict__ y, int64_t n, float p,
                                    uint32_t seed) {
+    seed = ag_salted(seed);
     const float sc = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = resid[i] + ((p == 0.f || keep_elem(seed, (uint64_t)i, p)) ? x[i] * sc : 0.f);
@@ -481,6 +486,7 @@ __device__ __forceinline__ uint4 pack8_bf16(const float4 a, const float4 b) {
 template <int MODE, bool FWD, bool IO16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    p.seed = ag_salted(p.seed);
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -789,6 +795,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 }  // namespace
+
+int ag_set_salt_train(uint32_t salt, hipStream_t s) { return set_salt_here(salt, s); }
 
 extern "C" int ag_transpose_f32(const float* d_src, int rows, int cols, int64_t lds, float* d_dst, int64_t ldd, void* stream) {
     AG_REQUIRE(d_src && d_dst && rows >= 0 && cols >= 0 && lds >= cols && ldd >= rows, "ag_transpose_f32: bad arguments");

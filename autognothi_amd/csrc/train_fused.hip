@@ -14,7 +14,11 @@
 // One wave per row, the row in registers (H <= 1024), fp32 arithmetic throughout.
 #include "common.h"
 
+int ag_set_salt_fused(uint32_t salt, hipStream_t s);
+int ag_set_salt_train(uint32_t salt, hipStream_t s);   // train.hip
+
 namespace {
+AG_DEFINE_DROPOUT_SALT(set_salt_here)
 
 constexpr int MAXV = 4;   // float4 vectors per lane: H <= 1024
 
@@ -34,6 +38,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.M) return;
+    p.seed = ag_salted(p.seed);
     const long base = (long)row * p.H;
     float4 v[NV];
     bool on[NV];
@@ -116,6 +121,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void rows_ln_bwd_kernel(LnBwdArgs p) {
     __shared__ float4 sacc[4][3][MAXV * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    p.seed = ag_salted(p.seed);
     float4 ag[NV], ab[NV], ac[NV], gv[NV];
     bool on[NV];
 #pragma unroll
@@ -363,6 +369,14 @@ __global__ void pad_cols_kernel(const float* __restrict__ src, long ld_s, int co
 }
 
 }  // namespace
+
+int ag_set_salt_fused(uint32_t salt, hipStream_t s) { return set_salt_here(salt, s); }
+
+extern "C" int ag_set_dropout_salt(uint32_t salt, void* stream) {
+    if (ag_set_salt_fused(salt, (hipStream_t)stream) != AG_OK || ag_set_salt_train(salt, (hipStream_t)stream) != AG_OK)
+        return ag_fail(AG_ERR_HIP, "ag_set_dropout_salt: hipMemcpyToSymbolAsync failed");
+    return AG_OK;
+}
 
 extern "C" int ag_pad_cols_f32(const float* d_src, int64_t ld_src, int cols_src, void* d_dst, int64_t ld_dst, int cols_dst, int dst_dtype,
                                int M, void* stream) {

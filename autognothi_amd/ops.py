@@ -395,6 +395,12 @@ def cast_many(pairs) -> None:
         L.check(L.lib().ag_cast_f32_many(src, dst, cnt, dty, n, L.stream()))
 
 
+def set_dropout_salt(salt: int, device) -> None:
+    """ag_set_dropout_salt on the current stream of ``device`` (0 = the eager default: seeds as given)."""
+    with L.on(device):
+        L.check(L.lib().ag_set_dropout_salt(salt & 0xFFFFFFFF, L.stream()))
+
+
 def pad_cols(src: Tensor, cols_dst: int, dtype: int = F32) -> Tensor:
     """fp32 [M, ld >= C] (first C columns) -> dense [M, cols_dst] fp32 / bf16, zero-filled beyond C (or cut to cols_dst < C)."""
     L.require_gpu(src)

@@ -314,7 +314,10 @@ def train_step_rate(job, dist, n_train, tb, precision):
     opt = torch.optim.AdamW([q for q in m_exp.parameters() if q.requires_grad], lr=1e-5, fused=True)
     v0 = torch.full((1, cfg.num_labels), 1.0 / cfg.num_labels, device=dev)
     gen = lambda a, b_: (tx, labels)  # noqa: E731
-    te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * 2, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
+    # warm-up: one whole look-ahead group (the K-mask targets of consecutive batches run as ONE forward of >= 1 536 rows), so that the
+    # workspace of that forward exists before the timed epoch (its hipMalloc of several GB takes anything from 1 to 100+ ms)
+    n_warm = max(2, -(-1536 // max(1, tb * job.K)))
+    te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * n_warm, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -348,6 +351,83 @@ def train_step_rate(job, dist, n_train, tb, precision):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
+def grad_exchange_overlap(job, dev, tb, steps=6):
+    """Exposed time of the gradient exchange of one explainer training step at ONE rank: every gradient of the vanilla explainer
+    (ViT-base: 104.7 M fp32 = 419 MB) goes through distributed.GradBucketReducer — 64 MiB buckets, each an asynchronous RCCL all-reduce —
+    (a) from inside the backward (training.GRAD_SINK: a bucket is in flight while the layers below still run) and (b) after it,
+    against (c) no exchange.  With one rank the collective moves nothing over xGMI: what is measured is packing, RCCL launch, the
+    in-place reduction and unpacking, and how much of it the backward hides."""
+    import socket
+    import torch.distributed as tdist
+    from autognothi_amd import distributed as D, training as _tr
+    made = False
+    if not tdist.is_initialized():
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        made = True
+    keep_world, keep_mixed = D.world, _tr.MIXED_BF16
+    _tr.MIXED_BF16 = True
+    recipe, cfg = job.recipe, job.cfg
+    try:
+        m_exp = recipe.t_explainer(cfg)
+        synth.load_synth_weights(m_exp, seed=1)
+        m_exp = m_exp.to(dev).train()
+        params = [q for q in m_exp.parameters() if q.requires_grad]
+        trainer = _tr.make_explainer_trainer(recipe, m_exp)
+        xs = torch.from_numpy(job.inputs(tb, 300)).to(dev)
+        c_ = cfg.num_labels
+        bits = ops.mask_shapley_new(ops.DeviceMT19937(dev, 5), tb * job.K, job.P, want_i64=False, want_bits=True)[1]
+        v_s, v_1 = torch.softmax(torch.randn(tb * job.K, c_, device=dev), -1), torch.softmax(torch.randn(tb, c_, device=dev), -1)
+        v_0 = torch.full((1, c_), 1.0 / c_, device=dev)
+        labels = torch.zeros(tb, dtype=torch.long, device=dev)
+        D.world = lambda: (0, 2)         # the reducer issues its collectives (a sum over the one real rank)
+
+        def step(mode):
+            for q in params:
+                q.grad = None
+            red = D.GradBucketReducer(params)
+            if mode == "overlapped":
+                red.begin(0.5)
+                _tr.GRAD_SINK = red.ready
+            try:
+                trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, job.K, labels=labels, train=True, seed=1)
+            finally:
+                _tr.GRAD_SINK = None
+            if mode == "after_backward":
+                red.begin(0.5)
+            return red.finish() if mode != "none" else 0
+
+        out = {}
+        for mode in ("none", "overlapped", "after_backward"):
+            for _ in range(2):
+                n_coll = step(mode)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(steps):
+                step(mode)
+            torch.cuda.synchronize()
+            out[mode] = (time.perf_counter() - t_) / steps * 1e3
+            if mode == "overlapped":
+                out["collectives"] = n_coll
+        gbytes = sum(q.numel() for q in params) * 4 / 1e9
+        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step at ONE rank: no exchange / "
+                        "bucketed all-reduce from inside the backward / the same buckets after the backward; exposed = step - no-exchange step. "
+                        "One rank: nothing crosses xGMI, the figures are packing + RCCL launch + in-place reduction + unpacking",
+                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": out.get("collectives"),
+                "ms_no_exchange": round(out["none"], 3), "ms_overlapped": round(out["overlapped"], 3), "ms_after_backward": round(out["after_backward"], 3),
+                "exposed_ms_overlapped": round(out["overlapped"] - out["none"], 3),
+                "exposed_ms_after_backward": round(out["after_backward"] - out["none"], 3)}
+    finally:
+        D.world = keep_world
+        _tr.MIXED_BF16 = keep_mixed
+        if made:
+            tdist.destroy_process_group()
+
+
 FIXTURE_TAG = {"vit_base": "vit_base_l12", "bert_base": "bert_base_l12", "vit_large": "vit_large_l24",
                "duo_bert_base": "duo_bert_base_l12", "froyo_vit_base": "froyo_vit_base_l12"}
 
@@ -373,10 +453,10 @@ def bf16_vs_reference(workload, dev, tag=None):
     return out
 
 
-def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=None):
+def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=None, masks=0):
     """One BASELINE config as a compact block of the driver line: `steps` timed steps of the same step function, in-library
-    event timing of its dominant kernel class."""
-    job = Job(workload, dev, rank, world, batch, 0, "bf16")
+    event timing of its dominant kernel class.  ``masks``: K masks per input (0: the config's own K)."""
+    job = Job(workload, dev, rank, world, batch, masks, "bf16")
     keep = engine.PRUNE_BERT_TOKENS
     if prune is not None:
         engine.PRUNE_BERT_TOKENS = prune
@@ -559,6 +639,14 @@ def main():
         cfgs["bert_base_tayp_vanilla_seq128_K32"] = compact_config_line("bert_base", dev, rank, world, 48, dist)
         cfgs["bert_base_tayp_vanilla_seq128_K32_token_pruning_off"] = compact_config_line("bert_base", dev, rank, world, 48, dist, prune=False)
         cfgs["vit_large_imagenette_vanilla_K64"] = compact_config_line("vit_large", dev, rank, world, 48, dist, steps=3)
+        # the per-GPU shard of BASELINE config 4 under STRONG scaling over 8 GPUs: one ViT-large input x 64 masks per GPU (64 rows)
+        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_1_input_per_gpu"] = dict(
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10),
+            note="what each of 8 GPUs runs when a step of 8 inputs x K = 64 is sharded by input; with ONE input per step the shard is 8 masks "
+                 "per GPU (scripts/common.shard_auto: K-within-image): see ..._8_masks_per_gpu")
+        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_8_masks_per_gpu"] = dict(
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, masks=8),
+            note="config 4 at ONE input per step over 8 GPUs: every GPU embeds the input and runs 8 of its 64 masks")
         secondary["baseline_configs"] = {"what": "BASELINE.json configs 3 and 4 at one GPU per rank: masked-forwards/s, dominant-kernel "
                                                  "fraction of the 2.5 PF bf16 peak (in-library hipEvents), whole-step executed fraction",
                                          "configs": cfgs}
@@ -648,6 +736,23 @@ def main():
                           "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
                                        "frac": round(tf5 / peak, 4)}}
                 del j5
+            # the per-GPU shard of config 5 under strong scaling: the reference trains on 2-4 images per step and GPU
+            shards = {}
+            for wl in ("duo_bert_base", "froyo_vit_base"):
+                for tb_ in (2, 4):
+                    j5 = Job(wl, dev, rank, world, tb_, 0, args.precision)
+                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision)
+                    tf5 = r5 / world / tb_ * f5 / 1e12
+                    shards[f"{wl}_{tb_}_images_per_gpu"] = {"value": round(r5, 1), "unit": "images/s", "images_per_gpu_per_step": tb_,
+                                                              "ms_per_step": round(1e3 * tb_ * world / r5, 3), "frac": round(tf5 / peak, 4),
+                                                              "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1)}
+                    del j5
+            c5["strong_scaling_shards"] = shards
+            if world == 1 and rank == 0:
+                try:
+                    c5["gradient_exchange_overlap"] = grad_exchange_overlap(job, dev, args.train_batch)
+                except Exception as exc:   # (no RCCL on the box: the line still goes out)
+                    c5["gradient_exchange_overlap"] = {"error": repr(exc)[:200]}
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed

@@ -413,6 +413,11 @@ int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int
  * weight of a model after the optimiser step, q | k | v landing side by side in their fused buffer.  HOST arrays of DEVICE pointers
  * (passed to the kernel by value: no table copy, graph-capturable); segments 16-byte aligned. */
 int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, void* stream);
+/* Dropout salt of the bf16 training step: mixed into the seed of every dropout decision of ag_rows_finish, ag_rows_ln_bwd,
+ * ag_masked_attention_*_bf16 / _mixed, ag_dropout_f32 and ag_dropout_add_f32 (seed ^ salt * 0x9E3779B1).  A hipGraph-captured step has
+ * its per-site seeds frozen into the kernel arguments; setting a new salt before each replay (stream-ordered, outside the graph)
+ * gives it fresh keep patterns.  0 — the value until this is called — leaves seeds as given. */
+int ag_set_dropout_salt(uint32_t salt, void* stream);
 /* dst[m, c] = c < cols_src ? src[m, c] : 0 for c < cols_dst; dst fp32 or bf16 (dst_dtype).  Pads the C-wide output / gradient of the
  * explainer's last Linear (C = 10 / 2 classes, models/vanilla_vit.py:92-100) to the 16 columns ag_gemm_ex wants, or strips them. */
 int ag_pad_cols_f32(const float* d_src, int64_t ld_src, int cols_src, void* d_dst, int64_t ld_dst, int cols_dst, int dst_dtype, int M,
