@@ -1401,19 +1401,27 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         if (a.R && a.share == 1 && (unsigned long long)a.M * (unsigned long long)a.ldr < 0x7FFFFFF0ull && (int)k_rlds.get(1) != 0)
             return launch_stream_var<EPI, VAR, true>(a, s);
     }
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
+    // per device (a process may drive several: the attribute belongs to the device's copy of the code object, and partitions
+    // differ in their CU count)
+    constexpr int MAX_DEV = 16;
+    static bool attr_set[MAX_DEV] = {};
+    static int n_cu_of[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ag_fail(AG_ERR_HIP, "gemm_stream: hipGetDevice");
+    if (dev < 0 || dev >= MAX_DEV) return ag_fail(AG_ERR_UNSUPPORTED, "gemm_stream: device index %d", dev);
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream): %s", hipGetErrorString(e));
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return ag_fail(AG_ERR_HIP, "gemm_stream: device properties");
-        n_cu = prop.multiProcessorCount & ~7;        // one resident workgroup per CU; a multiple of the 8 XCDs keeps a workgroup's tiles on its XCD
-        attr_set = true;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ag_fail(AG_ERR_HIP, "gemm_stream: device properties");
+        // one resident workgroup per CU; a multiple of the 8 XCDs keeps a workgroup's tiles on its XCD (a partition with fewer than
+        // 8 CUs: every CU)
+        const int cu = prop.multiProcessorCount;
+        n_cu_of[dev] = cu >= 8 ? (cu & ~7) : (cu > 0 ? cu : 1);
+        attr_set[dev] = true;
     }
+    const int n_cu = n_cu_of[dev];
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
     hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();

@@ -198,6 +198,7 @@ class GradBucketReducer:
         self._seen = set()
         self.collectives = 0
         self._weight: Optional[float] = None
+        self._known = None            # ids of the parameters that received a gradient in the last regular (non-ragged) step
 
     def begin(self, weight: Optional[float] = None) -> None:
         """Start a step.  ``weight`` = this rank's share of the step's global batch (inputs of this rank / inputs of all ranks):
@@ -237,9 +238,15 @@ class GradBucketReducer:
         the others: such steps run un-instrumented on all ranks, in parameter order)."""
         _, w = world()
         if w > 1:
+            if not fill_missing:                  # a regular step: remember which parameters a backward gives a gradient to
+                self._known = {id(p) for p in self.params if p.grad is not None}
+            filled = []
             for p in self.params:                 # gradients nobody reported (un-instrumented backward)
-                if p.grad is None and fill_missing:
+                if p.grad is None and fill_missing and (self._known is None or id(p) in self._known):
+                    # (only parameters a backward DOES reach: a zero gradient for, e.g., a head outside the loss would make AdamW
+                    # decay it and start its moments on ragged steps only — the single-process run leaves it untouched)
                     p.grad = torch.zeros_like(p)
+                    filled.append(p)
                 if p.grad is not None and id(p) not in self._seen:
                     self.ready(p)
             self._flush()

@@ -303,8 +303,10 @@ _SCRATCH = {}
 
 
 def _scratch(dev, floats: int) -> Tensor:
-    """a grow-only fp32 scratch buffer per device (per-block partials of the row kernels; consumed inside the call that fills it)."""
-    key = str(dev)
+    """a grow-only fp32 scratch buffer per device AND stream (per-block partials of the row kernels, consumed inside the call that
+    fills it: stream order protects it on one stream — the backward's side streams run such kernels concurrently with the main
+    stream's, so each stream has its own)."""
+    key = (str(dev), L.stream())
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < floats:
         buf = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=dev)

@@ -6,6 +6,13 @@ from typing import Any, Callable, Optional
 import torch
 
 
+# Dropout keys of row-sharded ranks: trainer.loss_and_grads(seed=...) gets ``seed + epoch + DROPOUT_RANK_STRIDE * lo`` (lo = this
+# rank's first input of the global batch), so that rank r's local row i does not share its keep pattern with rank 0's row i.
+# One rank (lo = 0): the single-process keys.  The keep decisions are a counter hash, not torch's Philox stream, so an N-rank run
+# with dropout is statistically — not bitwise — the single-process run; with p = 0 it is equal to it.
+DROPOUT_RANK_STRIDE = 1000003
+
+
 class Log:
     """Stand-in for the reference's ExpEnv (scripts/env.py:13): only ``.log`` is used by the loop bodies."""
 

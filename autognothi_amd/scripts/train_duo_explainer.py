@@ -12,7 +12,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, MaskSource, mask_source as common_mask_source, shard_auto
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard_auto
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -83,7 +83,8 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
             _training.GRAD_SINK = reducer.ready if (reducer is not None and not ragged) else None
             try:
                 if hi > lo:
-                    trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True, seed=(seed or 0) + epoch)
+                    trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
+                                           seed=(seed or 0) + epoch + DROPOUT_RANK_STRIDE * lo)
             finally:
                 _training.GRAD_SINK = None
             if reducer is not None:

@@ -17,7 +17,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, MaskSource, Span, device_rng, shard, shard_auto
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, shard, shard_auto
 from .common import mask_source as common_mask_source
 
 
@@ -239,7 +239,7 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         try:
             if hi > lo:
                 loss, _phi = trainer.loss_and_grads(xs, bits, v_0, v_s, v_1, n_mask_samples, labels=zs, train=True,
-                                                    seed=(seed or 0) + epoch)
+                                                    seed=(seed or 0) + epoch + DROPOUT_RANK_STRIDE * lo)
                 loss = loss.reshape(())
             else:
                 loss = torch.zeros((), dtype=torch.float32, device=v_0.device)

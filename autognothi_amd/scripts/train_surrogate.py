@@ -11,7 +11,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import Log, MaskSource, mask_source as common_mask_source, shard
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard
 
 
 def surrogate_batch_loss(recipe: ModelRecipe, m_classifier, m_surrogate, xs: Tensor, n_players: int, rng,
@@ -80,6 +80,7 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
     _, n_ranks = distributed.world()
     reducer = distributed.GradBucketReducer(m_surrogate.parameters()) if n_ranks > 1 else None
     parts = []                                    # device scalars (loss * local batch): read once per epoch
+    running = None                                # their running sum (what the per-batch log of the reference prints)
     for batch_idx, (_inputs, _targets) in enumerate(d_items):
         xs, _ = gen_input(_inputs, _targets)
         xs, _, n_tot, lo, hi = shard(xs)
@@ -95,8 +96,11 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
                 ones = torch.ones((b, n_players), dtype=torch.long, device=xs.device)
                 with torch.no_grad():
                     _, orig = m_recipe.fw_classifier(m_classifier, xs, ones)   # second output (reference :141)
-                loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch)
+                # (dropout keys: the same (seed, epoch) on every rank, offset by this rank's first input so that two ranks never
+                # draw the same keep pattern for different inputs; lo = 0 at one rank)
+                loss, _probs = trainer.loss_and_grads(xs, bits, orig, train=True, seed=(seed or 0) + epoch + DROPOUT_RANK_STRIDE * lo)
                 parts.append(loss.reshape(()).float() * b)
+                running = parts[-1] if running is None else running + parts[-1]
         finally:
             _training.GRAD_SINK = None
         if reducer is not None:
@@ -104,7 +108,7 @@ def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_item
         optimizer.step()
         n += b
         if getattr(env, "log_every_step", False) and n_ranks == 1 and b:   # the reference logs every batch (a host read per step)
-            env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: kl {float(torch.stack(parts).sum().item()) / n:.6f}")
+            env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: kl {float(running.item()) / n:.6f}")
     tot = float(torch.stack(parts).sum().item()) if parts else 0.0
     tot, n = distributed.reduce_scalars([tot, n], device)
     env.log(f"  > epoch {epoch} :train // loss: kl {tot / max(n, 1):.6f}")

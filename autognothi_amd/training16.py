@@ -35,6 +35,11 @@ BF16, F32 = L.AG_BF16, L.AG_F32
 VIT, BERT = L.AG_MASK_VIT_MUL, L.AG_MASK_BERT_ADD
 SIDE_STREAM = os.environ.get("AG_TRAIN_SIDE", "1") != "0"
 N_SIDE = max(1, int(os.environ.get("AG_TRAIN_SIDE", "1") or 1))     # number of side streams (AG_TRAIN_SIDE=0: none)
+# hipGraph capture of the explainer step (forward + loss + backward, both streams): "1" on, "0" off (the default: the epoch bodies
+# keep the GPU busy with the K-mask target forward while the host issues the step, so eager launches cost nothing there; it pays at
+# 2-4 images per step, where the ~420 launches are host-bound).  Never used while a gradient sink is installed (N > 1 ranks: the
+# bucket reducer must be told, kernel by kernel, which gradients are final).
+GRAPH_STEP = os.environ.get("AG_TRAIN_GRAPH", "0") == "1"
 
 
 def supported(module: nn.Module) -> bool:
@@ -138,6 +143,15 @@ class WeightBank:
         lw = LinW(mods, pad_rows_to, self.device)
         self.lins.append(lw)
         return lw
+
+    def keys(self, trainable: bool):
+        """current parameter keys of the trainable (or the frozen) Linears: what a captured step compares to notice a reload."""
+        return tuple(tuple(engine.param_key(p) for m in lw.mods for p in (m.weight, m.bias)) for lw in self.lins if lw.trainable == trainable)
+
+    def invalidate(self, trainable: bool) -> None:
+        for lw in self.lins:
+            if lw.trainable == trainable:
+                lw.key = None
 
     def refresh(self) -> None:
         pairs = []
@@ -570,6 +584,56 @@ def _cls_rows(z: Tensor, b: int, t: int, h: int) -> Tensor:
     return z.view(b, t, h)[:, 0, :].contiguous()
 
 
+# ------------------------------------------------------------------------------------------------ captured step
+class _StepGraph:
+    """One hipGraph of ``trainer._loss_and_grads_eager`` (weight refresh + forward + loss + backward on the main and the side
+    streams) for fixed input shapes.  Inputs are copied into static buffers, the graph is replayed, the parameters get the graph's
+    gradient tensors as ``.grad`` (the caller's optimiser then steps eagerly).  Per-site dropout seeds are frozen into the kernel
+    arguments at capture; ``ag_set_dropout_salt`` before every replay makes each replay draw new keep patterns."""
+
+    def __init__(self, trainer, xs, bits_loss, v_0, v_s, v_1, k, labels, train, seed):
+        self.trainer = trainer
+        self.static = [t.clone() if t is not None else None for t in (xs, bits_loss, v_0, v_s, v_1, labels)]
+        self.k, self.train = k, train
+        self.params = [p for p in trainer.m.parameters() if p.requires_grad]
+        self.param_ids = tuple(id(p) for p in self.params)
+        self.ptrs = tuple(p.data_ptr() for p in trainer.m.parameters())
+        self.frozen_key = trainer.bank.keys(trainable=False)
+        dev = xs.device
+        trainer.bank.invalidate(trainable=True)          # the refresh of every trainable weight becomes part of the graph
+        for lin in (trainer.cls, trainer.pool):
+            if lin is not None:
+                lin._wkey = None
+        ops.set_dropout_salt(0, dev)
+        for p in self.params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            sx, sb, s0, ss, s1, sl = self.static
+            self.total, self.phi = trainer._loss_and_grads_eager(sx, sb, s0, ss, s1, k, sl, train, seed)
+            self.parts = trainer.last_parts
+        self.grads = [(p, p.grad) for p in self.params if p.grad is not None]
+        for p in self.params:
+            p.grad = None
+
+    def valid(self, trainer) -> bool:
+        return (self.ptrs == tuple(p.data_ptr() for p in trainer.m.parameters()) and self.frozen_key == trainer.bank.keys(trainable=False)
+                and tuple(id(p) for p in trainer.m.parameters() if p.requires_grad) == self.param_ids)
+
+    def run(self, xs, bits_loss, v_0, v_s, v_1, labels, salt: int):
+        for dst, src in zip(self.static, (xs, bits_loss, v_0, v_s, v_1, labels)):
+            if dst is not None:
+                dst.copy_(src)
+        ops.set_dropout_salt(salt, xs.device)
+        self.graph.replay()
+        ops.set_dropout_salt(0, xs.device)
+        for p, g in self.grads:
+            T._touch(p)
+            p.grad = g
+        self.trainer.last_parts = self.parts
+        return self.total.clone(), self.phi
+
+
 # ------------------------------------------------------------------------------------------------ trainers
 class ExplainerTrainer16:
     """fw_explainer + loss_shapley_new with gradients (vanilla / froyo / duo; ViT or BERT) on the bf16 step."""
@@ -593,6 +657,9 @@ class ExplainerTrainer16:
         self.pool = T.Lin([m_explainer.bert_pooler.dense]) if (self.duo and not self.is_vit) else None
         self.step = 0
         self.saved = None
+        self.use_graph = GRAPH_STEP
+        self.graph_salt: Optional[int] = None     # tests: a fixed dropout salt for every replay (0 = the captured step's own patterns)
+        self._graphs, self._seen = {}, set()
 
     def forward_phi(self, xs: Tensor, v_0: Optional[Tensor], v_1: Optional[Tensor], train: bool = True, seed: int = 0,
                     bits: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
@@ -712,6 +779,25 @@ class ExplainerTrainer16:
 
     def loss_and_grads(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
                        labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
+        """One reference training-step body (scripts/train_explainer.py:182-196 / train_duo_explainer.py:180-196) -> (loss, phi).
+        With ``use_graph`` (AG_TRAIN_GRAPH=1) the step is captured into a hipGraph at its second call with a given set of shapes
+        and replayed from then on (gradients bit-identical to the eager step; phi is then the graph's static output buffer)."""
+        if self.use_graph and T.GRAD_SINK is None and all(p.grad is None for p in self.m.parameters() if p.requires_grad):
+            key = (tuple(xs.shape), xs.dtype, tuple(bits_loss.shape), tuple(v_s.shape), n_mask_samples, bool(train), labels is None)
+            g = self._graphs.get(key)
+            if g is not None and not g.valid(self):
+                g = None
+            if g is None and key in self._seen:
+                g = self._graphs[key] = _StepGraph(self, xs, bits_loss, v_0, v_s, v_1, n_mask_samples, labels, train, seed)
+            if g is not None:
+                self.step += 1
+                salt = ((seed * 7919 + self.step) * 2654435761) & 0xFFFFFFFF if self.graph_salt is None else self.graph_salt
+                return g.run(xs, bits_loss, v_0, v_s, v_1, labels, salt=salt)
+            self._seen.add(key)          # first call with these shapes: eager (allocates every lazily created buffer)
+        return self._loss_and_grads_eager(xs, bits_loss, v_0, v_s, v_1, n_mask_samples, labels, train, seed)
+
+    def _loss_and_grads_eager(self, xs: Tensor, bits_loss: Tensor, v_0: Tensor, v_s: Tensor, v_1: Tensor, n_mask_samples: int,
+                              labels: Optional[Tensor] = None, train: bool = True, seed: int = 0):
         b = xs.shape[0]
         phi, base = self.forward_phi(xs, v_0, v_1, train, seed)
         loss, dphi = ops.shapley_loss(bits_loss, v_0, v_s, phi, b, n_mask_samples, want_grad=True)

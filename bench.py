@@ -296,12 +296,16 @@ def timed(fn, steps, warmup, dist, dev):
 LAST_TRAIN_LAUNCHES = [0.0]   # kernels of this library per training step in the last train_step_rate call (targets + grand + fwd/bwd)
 
 
-def train_step_rate(job, dist, n_train, tb, precision):
+def train_step_rate(job, dist, n_train, tb, precision, graph=False):
     """One reference _explainer_epoch_train body per step (scripts/train_explainer.py:128-207) = K-mask surrogate targets
-    (inference path) + the all-ones grand forward + explainer forward/backward + AdamW.  -> (images/s, flops per step)."""
+    (inference path) + the all-ones grand forward + explainer forward/backward + AdamW.  -> (images/s, flops per step).
+    ``graph``: the explainer forward + loss + backward replayed from a hipGraph (training16.GRAPH_STEP; one rank only)."""
     from autognothi_amd import training as _tr
+    from autognothi_amd import training16 as _tr16
     from autognothi_amd.scripts import train_explainer as te
     _tr.MIXED_BF16 = precision == "bf16"   # throughput mode: bf16 GEMM operands (autocast semantics), fp32 everything else
+    keep_graph = _tr16.GRAPH_STEP
+    _tr16.GRAPH_STEP = bool(graph) and precision == "bf16" and job.world == 1
     recipe, cfg, dev = job.recipe, job.cfg, job.dev
     m_exp = recipe.t_explainer(cfg)
     synth.load_synth_weights(m_exp, seed=1)
@@ -348,6 +352,7 @@ def train_step_rate(job, dist, n_train, tb, precision):
     job.surrogate.eval()
     del m_exp, opt
     _tr.MIXED_BF16 = False
+    _tr16.GRAPH_STEP = keep_graph
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
@@ -711,9 +716,18 @@ def main():
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         rate, f_step, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision)
+        launches_eager = LAST_TRAIN_LAUNCHES[0]
+        rate_graph = None
+        if world == 1 and args.precision == "bf16" and not args.no_secondary:
+            rate_graph, _, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision, graph=True)
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                       "steps": 12, "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
+                       "steps": 12, "library_launches_per_step": round(launches_eager, 1),
+                       "launch": "eager (the epoch body keeps the GPU busy with the K-mask target forward of the next batches while the host "
+                                 "issues the step)",
+                       "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
+                       "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
+                                       "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
                        "sharding": "global batch = images_per_gpu_per_step x ranks; rank r trains on its input slice with its rows of the one "
                                    "global mask call; gradients summed over RCCL in 64 MiB buckets from inside the backward "
                                    "(scripts/train_explainer.explainer_epoch_train)",
@@ -742,10 +756,14 @@ def main():
                 for tb_ in (2, 4):
                     j5 = Job(wl, dev, rank, world, tb_, 0, args.precision)
                     r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision)
+                    l5 = LAST_TRAIN_LAUNCHES[0]
+                    r5g = train_step_rate(j5, dist, 12, tb_, args.precision, graph=True)[0] if world == 1 else None
                     tf5 = r5 / world / tb_ * f5 / 1e12
                     shards[f"{wl}_{tb_}_images_per_gpu"] = {"value": round(r5, 1), "unit": "images/s", "images_per_gpu_per_step": tb_,
                                                               "ms_per_step": round(1e3 * tb_ * world / r5, 3), "frac": round(tf5 / peak, 4),
-                                                              "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1)}
+                                                              "graph_replay_value": None if r5g is None else round(r5g, 1),
+                                                              "graph_replay_frac": None if r5g is None else round(r5g / world / tb_ * f5 / 1e12 / peak, 4),
+                                                              "library_launches_per_step": round(l5, 1)}
                     del j5
             c5["strong_scaling_shards"] = shards
             if world == 1 and rank == 0:

@@ -27,6 +27,7 @@ labels = torch.zeros(B, dtype=torch.long, device=dev)
 opt = torch.optim.AdamW([q for q in exp.parameters() if q.requires_grad], lr=1e-5, fused=True)
 engine.watch_optimizer(opt)
 tr = _tr.make_explainer_trainer(recipe, exp)
+tr.use_graph = os.environ.get("AG_TRAIN_GRAPH", "0") == "1"
 
 
 def step():
