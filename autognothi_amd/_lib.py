@@ -122,7 +122,18 @@ SIGNATURES = {
     "ag_masked_attention_varlen": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
 }
 
+# test infrastructure (never loaded by the product path): the same library built with -DAG_REF_KERNELS, i.e. with the two earlier
+# large-M GEMM generations the shipped stream kernel is checked against bit for bit (tests/test_gpu_gemm_ring.py: use_library)
+REF_LIB_PATH = os.path.join(_HERE, "lib", "libautognothi_hip_ref.so")
+
 _lib: Optional[C.CDLL] = None
+_handles = {}
+
+
+def use_library(path: Optional[str] = None) -> None:
+    """switch every later call of this process to the library at ``path`` (None: back to LIB_PATH).  Parity tests only."""
+    global _lib
+    _lib = None if path is None else _load(path)
 
 
 class HipLibraryMissing(RuntimeError):
@@ -133,16 +144,22 @@ def lib() -> C.CDLL:
     """Load (once) and return the shared library; raise loudly if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path: str) -> C.CDLL:
+    if path not in _handles:
+        if not os.path.exists(path):
             raise HipLibraryMissing(
-                f"{LIB_PATH} is not built; there is no CPU fallback. Run "
+                f"{path} is not built; there is no CPU fallback. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` from the repo root.")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here = header/library drift
             fn.restype, fn.argtypes = res, args
-        _lib = handle
-    return _lib
+        _handles[path] = handle
+    return _handles[path]
 
 
 def check(rc: int) -> None:

@@ -312,6 +312,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     }
 }
 
+#ifdef AG_REF_KERNELS   // the round-1/2 ring kernel: parity reference of the shipped kernel (libautognothi_hip_ref.so: tests only)
 // VAR: 0 plain, 1 LayerNorm-folded consumer (ln_stats / ln_s), 2 row-statistics producer (stats_out), 3 producer whose
 // residual is the LayerNorm of the stored pre-LN rows (BERT post-LN: ln_stats / rln_g / rln_b describe R)
 template <int EPI, int VAR = 0, bool DBG = false>
@@ -593,6 +594,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
 #undef AG_MARK
 }
 
+#endif  // AG_REF_KERNELS
+
 // =====================================================================================================================
 // gemm_line_kernel — the same tile, waves, phases and epilogue, fed by WHOLE 128-byte cache lines.
 //
@@ -682,6 +685,7 @@ __device__ __forceinline__ void l2_touch(const char* base, uint32_t voff, uint32
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_sink) : "memory");
 }
 
+#ifdef AG_REF_KERNELS   // one tile per workgroup on the whole-line feed: A/B + parity reference of the stream kernel (tests only)
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
     BigArgs p = pin;
@@ -982,6 +986,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         if (tid == 0) { p.dbg[8 * (long)b + 1] = t1; p.dbg[8 * (long)b + 2] = t2; }
     }
 }
+
+#endif  // AG_REF_KERNELS
 
 // gemm_stream_kernel — gemm_line_kernel as ONE request stream per CU.
 //
@@ -1428,6 +1434,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
     return AG_OK;
 }
 
+#ifdef AG_REF_KERNELS
 template <int EPI, int VAR>
 int launch_line_var(const BigArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -1442,9 +1449,15 @@ int launch_line_var(const BigArgs& a, hipStream_t s) {
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
+#endif
 
+// The shipped library carries ONE large-M kernel, gemm_stream_kernel (K % 128 == 0: every encoder shape of the base / large
+// configurations).  The reference build (-DAG_REF_KERNELS -> libautognothi_hip_ref.so, loaded by the parity tests only) adds the two
+// earlier generations behind AG_GEMM_STREAM=0 (gemm_line_kernel) and AG_GEMM_LINE=0 / K % 128 != 0 (gemm_ring_kernel): the stream
+// kernel's every epilogue is tested bit for bit against them.
 template <int EPI, int VAR>
 int launch_ring_var(const BigArgs& a, hipStream_t s) {
+#ifdef AG_REF_KERNELS
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI, VAR>),
@@ -1452,7 +1465,6 @@ int launch_ring_var(const BigArgs& a, hipStream_t s) {
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_ring): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    // whole-line staging (K = 64 steps, gemm_line_kernel) wherever K allows; AG_GEMM_LINE=0 keeps the K = 32 ring (A/B, parity tests)
     static AgKnob k_line("AG_GEMM_LINE");
     static AgKnob k_stream("AG_GEMM_STREAM");
     if (a.K % 128 == 0 && (int)k_line.get(1) != 0 && (int)k_stream.get(1) != 0) return launch_stream_var<EPI, VAR>(a, s);
@@ -1461,6 +1473,10 @@ int launch_ring_var(const BigArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_ring_kernel<EPI, VAR>), dim3(tiles), dim3(NT), LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
+#else
+    if (a.K % 128 != 0) return ag_fail(AG_ERR_UNSUPPORTED, "ag_gemm_big: K=%d is not a multiple of 128 (ag_gemm_big_eligible)", a.K);
+    return launch_stream_var<EPI, VAR>(a, s);
+#endif
 }
 
 template <int EPI>
@@ -1475,6 +1491,7 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
         if constexpr (CAN_STATS) return launch_ring_var<EPI, 2>(a, s);
         else return ag_fail(AG_ERR_INVALID, "ag_gemm: row statistics are built for the bias+residual epilogue only");
     }
+#ifdef AG_REF_KERNELS
     if (a.dbg && EPI == AG_EPI_BIAS) {  // diagnostic (stamped) build, tools/gemm_stamps.py
         static bool dset = false;
         if (!dset) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<AG_EPI_BIAS, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); dset = true; }
@@ -1483,6 +1500,7 @@ int launch_ring(const BigArgs& a, hipStream_t s) {
         AG_LAUNCH_CHECK();
         return AG_OK;
     }
+#endif
     return launch_ring_var<EPI, 0>(a, s);
 }
 
@@ -1500,7 +1518,12 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
     static AgKnob k_min_tiles("AG_GEMM_BIG_MIN_TILES");    // (the kernel parity tests pin the ring with it: ag_reload_knobs)
     const int min_tiles = (int)k_min_tiles.get(epilogue == AG_EPI_BIAS_F32 ? 130 : 48);
     if ((long)ceil_div(M, BT) * ceil_div(N, BT) < min_tiles) return false;
-    return M >= 1024 && N >= 256 && (N % 8) == 0 && K % 32 == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
+#ifdef AG_REF_KERNELS
+    constexpr int KMULT = 32;      // (the ring kernel walks K in 32-element half-steps)
+#else
+    constexpr int KMULT = 128;     // the stream kernel's step pair; other K (ViT-tiny's 192) go to the 128-tile kernel of gemm.hip
+#endif
+    return M >= 1024 && N >= 256 && (N % 8) == 0 && K % KMULT == 0 && K >= 128 && (lda % 8) == 0 && (ldc % 8) == 0 &&
            (epilogue != AG_EPI_BIAS_RESID || (ldr % 4) == 0);
 }
 

@@ -22,6 +22,46 @@ AG_DEFINE_DROPOUT_SALT(set_salt_here)
 
 constexpr int MAXV = 4;   // float4 vectors per lane: H <= 1024
 
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// v[i] = sum over slabs of the NV float4 vectors of one row, ADDED IN SLAB ORDER (bit-reproducible) with the loads of four slabs in
+// flight at a time (a runtime-length loop of load -> add serialises one memory round trip per slab: 6 slabs x 3 vectors took the row
+// kernels 20+ us at 1 576 rows)
+template <int NV>
+__device__ __forceinline__ void slab_sum(const float* __restrict__ slabs, int splits, long stride, long base, int lane, int H, float4 (&v)[NV]) {
+    const float* p0 = slabs + base;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < H ? *reinterpret_cast<const float4*>(p0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {
+        float4 y[4][NV];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                y[j][i] = c < H ? *reinterpret_cast<const float4*>(p0 + (long)(k + j) * stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) add4(v[i], y[j][i]);
+    }
+    for (; k < splits; ++k) {
+        float4 y[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            y[i] = c < H ? *reinterpret_cast<const float4*>(p0 + (long)k * stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) add4(v[i], y[i]);
+    }
+}
+
 struct RowsArgs {
     const float* slabs; int splits; long slab_stride;
     const float* bias;
@@ -43,17 +83,13 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(RowsArgs p) {
     float4 v[NV];
     bool on[NV];
     const float sc = 1.0f / (1.0f - p.pdrop);
+    slab_sum<NV>(p.slabs, p.splits, p.slab_stride, base, lane, p.H, v);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         on[i] = c < p.H;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!on[i]) continue;
-        float4 x = *reinterpret_cast<const float4*>(p.slabs + base + c);
-        for (int s = 1; s < p.splits; ++s) {
-            const float4 y = *reinterpret_cast<const float4*>(p.slabs + (long)s * p.slab_stride + base + c);
-            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
-        }
+        float4 x = v[i];
         if (p.bias) {
             const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
             x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
@@ -137,16 +173,13 @@ __global__ __launch_bounds__(256) void rows_ln_bwd_kernel(LnBwdArgs p) {
         const long base = (long)row * p.H;
         float4 dv[NV], xv[NV];
         float s = 0.f;
+        slab_sum<NV>(p.slabs, p.splits, p.slab_stride, base, lane, p.H, dv);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
-            dv[i] = xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!on[i]) continue;
-            float4 d = *reinterpret_cast<const float4*>(p.slabs + base + c);
-            for (int k = 1; k < p.splits; ++k) {
-                const float4 y = *reinterpret_cast<const float4*>(p.slabs + (long)k * p.slab_stride + base + c);
-                d.x += y.x; d.y += y.y; d.z += y.z; d.w += y.w;
-            }
+            float4 d = dv[i];
             if (p.dy_add) {
                 const float4 y = *reinterpret_cast<const float4*>(p.dy_add + base + c);
                 d.x += y.x; d.y += y.y; d.z += y.z; d.w += y.w;
@@ -278,41 +311,48 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
-// column sums of a bf16 [M, N] matrix (N % 8 == 0): a block owns 64 x 8 = 512... columns [512 b, +512) as 64 lanes x 8 columns, its 4 waves
-// walk rows w, w + 4, ...; the waves' partials are folded through LDS in wave order (fixed tree: bit-reproducible)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int M, int N, long ldx, float* __restrict__ out, int accumulate,
-                                                          int rows_per_block, float* __restrict__ part) {
-    __shared__ float sacc[4][64][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 8;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+// column sums of a bf16 [M, N] matrix (N % 8 == 0) in ONE launch: a block owns 32 columns (4 chunks of 8 = 16 bytes) for all rows, its
+// 256 threads are 4 chunks x 64 row groups; row group g walks rows g, g + 64, ... in order and the 64 partials of a column are added
+// in group order by one thread: a fixed summation tree, bit-reproducible, no scratch.  (The first version spread the rows over
+// blocks and folded them in a second launch: two dependent launches of 8 us each for 5-10 MB of input.)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, int M, int N, long ldx, float* __restrict__ out, int accumulate) {
+    __shared__ float sacc[64][4][8];
+    const int cg = threadIdx.x & 3, rg = threadIdx.x >> 2;
+    const int c = blockIdx.x * 32 + cg * 8;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c < N)
-        for (int m = r0 + wave; m < r1; m += 4) {
+    if (c < N) {
+        int m = rg;
+        for (; m + 192 < M; m += 256) {          // four independent loads in flight per thread
+            uint4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const uint4*>(x + (long)(m + 64 * j) * ldx + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[0] += __uint_as_float(u[j].x << 16); a[1] += __uint_as_float(u[j].x & 0xFFFF0000u);
+                a[2] += __uint_as_float(u[j].y << 16); a[3] += __uint_as_float(u[j].y & 0xFFFF0000u);
+                a[4] += __uint_as_float(u[j].z << 16); a[5] += __uint_as_float(u[j].z & 0xFFFF0000u);
+                a[6] += __uint_as_float(u[j].w << 16); a[7] += __uint_as_float(u[j].w & 0xFFFF0000u);
+            }
+        }
+        for (; m < M; m += 64) {
             const uint4 u = *reinterpret_cast<const uint4*>(x + (long)m * ldx + c);
             a[0] += __uint_as_float(u.x << 16); a[1] += __uint_as_float(u.x & 0xFFFF0000u);
             a[2] += __uint_as_float(u.y << 16); a[3] += __uint_as_float(u.y & 0xFFFF0000u);
             a[4] += __uint_as_float(u.z << 16); a[5] += __uint_as_float(u.z & 0xFFFF0000u);
             a[6] += __uint_as_float(u.w << 16); a[7] += __uint_as_float(u.w & 0xFFFF0000u);
         }
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sacc[wave][lane][j] = a[j];
+    for (int j = 0; j < 8; ++j) sacc[rg][cg][j] = a[j];
     __syncthreads();
-    if (wave == 0 && c < N) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = (sacc[0][lane][j] + sacc[1][lane][j]) + (sacc[2][lane][j] + sacc[3][lane][j]);
-            if (part) part[(long)blockIdx.y * N + c + j] = t;
-            else out[c + j] = accumulate ? out[c + j] + t : t;
+    if (threadIdx.x < 32) {
+        const int col = blockIdx.x * 32 + threadIdx.x;
+        if (col < N) {
+            float t = 0.f;
+            for (int g = 0; g < 64; ++g) t += sacc[g][threadIdx.x >> 3][threadIdx.x & 7];
+            out[col] = accumulate ? out[col] + t : t;
         }
     }
-}
-__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
-    float t = 0.f;
-    for (int i = 0; i < nparts; ++i) t += part[(long)i * N + c];
-    out[c] = accumulate ? out[c] + t : t;
 }
 
 constexpr int CAST_MAX = 96;
@@ -464,29 +504,14 @@ extern "C" int ag_slab_reduce(const float* d_slabs, int splits, int64_t slab_str
     return AG_OK;
 }
 
-extern "C" size_t ag_colsum_bf16_scratch_floats(int M, int N) { return (size_t)ceil_div(M > 0 ? M : 1, 64) * (size_t)N; }
+extern "C" size_t ag_colsum_bf16_scratch_floats(int M, int N) { (void)M; (void)N; return 0; }   // (ABI 3 kept the query; no scratch since the one-launch form)
 
 extern "C" int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, float* d_scratch, void* stream) {
+    (void)d_scratch;
     AG_REQUIRE(d_x && d_out && M >= 0 && N > 0, "ag_colsum_bf16: bad arguments");
     AG_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)d_x % 16) == 0, "ag_colsum_bf16: N and ldx must be multiples of 8, x 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    // enough blocks to cover the chip: columns x row groups of >= 64 rows (partials folded by a second small launch when needed)
-    const int cb = ceil_div(N, 512);
-    int rg = 1;
-    if (d_scratch && M > 128) {
-        rg = ceil_div(256, cb);
-        const int rg_max = ceil_div(M, 64);
-        rg = rg < rg_max ? rg : rg_max;
-    }
-    const int rpb = ceil_div(M > 0 ? M : 1, rg);
-    rg = ceil_div(M > 0 ? M : 1, rpb);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cb, rg), dim3(256), 0, s, (const bf16_t*)d_x, M, N, (long)ldx, d_out, accumulate, rpb,
-                       rg > 1 ? d_scratch : nullptr);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_x, M, N, (long)ldx, d_out, accumulate);
     AG_LAUNCH_CHECK();
-    if (rg > 1) {
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, d_scratch, rg, N, d_out, accumulate);
-        AG_LAUNCH_CHECK();
-    }
     return AG_OK;
 }
 

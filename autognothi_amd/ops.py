@@ -372,9 +372,8 @@ def colsum_bf16(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = Fals
     m, n = x.shape
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=x.device)
-    scratch = _scratch(x.device, int(L.lib().ag_colsum_bf16_scratch_floats(m, n)))
     with L.on(x.device):
-        L.check(L.lib().ag_colsum_bf16(L.ptr(x), m, n, x.stride(0), L.ptr(out), 1 if accumulate else 0, L.ptr(scratch), L.stream()))
+        L.check(L.lib().ag_colsum_bf16(L.ptr(x), m, n, x.stride(0), L.ptr(out), 1 if accumulate else 0, None, L.stream()))
     return out
 
 

@@ -507,6 +507,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-child", action="store_true", help=argparse.SUPPRESS)   # (internal: grad_exchange_overlap in its own process)
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per explainer training step of the secondary block (0 = skip)")
     # 220 images x 197 tokens = 170 M-tiles: 510 / 1530 / 2040 tiles for N = 768 / 2304 / 3072 = 1.99 / 5.98 / 7.97 rounds of 256 CUs
     # (128 images leave 42 % of the second round of the N = 768 GEMMs idle: 6.3 k -> 7.6 k attributions/s)
@@ -514,6 +515,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="the timed hot path only (profiling runs)")
     ap.add_argument("--graph", action="store_true", help="replay the timed step from a hipGraph (no in-library kernel timing then)")
     args = ap.parse_args()
+    if args.overlap_child:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        engine.set_precision("bf16")
+        job = Job("vit_base", dev, 0, 1, max(1, args.train_batch), 0, "bf16")
+        print(json.dumps({"gradient_exchange_overlap": grad_exchange_overlap(job, dev, max(1, args.train_batch))}), flush=True)
+        return
     maybe_spawn(args)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -767,8 +775,13 @@ def main():
                     del j5
             c5["strong_scaling_shards"] = shards
             if world == 1 and rank == 0:
+                # in a CHILD process: initialising RCCL prints its version banner on stdout, and this process owes the driver ONE line
                 try:
-                    c5["gradient_exchange_overlap"] = grad_exchange_overlap(job, dev, args.train_batch)
+                    r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--overlap-child", "--train-batch", str(args.train_batch)],
+                                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+                    got = [ln for ln in r_.stdout.splitlines() if ln.startswith('{"gradient_exchange_overlap"')]
+                    c5["gradient_exchange_overlap"] = (json.loads(got[-1])["gradient_exchange_overlap"] if got
+                                                       else {"error": (r_.stderr or r_.stdout)[-300:]})
                 except Exception as exc:   # (no RCCL on the box: the line still goes out)
                     c5["gradient_exchange_overlap"] = {"error": repr(exc)[:200]}
     if rank == 0:

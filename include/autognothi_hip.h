@@ -406,7 +406,8 @@ int ag_rows_ln_bwd(const float* d_dy, int splits, int64_t slab_stride, const flo
 /* dst[n] (+)= sum of slabs (a dW product split over the rows); n, slab_stride multiples of 4. */
 int ag_slab_reduce(const float* d_slabs, int splits, int64_t slab_stride, int64_t n, float* d_dst, int accumulate, void* stream);
 /* out[N] (+)= column sums of a bf16 [M,N] matrix (the bias gradient of a dY that a GEMM / attention epilogue produced);
- * N, ldx multiples of 8; d_scratch (optional, ag_colsum_bf16_scratch_floats) lets the launch spread rows over the chip. */
+ * N, ldx multiples of 8.  One launch, a fixed summation tree (bit-reproducible); d_scratch is unused (kept in the signature, may be NULL;
+ * ag_colsum_bf16_scratch_floats returns 0). */
 size_t ag_colsum_bf16_scratch_floats(int M, int N);
 int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, float* d_scratch, void* stream);
 /* `count` fp32 -> bf16 conversions (h_dst_dtype[i] = AG_BF16) or fp32 copies (AG_F32) in ONE launch per 96 segments: every

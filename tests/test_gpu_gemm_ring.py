@@ -14,10 +14,21 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def _pin_ring_kernel(ag_knobs):
-    """ag_gemm sends problems of fewer than 48 tiles to the 128-tile kernel; these tests are about the ring kernel at every
-    shape class, small ones included."""
+def _pin_ring_kernel(request, ag_knobs):
+    """ag_gemm sends problems of fewer than 48 tiles to the 128-tile kernel; these tests are about the large-M kernels at every
+    shape class, small ones included.  Which library: the SHIPPED one (its one large-M kernel, gemm_stream_kernel) for every shape
+    it serves (K % 128 == 0); the reference build (libautognothi_hip_ref.so = the same sources + the round-1/2 ring and the
+    one-tile-per-workgroup line kernel, tests only) for the shapes with a contraction that is not a multiple of 128, which only the
+    ring kernel walks."""
+    from autognothi_amd import _lib as L
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    # (the chained tests feed a GEMM's N-wide output into the next one as its K)
+    use_ref = any(params.get(key) is not None and params[key] % 128 != 0 for key in ("k", "n"))
+    if use_ref:
+        L.use_library(L.REF_LIB_PATH)
     ag_knobs(AG_GEMM_BIG_MIN_TILES=1)
+    yield
+    L.use_library(None)
 
 BF16 = 1
 TOL = dict(rtol=1e-2, atol=2e-2)      # bf16 storage of the result: half an ulp at |x| <= 4 is 1.6e-2
@@ -425,10 +436,15 @@ def test_whole_line_kernel_equals_the_k32_ring_bit_for_bit(cuda_device, ag_knobs
             out["rln"], out["rln_stats"] = o, s2
         return out
 
-    ag_knobs(AG_GEMM_LINE=1, AG_GEMM_STREAM=int(stream != "line"), AG_GEMM_RLDS=int(stream == "stream+rlds"))
+    # "stream" / "stream+rlds": the SHIPPED library's kernel; "line": the reference build's; the ring always from the reference build
+    if stream == "line":
+        L.use_library(L.REF_LIB_PATH)
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1, AG_GEMM_LINE=1, AG_GEMM_STREAM=int(stream != "line"), AG_GEMM_RLDS=int(stream == "stream+rlds"))
     line = run_all()
-    ag_knobs(AG_GEMM_LINE=0)
+    L.use_library(L.REF_LIB_PATH)
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1, AG_GEMM_LINE=0)
     ring = run_all()
+    L.use_library(None)
     assert set(line) == set(ring)
     for key in line:
         assert torch.equal(line[key], ring[key]), key

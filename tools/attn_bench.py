@@ -17,8 +17,11 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 out = []
+only = os.environ.get("ATTN_ONLY")
 for name, R, T, H, heads, mode in (("vit_base", 1536, 197, 768, 12, L.AG_MASK_VIT_MUL), ("vit_1head", 18432, 197, 64, 1, L.AG_MASK_VIT_MUL),
                                    ("bert_fixed", 512, 512, 768, 12, L.AG_MASK_BERT_ADD)):
+    if only and name != only:
+        continue
     qkv = torch.randn((R, T, 3 * H), device=dev, generator=g).to(torch.bfloat16)
     keep = torch.rand((R, T - 1), device=dev, generator=g) < 0.5
     bits = ops.pack_mask(keep.to(torch.int64))
