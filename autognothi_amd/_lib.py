@@ -69,6 +69,8 @@ SIGNATURES = {
     "ag_gemm_supports_ln_fold": (i32, [i32, i32, i32, i64, i64, i64, i32, i32]),
     "ag_gemm_resid_ln": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i32, vp, vp, vp]),
     "ag_gemm_resid_ln_supported": (i32, [i32, i32, i32, i64, i64, i64]),
+    "ag_gemm_resid_split_scratch_bytes": (C.c_size_t, [i32, i32, i32]),
+    "ag_gemm_resid_split": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, C.c_size_t, vp]),
     "ag_side_mlp_supported": (i32, [i32, i32, i32]),
     "ag_side_mlp": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp]),
     "ag_side_linear_supported": (i32, [i32, i32, i32, i32]),

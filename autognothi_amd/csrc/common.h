@@ -124,6 +124,37 @@ __device__ __forceinline__ f32x2_t fast_gelu2(f32x2_t x) {
     return __builtin_elementwise_fma(-a, e, r);
 }
 
+// the same on eight pairs (a lane's 16 outputs of one token in the large-M GEMM epilogue), written stage by stage: every packed
+// FMA of the Horner chain has seven independent ones between itself and its consumer, so no wait state is paid between
+// dependent packed instructions (fast_gelu2 pair after pair cost one s_nop per chain link where the scheduler ran out of filler)
+__device__ __forceinline__ void fast_gelu2x8(f32x2_t (&lo)[4], f32x2_t (&hi)[4]) {
+    const f32x2_t c3 = {0.003938046284019947f, 0.003938046284019947f}, c2 = {-0.044971074908971786f, -0.044971074908971786f},
+                  c1 = {-0.46572810411453247f, -0.46572810411453247f}, c0 = {-1.1492576599121094f, -1.1492576599121094f},
+                  m1 = {-1.0f, -1.0f};
+    f32x2_t a[8], r[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2_t x = (i & 1) ? hi[i >> 1] : lo[i >> 1];
+        a[i].x = fminf(fabsf(x.x), 9.0f); a[i].y = fminf(fabsf(x.y), 9.0f);
+        r[i].x = fmaxf(x.x, 0.0f); r[i].y = fmaxf(x.y, 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(c3, a[i], c2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], c1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], c0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], m1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { q[i].x = __builtin_amdgcn_exp2f(q[i].x); q[i].y = __builtin_amdgcn_exp2f(q[i].y); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2_t g = __builtin_elementwise_fma(-a[i], q[i], r[i]);
+        if (i & 1) hi[i >> 1] = g; else lo[i >> 1] = g;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

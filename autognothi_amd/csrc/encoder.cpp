@@ -28,6 +28,8 @@ struct Ws {
     float* st1;    // [S, M, 2]  per-256-column partial (sum, sumsq) of the rows entering LN1 (folded into the QKV GEMM), S = ceil(H/256)
     float* st2;    // [S, M, 2]  same for LN2 (folded into fc1)
     int* idx;      // [R+1 + M] token pruning plan
+    float* split;  // fp32 partial tiles of a split fc2 (ag_gemm_resid_split; NULL when the shape does not split)
+    size_t split_bytes;
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -47,6 +49,10 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* st1 = take(S * M * 2 * sizeof(float));
     char* st2 = take(S * M * 2 * sizeof(float));
     char* idx = take((M + (size_t)R + 1) * sizeof(int));   // token pruning: cu_seqlens [R+1] + packed-row sources [M]
+    // under-filled fc2 (the reference's own batch sizes: one to four inputs x K masks): the tail round's rows as contraction ranges side by side
+    const size_t split_bytes = (d->dtype == AG_BF16 && M <= 0x7FFFFFFF) ? ag_gemm_resid_split_scratch_bytes((int)M, d->H, d->I) : 0;
+    char* split = split_bytes ? take(split_bytes) : nullptr;
+    if (ws) { ws->split = (float*)split; ws->split_bytes = split_bytes; }
     if (ws) ws->idx = (int*)idx;
     if (ws) { ws->xs = xs; ws->qkv = qkv; ws->ctx = ctx; ws->inter = inter; ws->hx = hx; ws->ha = ha; ws->st1 = (float*)st1; ws->st2 = (float*)st2; }
     return off;
@@ -114,7 +120,19 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                          ag_gemm_supports_ln_fold(Mo, H, I, I, ld_tok, H, AG_EPI_BIAS_RESID, dt);
         }
         // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
-        if (fold1) {
+        static const bool trim_off = getenv("AG_LAST_Q_TRIM") && atoi(getenv("AG_LAST_Q_TRIM")) == 0;
+        if (fold1 && last_cls && in_share == 1 && !trim_off && w.ln1_g &&
+            ag_gemm_supports_ln_fold(Min, 2 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt)) {
+            // the last layer's attention reads the CLS query only (cls_only_last): keys and values of every token (the [H, 3H) rows of the
+            // fused projection), queries of the R CLS rows — a third of this layer's QKV product is never computed.  The CLS rows are
+            // normalised by the LayerNorm kernel (strided: one row per sequence) and projected with the unfolded query rows.
+            if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
+            TRY(ag_gemm(h_in, H, (const char*)w.w_qkv_ln + (size_t)H * H * es, w.b_qkv_ln + H, ws.qkv + (size_t)H * es, 3 * H, nullptr, 0, 0, 0,
+                        Min, 2 * H, H, AG_EPI_BIAS, dt, ws.st1, w.s_qkv_ln + H, d->ln_eps, nullptr, dyn, stream));
+            TRY(ag_layernorm(h_in, dt, (int64_t)T * H, R, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
+            TRY(ag_gemm(ws.xs, H, w.w_qkv, w.b_qkv, ws.qkv, (int64_t)T * 3 * H, nullptr, 0, 0, 0, R, H, H, AG_EPI_BIAS, dt,
+                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
+        } else if (fold1) {
             if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
             TRY(ag_gemm(h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
                         ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, dyn, stream));
@@ -161,6 +179,10 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                             nullptr, nullptr, 0.f, nullptr, dyn, stream));
             }
             // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
+            if (ws.split && Mo == M) {
+                TRY(ag_gemm_resid_split(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, Mo, H, I, next_fold1 ? ws.st1 : nullptr,
+                                        ws.split, ws.split_bytes, stream));
+            } else
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, dyn, stream));
             }
@@ -190,6 +212,9 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
             TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
                         nullptr, nullptr, 0.f, nullptr, dyn, stream));
             char* pre = (a == ws.hx) ? ws.ha : ws.hx;
+            if (ws.split && Mo == M) {
+                TRY(ag_gemm_resid_split(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, Mo, H, I, nullptr, ws.split, ws.split_bytes, stream));
+            } else
             TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
                         nullptr, nullptr, 0.f, nullptr, dyn, stream));
             if (last_cls) {

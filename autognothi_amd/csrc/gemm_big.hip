@@ -74,6 +74,9 @@ struct BigArgs {
     const int* dyn;  // ag_dynamic_rows(): actual row count (NULL: M is exact)
     int ngrp;      // N-tiles per tile-order group (>= 1)
     int nt_store;  // outputs far larger than the 256 MiB Infinity Cache: stream them past the caches
+    // contraction ranges side by side (gemm_stream_kernel, fp32-output epilogue only; ag_gemm_resid_split): `nbatch` products of the
+    // same shape in one launch, product z reading A / W `bk_b` bytes further along K and writing `bc` output elements further
+    int nbatch; long bk_b; long bc;
 };
 
 // LDS-DMA issued through inline asm ON PURPOSE: hipcc does not count an asm load in its s_waitcnt
@@ -143,7 +146,7 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
 template <int EPI, bool LNF, bool STATS, bool RLN = false, int LAYOUT = 0>
 __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
                                               char* stg, const int lane, const char* smem_base, const int tile_n,
-                                              const char* tail_at = nullptr) {
+                                              const char* tail_at = nullptr, const long c_ofs = 0) {
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
     constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
@@ -226,17 +229,28 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             ln_mean = mr.x; ln_rstd = mr.y;
         }
         float row_s = 0.f, row_q = 0.f;  // producer side: stats of the bf16-rounded values this lane writes
+        // LayerNorm fold + bias of all four column groups first, as PACKED fp32 FMAs (two elements per issue slot: this code runs with the
+        // matrix cores idle, every VALU slot of it is tile time): rstd * (acc - mean * s) + b  =  fma(rstd, fma(-mean, s, acc), b), the
+        // contraction hipcc made of the scalar form (bit-identical)
+        f32x2_t vlo[4], vhi[4];
+#pragma unroll
+        for (int sn = 0; sn < 4; ++sn) {
+            vlo[sn] = f32x2_t{acc[sn][sm][0], acc[sn][sm][1]}; vhi[sn] = f32x2_t{acc[sn][sm][2], acc[sn][sm][3]};
+            const f32x2_t blo = {bv[sn].x, bv[sn].y}, bhi = {bv[sn].z, bv[sn].w};
+            if (LNF) {
+                const f32x2_t nm2 = {-ln_mean, -ln_mean}, rs2 = {ln_rstd, ln_rstd};
+                vlo[sn] = __builtin_elementwise_fma(rs2, __builtin_elementwise_fma(nm2, f32x2_t{sv[sn].x, sv[sn].y}, vlo[sn]), blo);
+                vhi[sn] = __builtin_elementwise_fma(rs2, __builtin_elementwise_fma(nm2, f32x2_t{sv[sn].z, sv[sn].w}, vhi[sn]), bhi);
+            } else {
+                vlo[sn] += blo; vhi[sn] += bhi;
+            }
+        }
+        if (EPI == AG_EPI_BIAS_GELU) fast_gelu2x8(vlo, vhi);   // the eight pairs stage by stage: no dependent back-to-back packed FMAs
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn) {
             const int n = nw0 + sn * 16 + fq * 4;
-            float v[4] = {acc[sn][sm][0], acc[sn][sm][1], acc[sn][sm][2], acc[sn][sm][3]};
+            float v[4] = {vlo[sn].x, vlo[sn].y, vhi[sn].x, vhi[sn].y};
             const bool inb = (m < p.M) && (n < p.N);
-            if (LNF) {  // fold the LayerNorm of the A operand's rows into the result
-                const float nm = -ln_mean;
-                v[0] = ln_rstd * fmaf(nm, sv[sn].x, v[0]); v[1] = ln_rstd * fmaf(nm, sv[sn].y, v[1]);
-                v[2] = ln_rstd * fmaf(nm, sv[sn].z, v[2]); v[3] = ln_rstd * fmaf(nm, sv[sn].w, v[3]);
-            }
-            v[0] += bv[sn].x; v[1] += bv[sn].y; v[2] += bv[sn].z; v[3] += bv[sn].w;
             if (RESID && RLN) {   // residual = LayerNorm of the stored pre-LN row (never materialised)
                 constexpr int SI = RLN ? 1 : 0;    // (gv / btv have one element in the other instantiations)
                 const float nm = -ln_mean;
@@ -248,16 +262,12 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 v[0] += __uint_as_float(rcur[sn].x << 16); v[1] += __uint_as_float(rcur[sn].x & 0xFFFF0000u);
                 v[2] += __uint_as_float(rcur[sn].y << 16); v[3] += __uint_as_float(rcur[sn].y & 0xFFFF0000u);
             }
-            if (EPI == AG_EPI_BIAS_GELU) {
-                const f32x2_t g0 = fast_gelu2(f32x2_t{v[0], v[1]}), g1 = fast_gelu2(f32x2_t{v[2], v[3]});
-                v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
-            }
             if (EPI == AG_EPI_BIAS_TANH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
             }
             if (OUT_F32) {
-                if (inb) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                if (inb) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + c_ofs + (long)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 *reinterpret_cast<uint2*>(stg + ((sm & 1) * 16 + frow) * SROW + sn * 32 + fq * 8) = pk;
@@ -276,13 +286,18 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             if (fq == 0) *reinterpret_cast<float2*>(stg + STAT_OFF + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
         }
         if (!OUT_F32 && (sm & 1)) {
-            // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B)
+            // 32 staged rows ready (this wave's own LDS ops complete in order): 4 x (8 rows x 128 B).  (Stores after every 16 rows instead:
+            // built and measured in round 4, same box — no gain, fc1 + GELU +0.6 %.)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rr = i * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
                 const int mm = mw0 + (sm - 1) * 16 + rr;
+#ifdef AG_ABL_NOSTORE   // (ablation build, wrong results: the epilogue without its global stores)
+                if (mm < 0) {
+#else
                 if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+#endif
                     uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (p.nt_store) {
@@ -1025,7 +1040,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     const int wm = wave >> 2, wn = wave & 3;
     const int grp = wave >> 2, gw = wave & 3;         // wave group (phase offset) and index inside it
     const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
-    const int nwg = tiles_m * tiles_n;
+    // BATCH (fp32-output instantiation only): p.nbatch products of this shape side by side, unit = (product, tile)
+    constexpr bool BATCH = (EPI == AG_EPI_BIAS_F32 && VAR == 0);
+    const int nwg_t = tiles_m * tiles_n;
+    const int nwg = BATCH ? nwg_t * p.nbatch : nwg_t;
     const int nres = (int)gridDim.x;                  // resident workgroups: a multiple of 8 (or all tiles)
     int bt = blockIdx.x;
     if (bt >= nwg) return;
@@ -1048,10 +1066,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     asm volatile("" : "+v"(vA), "+v"(vW));
 
     // a tile of the stream: scalars only
-    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; };     // (whole words only: never copied through memory)
+    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; long cz; };     // (whole words only: never copied through memory)
     auto tile_of = [&](int b) {
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        int bz = 0;
+        if (BATCH && p.nbatch > 1) { bz = wg / nwg_t; wg -= bz * nwg_t; }
         int tm, tn;
         const int ngrp = p.ngrp;
         const int full = (tiles_n / ngrp) * ngrp * tiles_m;
@@ -1066,6 +1086,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         t.m0 = __builtin_amdgcn_readfirstlane(tm * BT); t.n0 = __builtin_amdgcn_readfirstlane(tn * BT); t.tn = __builtin_amdgcn_readfirstlane(tn);
         const int vrows = stA ? min(BT, p.M - t.m0) : min(BT, p.N - t.n0);
         t.x = stA ? p.A + (long)t.m0 * p.lda_b : p.W + (long)t.n0 * p.ldw_b;
+        t.cz = 0;
+        if (BATCH) {
+            bz = __builtin_amdgcn_readfirstlane(bz);
+            t.x += (long)bz * p.bk_b;
+            t.cz = (long)bz * p.bc;
+        }
         t.off_max = (uint32_t)((vrows - 1) * ldx + 112);
         t.edge = vrows < BT ? 1 : 0;
         return t;
@@ -1379,7 +1405,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
             wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3, 1>(p, acc, cur.m0 + wm * 128, cur.n0 + wn * 64,
                                                                               smem + 32768 + grp * 65536 + gw * 8192, lane_e, smem, cur.tn,
-                                                                              smem + STREAM_TAIL + par * TAIL_BYTES);
+                                                                              smem + STREAM_TAIL + par * TAIL_BYTES, cur.cz);
         }
         if (p.dbg) {
             unsigned long long t1, t2;
@@ -1428,7 +1454,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         attr_set[dev] = true;
     }
     const int n_cu = n_cu_of[dev];
-    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT);
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT) * ((EPI == AG_EPI_BIAS_F32 && VAR == 0) ? a.nbatch : 1);
     hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
@@ -1530,16 +1556,18 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                    const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
                    const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out,
-                   const float* d_rln_g, const float* d_rln_b, const int* d_rows, hipStream_t s) {
+                   const float* d_rln_g, const float* d_rln_b, const int* d_rows, hipStream_t s,
+                   long stats_rows = 0, int nbatch = 1, long ldw = 0, long bk_b = 0, long bc = 0) {
     BigArgs a;
     a.rln_g = d_rln_g; a.rln_b = d_rln_b;
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
-    a.W = (const char*)d_W; a.ldw_b = (long)K * 2;
+    a.W = (const char*)d_W; a.ldw_b = (ldw > 0 ? ldw : (long)K) * 2;
+    a.nbatch = nbatch; a.bk_b = bk_b; a.bc = bc;
     a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc; a.R = (const bf16_t*)d_R; a.ldr = ldr;
     a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
     a.M = M; a.N = N; a.K = K;
     a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K; a.stats_out = d_stats_out;
-    a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, BT);
+    a.stats_slab = 2L * (stats_rows > 0 ? stats_rows : (long)M); a.ln_nslab = ceil_div(K, BT);   // (stats_rows: this launch covers a row range of a taller output)
     if (d_rln_g) { a.ln_inv_h = 1.0f / (float)N; a.ln_nslab = ceil_div(N, BT); }   // the statistics describe the residual rows [M, N]
     a.dbg = nullptr;
     a.dyn = d_rows;
@@ -1609,4 +1637,163 @@ extern "C" int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, c
 extern "C" int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr) {
     static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
     return (!force_small && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID)) ? 1 : 0;
+}
+
+// =====================================================================================================================
+// ag_gemm_resid_split — C = A·Wᵀ + bias + R for launches whose LAST ROUND of 256² tiles is under-filled.
+//
+// The persistent kernel gives every CU the tiles b, b + 256, ...: 297 tiles (one input x K = 32 ViT-base masks x 4, N = 768) are a
+// full round and a second one with 41 CUs busy — for all 48 steps of fc2's K = 3 072.  (One input x 32 masks: 75 tiles, one round,
+// 29 % of the CUs.)  Here the row panels of the full rounds run as before and the rows of the tail round are computed as `splits`
+// contraction ranges SIDE BY SIDE in one launch (gemm_stream_kernel's BATCH form: unit = (range, tile), fp32 partial tiles into
+// d_scratch [splits][M2][N]): 41 x 6 = 246 units of 8 steps.  A row kernel then adds the partials in range order, bias and the
+// residual, rounds to bf16, stores, and emits the (sum, sum of squares) slab statistics of what it stored exactly as the
+// GEMM epilogue would (LayerNorm fold of the consumer): no atomics, bit-reproducible from run to run (the sums are taken in
+// another order than the unsplit launch's, i.e. equal to it to fp32 rounding, not bit for bit).
+// Reference: the Linear of models/vanilla_vit.py:498-504 (ViTOutput: dense + residual) at the reference's own batch sizes.
+namespace {
+
+struct SplitPlan { int m1, m2, splits; };
+
+int device_cus() {
+    constexpr int MAX_DEV = 16;
+    static int n_cu_of[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 0;
+    if (!n_cu_of[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        const int cu = prop.multiProcessorCount;
+        n_cu_of[dev] = cu >= 8 ? (cu & ~7) : (cu > 0 ? cu : 1);
+    }
+    return n_cu_of[dev];
+}
+
+bool split_plan(int M, int N, int K, int n_cu, SplitPlan* pl) {
+    static AgKnob k_split("AG_GEMM_SPLIT");            // 0: never split (A/B, parity tests)
+    if ((int)k_split.get(1) == 0 || n_cu <= 0 || K % 128 != 0) return false;
+    const int tiles_n = ceil_div(N, BT);
+    if (tiles_n > n_cu) return false;
+    const int ppr = n_cu / tiles_n;                     // row panels per round
+    const int panels = ceil_div(M, BT);
+    const int tail_panels = panels % ppr;
+    if (tail_panels == 0) return false;
+    const int tail_tiles = tail_panels * tiles_n;
+    if (tail_tiles * 2 > n_cu) return false;            // more than half a round: the split's fixed costs eat the gain
+    const int ns = K / 64;
+    int s_max = n_cu / tail_tiles;
+    if (s_max > 8) s_max = 8;
+    const int m1 = (panels - tail_panels) * BT, m2 = M - m1;
+    for (int s = s_max; s >= 2; --s) {
+        if (K % (s * 128) != 0 || ns / s < 8) continue;
+        // what the split saves: (ns - ns / s) steps of ~1.45 us on the tail round; what it costs: the partial tiles written and read back
+        // (m2 x N x (4 s + 4) bytes through the finishing kernel at ~4 TB/s) + ~6 us of extra prologue / epilogue / launch.  Measured
+        // (tools/r4_split_check.sh): worth it from a 1.5 x margin on.
+        const double gain_us = 1.45 * (ns - ns / s);
+        const double cost_us = (double)m2 * N * (4.0 * s + 4.0) / 4.0e6 + 6.0;
+        if (gain_us < 1.5 * cost_us) continue;
+        pl->m1 = m1; pl->m2 = m2; pl->splits = s;
+        return true;
+    }
+    return false;
+}
+
+// a half-wave (32 lanes x 8 columns) per (row, 256-column slab); SPLITS partial rows loaded at once (a runtime-length loop of
+// load -> add would pay one memory round trip per range)
+template <int SPLITS>
+__global__ __launch_bounds__(256) void split_finish_kernel(const float* __restrict__ slabs, long slab_stride, const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ R, long ldr, bf16_t* __restrict__ C, long ldc, int m1, int M, int N,
+                                                           float* __restrict__ stats_out, long stats_slab) {
+    const int nslab = (N + 255) >> 8;
+    const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 5;       // (row of the tail, slab)
+    const int sub = threadIdx.x & 31;
+    const int row = (int)(item / nslab), slab = (int)(item - (long)row * nslab);
+    if (row >= M - m1) return;                                          // (whole half-waves leave together)
+    const int m = m1 + row;
+    const int c = slab * 256 + sub * 8;
+    const bool on = c < N;                                              // (N % 8 == 0)
+    float sum = 0.f, sq = 0.f;
+    if (on) {
+        const float* p0 = slabs + (long)row * N + c;
+        float4 x0[SPLITS], x1[SPLITS];
+#pragma unroll
+        for (int s = 0; s < SPLITS; ++s) {
+            x0[s] = *reinterpret_cast<const float4*>(p0 + s * slab_stride);
+            x1[s] = *reinterpret_cast<const float4*>(p0 + s * slab_stride + 4);
+        }
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (bias) { b0 = *reinterpret_cast<const float4*>(bias + c); b1 = *reinterpret_cast<const float4*>(bias + c + 4); }
+        const uint4 r = *reinterpret_cast<const uint4*>(R + (long)m * ldr + c);
+        float4 a0 = x0[0], a1 = x1[0];
+#pragma unroll
+        for (int s = 1; s < SPLITS; ++s) {                              // in range order: bit-reproducible
+            a0.x += x0[s].x; a0.y += x0[s].y; a0.z += x0[s].z; a0.w += x0[s].w;
+            a1.x += x1[s].x; a1.y += x1[s].y; a1.z += x1[s].z; a1.w += x1[s].w;
+        }
+        // (acc + bias) + residual: the order of the GEMM epilogue
+        const float v0 = (a0.x + b0.x) + __uint_as_float(r.x << 16), v1 = (a0.y + b0.y) + __uint_as_float(r.x & 0xFFFF0000u);
+        const float v2 = (a0.z + b0.z) + __uint_as_float(r.y << 16), v3 = (a0.w + b0.w) + __uint_as_float(r.y & 0xFFFF0000u);
+        const float v4 = (a1.x + b1.x) + __uint_as_float(r.z << 16), v5 = (a1.y + b1.y) + __uint_as_float(r.z & 0xFFFF0000u);
+        const float v6 = (a1.z + b1.z) + __uint_as_float(r.w << 16), v7 = (a1.w + b1.w) + __uint_as_float(r.w & 0xFFFF0000u);
+        const uint4 pk = make_uint4(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3), pack_bf16x2(v4, v5), pack_bf16x2(v6, v7));
+        *reinterpret_cast<uint4*>(C + (long)m * ldc + c) = pk;
+        const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                   // statistics of the ROUNDED values, as the GEMM epilogue takes them
+            const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xFFFF0000u);
+            sum += lo + hi; sq += lo * lo + hi * hi;
+        }
+    }
+    if (stats_out) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); sq += __shfl_xor(sq, o, 64); }
+        if (sub == 0) *reinterpret_cast<float2*>(stats_out + (long)slab * stats_slab + 2 * (long)m) = make_float2(sum, sq);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ag_gemm_resid_split_scratch_bytes(int M, int N, int K) {
+    SplitPlan pl;
+    if (!ag_gemm_big_eligible(M, N, K, K, N, N, AG_EPI_BIAS_RESID) || !split_plan(M, N, K, device_cus(), &pl)) return 0;
+    return (size_t)pl.splits * (size_t)pl.m2 * (size_t)N * sizeof(float);
+}
+
+extern "C" int ag_gemm_resid_split(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                                   const void* d_R, int64_t ldr, int M, int N, int K, float* d_stats_out, void* d_scratch,
+                                   size_t scratch_bytes, void* stream) {
+    AG_REQUIRE(d_A && d_W && d_C && d_R && d_scratch, "ag_gemm_resid_split: null pointer");
+    SplitPlan pl;
+    AG_REQUIRE(ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID) && split_plan(M, N, K, device_cus(), &pl),
+               "ag_gemm_resid_split: M=%d N=%d K=%d does not split (ag_gemm_resid_split_scratch_bytes == 0: call ag_gemm)", M, N, K);
+    AG_REQUIRE(scratch_bytes >= (size_t)pl.splits * pl.m2 * N * sizeof(float), "ag_gemm_resid_split: scratch too small");
+    AG_REQUIRE((N % 8) == 0 && (lda % 8) == 0 && (ldc % 8) == 0 && (ldr % 8) == 0 && ((uintptr_t)d_scratch % 16) == 0, "ag_gemm_resid_split: N, lda, ldc, ldr must be multiples of 8");
+    hipStream_t s = (hipStream_t)stream;
+    AgProfScope prof(AG_EPI_BIAS_RESID, 2.0 * M * (double)N * K, ((double)M * K + (double)N * K + 2.0 * (double)M * N) * 2.0, s, nullptr, (double)M);
+    if (pl.m1 > 0) {
+        int rc = run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, 1, 1, pl.m1, N, K, AG_EPI_BIAS_RESID, nullptr, nullptr, 0.f, d_stats_out,
+                         nullptr, nullptr, nullptr, s, /*stats_rows=*/M);
+        if (rc != AG_OK) return rc;
+    }
+    const int kp = K / pl.splits;
+    const char* a2 = (const char*)d_A + (size_t)pl.m1 * lda * 2;
+    int rc = run_big(a2, lda, d_W, nullptr, d_scratch, N, nullptr, 0, 1, 1, pl.m2, N, kp, AG_EPI_BIAS_F32, nullptr, nullptr, 0.f, nullptr,
+                     nullptr, nullptr, nullptr, s, 0, pl.splits, /*ldw=*/K, /*bk_b=*/(long)kp * 2, /*bc=*/(long)pl.m2 * N);
+    if (rc != AG_OK) return rc;
+    const long items = (long)pl.m2 * ceil_div(N, BT);                   // half-waves
+    const dim3 fgrid((unsigned)((items + 7) / 8)), fblock(256);
+#define AG_FINISH(S_) hipLaunchKernelGGL(split_finish_kernel<S_>, fgrid, fblock, 0, s, (const float*)d_scratch, (long)pl.m2 * N, d_bias, \
+                                         (const bf16_t*)d_R, (long)ldr, (bf16_t*)d_C, (long)ldc, pl.m1, M, N, d_stats_out, 2L * M)
+    switch (pl.splits) {
+        case 2: AG_FINISH(2); break;
+        case 3: AG_FINISH(3); break;
+        case 4: AG_FINISH(4); break;
+        case 5: AG_FINISH(5); break;
+        case 6: AG_FINISH(6); break;
+        case 7: AG_FINISH(7); break;
+        default: AG_FINISH(8); break;
+    }
+#undef AG_FINISH
+    AG_LAUNCH_CHECK();
+    return AG_OK;
 }

@@ -451,6 +451,28 @@ def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r
     return out, stats_out
 
 
+def gemm_resid_split_scratch_bytes(m: int, n: int, k: int) -> int:
+    """bytes of scratch ag_gemm_resid_split needs for this shape on the current device; 0: the shape does not split (use gemm)."""
+    return int(L.lib().ag_gemm_resid_split_scratch_bytes(m, n, k))
+
+
+def gemm_resid_split(a: Tensor, w: Tensor, bias: Optional[Tensor], resid: Tensor, stats_out: Optional[Tensor] = None,
+                     out: Optional[Tensor] = None) -> Tensor:
+    """A @ W^T + bias + resid (bf16, identity residual rows) with the under-filled tail round of tiles split over the contraction
+    (ag_gemm_resid_split); raises when the shape does not split."""
+    L.require_gpu(a, w, bias, resid, stats_out, out)
+    n, k = w.shape
+    m = a.numel() // k
+    with L.on(a.device):
+        need = gemm_resid_split_scratch_bytes(m, n, k)
+        scratch = _scratch(a.device, (need + 3) // 4)
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+        L.check(L.lib().ag_gemm_resid_split(L.ptr(a), a.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), out.stride(0), L.ptr(resid), resid.stride(0),
+                                            m, n, k, L.ptr(stats_out), L.ptr(scratch), scratch.numel() * 4, L.stream()))
+    return out
+
+
 def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], ln_g: Optional[Tensor],
              ln_b: Optional[Tensor], eps: float, post_ln: bool, rows_dev: Optional[Tensor] = None) -> Tensor:
     """fused MLP half of a narrow layer (ag_side_mlp): x [M, h] bf16 -> [M, h] bf16."""

@@ -98,10 +98,10 @@ def flops_per_forward(kind, p, T):
     return float(f)
 
 
-def flops_executed(kind, p, T, K, frac=1.0):
+def flops_executed(kind, p, T, K, frac=1.0, bf16=True):
     """F_exec: F_ref minus work legitimately skipped per row: embed + layer-0 QKV shared across the K masks,
-    last layer's Q-projection/attention/out-proj/MLP on the CLS token only; BERT token pruning (frac = visible
-    tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
+    last layer's attention/out-proj/MLP (and, ViT in bf16 mode: Q-projection) on the CLS token only; BERT token pruning
+    (frac = visible tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
     H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
     if kind in ("vanilla_bert", "duo_vanilla_bert") and frac < 1.0 and Lr >= 2:
         layer = 8 * T * H * H + 4 * T * T * H + 4 * T * H * I
@@ -123,8 +123,11 @@ def flops_executed(kind, p, T, K, frac=1.0):
     shared = 6 * T * H * H + (2 * (T - 1) * (p["img_channels"] * p["img_patch_size"] ** 2) * H if kind.endswith("vit") else 0)
     f -= shared * (K - 1) / K
     if not kind.startswith("ltt_"):   # (the ladder taps every token of every layer: nothing to skip there)
-        # last layer: attention for 1 query instead of T, out-proj + MLP for 1 token instead of T (QKV still full)
+        # last layer: attention for 1 query instead of T, out-proj + MLP for 1 token instead of T
         f -= (4 * T * T * H + 2 * T * H * H + 4 * T * H * I) * (T - 1) / T
+        # ... and, in the LayerNorm-folded bf16 ViT encoder (csrc/encoder.cpp: AG_LAST_Q_TRIM), the query projection of the CLS rows only
+        if bf16 and kind in ("vanilla_vit", "duo_vanilla_vit", "froyo_vit") and Lr >= 2 and os.environ.get("AG_LAST_Q_TRIM", "1") != "0":
+            f -= 2 * T * H * H * (T - 1) / T
     return float(f)
 
 
@@ -598,7 +601,7 @@ def main():
         job.set_batch(8)
         el32, _ = timed(job.step, 3, 1, dist, dev)
         fps32 = 8 * K * world * 3 / el32
-        f_exec32 = flops_executed(kind if kind in ("vanilla_vit", "vanilla_bert") else kind, params, T, K, 1.0)
+        f_exec32 = flops_executed(kind if kind in ("vanilla_vit", "vanilla_bert") else kind, params, T, K, 1.0, bf16=False)
         secondary["fp32_parity_mode"] = {"value": round(fps32, 1), "unit": "masked-forwards/s", "inputs_per_gpu": 8, "dtype": "f32",
                                          "exec_tflops": round(fps32 / world * f_exec32 / 1e12, 1), "peak": PEAK_F32_TFLOPS,
                                          "exec_frac_of_peak": round(fps32 / world * f_exec32 / 1e12 / PEAK_F32_TFLOPS, 4),
@@ -777,8 +780,13 @@ def main():
             if world == 1 and rank == 0:
                 # in a CHILD process: initialising RCCL prints its version banner on stdout, and this process owes the driver ONE line
                 try:
+                    # (under a launcher this process carries the elastic agent's rendezvous variables: the child makes its own one-rank group)
+                    env_ = {k_: v_ for k_, v_ in os.environ.items()
+                            if not (k_.startswith("TORCHELASTIC_") or k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                             "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                                                                             "MASTER_ADDR", "MASTER_PORT", "TORCH_NCCL_ASYNC_ERROR_HANDLING"))}
                     r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--overlap-child", "--train-batch", str(args.train_batch)],
-                                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+                                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env_)
                     got = [ln for ln in r_.stdout.splitlines() if ln.startswith('{"gradient_exchange_overlap"')]
                     c5["gradient_exchange_overlap"] = (json.loads(got[-1])["gradient_exchange_overlap"] if got
                                                        else {"error": (r_.stderr or r_.stdout)[-300:]})
@@ -788,7 +796,7 @@ def main():
         total_rows = R * world * args.steps
         value = total_rows / elapsed
         frac = packed_rows / float(R * T) if (kind in ("vanilla_bert", "duo_vanilla_bert", "ltt_bert") and packed_rows) else 1.0
-        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac)
+        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac, bf16=args.precision == "bf16")
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         roofline = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s"}
         if not args.graph:
@@ -830,6 +838,19 @@ def main():
                 roofline["traffic_launches"] = "full-size residual-through-LDS launches only (out-proj of layers 1..L-2 + fc2 of layers 0..L-2)"
                 roofline["algorithmic_bytes_per_traffic_launch"] = round(algo_full)
                 roofline["traffic_over_algorithmic"] = round(traffic / algo_full, 3)
+                # the other two large classes, each paired with the algorithmic bytes of exactly the launches its counter average covers:
+                # fc1 + GELU = layers 0..L-2 (the last layer's CLS-only fc1 is another kernel); QKV = layer 0 on the B shared inputs,
+                # layers 1..L-2 in full, the last layer's keys / values only (AG_LAST_Q_TRIM)
+                gb = lambda m_, n_, k_: (m_ * k_ + n_ * k_ + m_ * n_) * 2.0   # noqa: E731
+                lyr = params["num_hidden_layers"]
+                trim = os.environ.get("AG_LAST_Q_TRIM", "1") != "0"
+                algo_qkv = (gb(B * T, 3 * hid, hid) + (lyr - 2) * gb(m_rows, 3 * hid, hid) + gb(m_rows, (2 if trim else 3) * hid, hid)) / lyr
+                by_class = {"gemm<bias+residual>": round(traffic / algo_full, 3)}
+                for lab_, algo_ in (("gemm<bias>", algo_qkv), ("gemm<bias+gelu>", gb(m_rows, inter_, hid))):
+                    t_ = tj["traffic_bytes_per_launch"].get(lab_)
+                    if t_:
+                        by_class[lab_] = round(t_ / algo_, 3)
+                roofline["traffic_over_algorithmic_by_class"] = by_class
         roofline["whole_step"] = {"f_ref_gflop_per_fwd": round(f_ref / 1e9, 3), "f_exec_gflop_per_fwd": round(f_exec / 1e9, 3),
                                   "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
                                   "exec_tflops": round(value / world * f_exec / 1e12, 1),

@@ -153,6 +153,17 @@ int ag_gemm_resid_ln(const void* d_A, int64_t lda, const void* d_W, const float*
                      const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps,
                      int M, int N, int K, float* d_stats_out, const int* d_rows, void* stream);
 int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr);
+/* ag_gemm with the bias + residual epilogue (identity residual rows: rows_per_seq = resid_share = 1; bf16) for launches whose LAST
+ * round of 256 x 256 tiles leaves most CUs idle — the reference's own batch sizes: one input x K = 32 masks of ViT-base is 75 tiles on
+ * 256 CUs, four inputs are one round and 41 tiles (`ViTOutput.dense` + residual, models/vanilla_vit.py:498-504; `BertOutput.dense`,
+ * models/vanilla_bert.py:596-604).  The rows of the full rounds run as in ag_gemm; the rows of the tail round are computed as several
+ * contraction ranges side by side in one launch (fp32 partial tiles in d_scratch) and finished by a row kernel that adds the ranges in
+ * order, the bias and the residual, stores bf16 and writes the same slab statistics (d_stats_out, optional) as the GEMM epilogue.
+ * Deterministic; equal to ag_gemm to fp32 rounding of the sums (another summation order).
+ * ag_gemm_resid_split_scratch_bytes: bytes of d_scratch for this shape on the current device, 0 = the shape does not split (use ag_gemm). */
+size_t ag_gemm_resid_split_scratch_bytes(int M, int N, int K);
+int ag_gemm_resid_split(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc, const void* d_R,
+                        int64_t ldr, int M, int N, int K, float* d_stats_out, void* d_scratch, size_t scratch_bytes, void* stream);
 /* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
  * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
  * kernel, bf16:   post_ln = 0 (ViT, models/vanilla_vit.py:373-376):  out = x + fc2(gelu(fc1(LN(x))))     (ln_g NULL: no LN)

@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 base=${SRC%.*}
 $HIPCC $FLAGS $EXTRA -x hip -c "$SRC" -o "$OUT/${NAME}_${base}.o"
 OBJS=()
-for src in gemm.hip gemm_big.hip side_mlp.hip probe.hip attention.hip sampler.hip elementwise.hip shapley.hip train.hip encoder.cpp capi.cpp; do
+for src in gemm.hip gemm_tn.hip gemm_big.hip side_mlp.hip probe.hip attention.hip sampler.hip elementwise.hip shapley.hip train.hip train_fused.hip encoder.cpp capi.cpp; do
   b=${src%.*}
   if [ "$b" == "$base" ]; then OBJS+=("$OUT/${NAME}_${base}.o"); else OBJS+=("$OUT/$b.o"); fi
 done
