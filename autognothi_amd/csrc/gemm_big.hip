@@ -157,6 +157,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     constexpr int STAT_OFF = LAYOUT ? 4608 : 8192;
     constexpr int WPIECE = LAYOUT ? 8192 : 16384, GPIECE = LAYOUT ? 65536 : 65536, GBASE = LAYOUT ? 32768 : 0;
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
+    const bool edge_tile = !full_cols || mw0 + 128 > p.M;   // (wave-uniform) some of this wave's outputs lie outside the matrix
 
     // ---- row and column constants: parked in the LDS tail by the kernel's prologue (tile_constants_*) ----
     const char* const tail = tail_at ? tail_at : smem_base + NSLOT * SLOT_BYTES;   // (gemm_stream_kernel alternates between two tails)
@@ -228,7 +229,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             const float2 mr = stat_lds[(wave_id >> 2) * 128 + sm * 16 + frow];
             ln_mean = mr.x; ln_rstd = mr.y;
         }
-        float row_s = 0.f, row_q = 0.f;  // producer side: stats of the bf16-rounded values this lane writes
+        f32x2_t rs2 = {0.f, 0.f}, rq2 = {0.f, 0.f};  // producer side: stats of the bf16-rounded values this lane writes
         // LayerNorm fold + bias of all four column groups first, as PACKED fp32 FMAs (two elements per issue slot: this code runs with the
         // matrix cores idle, every VALU slot of it is tile time): rstd * (acc - mean * s) + b  =  fma(rstd, fma(-mean, s, acc), b), the
         // contraction hipcc made of the scalar form (bit-identical)
@@ -271,17 +272,18 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             } else {
                 const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 *reinterpret_cast<uint2*>(stg + ((sm & 1) * 16 + frow) * SROW + sn * 32 + fq * 8) = pk;
-                if (STATS) {
-                    const float keep = inb ? 1.f : 0.f;
-                    const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xFFFF0000u);
-                    const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xFFFF0000u);
-                    row_s = fmaf(keep, (r0 + r1) + (r2 + r3), row_s);
-                    row_q = fmaf(keep, (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3), row_q);
+                if (STATS) {   // two partial sums per lane (even / odd element pairs) on packed instructions, folded once per row
+                    f32x2_t ra = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xFFFF0000u)};
+                    f32x2_t rb = {__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xFFFF0000u)};
+                    if (edge_tile) { const float keep = inb ? 1.f : 0.f; const f32x2_t k2 = {keep, keep}; ra *= k2; rb *= k2; }
+                    rs2 += ra + rb;
+                    rq2 = __builtin_elementwise_fma(rb, rb, __builtin_elementwise_fma(ra, ra, rq2));
                 }
             }
         }
         if (STATS) {  // lanes frow + 16*fq hold parts of row m: combine the 4 column groups; this wave's 64-column partial of
             // the row goes to LDS (combined with the other three column waves after the loop)
+            float row_s = rs2.x + rs2.y, row_q = rq2.x + rq2.y;
             row_s = quad_rows_sum(row_s); row_q = quad_rows_sum(row_q);
             if (fq == 0) *reinterpret_cast<float2*>(stg + STAT_OFF + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
         }
@@ -1118,20 +1120,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         l2_touch(t.x + (long)step * LROWB, po, lds0 + STREAM_SINK);
     };
     // RLDS: four 8-row pieces (j = 4 q .. 4 q + 3) of half h (rows [64 h, 64 h + 64)) of this wave's residual sub-tile -> its piece
-    // area of ring slot h.  Lane l fetches the 16-byte chunk that belongs at chunk position l & 7 of row l >> 3 of the piece: logical
-    // chunk (l & 7) ^ (l >> 3) (rows of a piece: row & 7 == l >> 3), so that the accumulator-layout ds_read_b64 of 16 rows spread over
-    // the banks.  Rows past M / columns past N are clamped to valid addresses (never stored).
+    // area of ring slot h.  Image: 128-byte rows, 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7) — the main loop's swizzle: the
+    // accumulator-layout ds_read_b64 / ds_write_b64 of 16 rows x 8 bytes then touch every bank once (rows 2j, 2j + 1 share a chunk position
+    // and differ in the 128-byte half of the bank space).  (Round 3 keyed the swizzle on r & 7: rows r and r + 8 of every 16-row access met in
+    // the same banks — the 1 536 conflict cycles per tile of profiles/r04_a_pmc_summary.)  Lane l fetches what belongs at chunk position l & 7 of
+    // row l >> 3 of piece i: logical chunk (l & 7) ^ (4 (i & 1) + (l >> 4)).  Rows past M / columns past N are clamped to valid addresses
+    // (never stored).
     auto res4 = [&](const Tile& t, const int h, const int q) {
         uint32_t ones = ~0u;
         int ldr = (int)p.ldr, mlast = p.M - 1, nlast = p.N - 8;
         asm volatile("" : "+s"(ones), "+s"(ldr), "+s"(mlast), "+s"(nlast));
         const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
-        const int col = min(t.n0 + wn * 64 + (((ln & 7) ^ (ln >> 3)) << 3), nlast);
+        const int ch_e = (ln & 7) ^ (ln >> 4);                                  // pieces 0, 2 (image rows 8 i + (l >> 3): key (4 i + (l >> 4)) & 7)
+        const int col_e = min(t.n0 + wn * 64 + (ch_e << 3), nlast), col_o = min(t.n0 + wn * 64 + ((ch_e ^ 4) << 3), nlast);
         const int row0 = t.m0 + wm * 128 + h * 64 + q * 32 + (ln >> 3);
         const uint32_t ldsR = lds0 + (stA ? 0 : LW_BASE) + gw * 8192 + h * LOP_BYTES + q * 4096;
         uint32_t o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)(min(row0 + 8 * i, mlast) * ldr + col) * 2u;
+        for (int i = 0; i < 4; ++i) o[i] = (uint32_t)(min(row0 + 8 * i, mlast) * ldr + ((i & 1) ? col_o : col_e)) * 2u;
         glds_x4(reinterpret_cast<const char*>(p.R), o[0], o[1], o[2], o[3], ldsR);
     };
     // tile constants (bias | LayerNorm column sums or residual-LN gamma | residual-LN beta by column; row-statistics partials by row):
@@ -1294,6 +1300,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const int frow = le & 15, fq = le >> 4;
             const int mw0 = cur.m0 + wm * 128, nw0 = cur.n0 + wn * 64;
             const bool full_cols = nw0 + 64 <= p.N;
+            const bool edge_tile = !full_cols || mw0 + 128 > p.M;               // (wave-uniform)
             char* const area = smem + (stA ? 0 : LW_BASE) + gw * 8192;          // this wave's piece area of slot 0; slot 1: + LOP_BYTES
             // this wave's 128 x (sum, sumsq) partials: in the raw-partials area of THIS tile's parity (consumed at the top of the tile; the
             // next tile's raw partials arrive in the other one)
@@ -1319,7 +1326,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                     const int sm = 4 * h + smh;
                     const int lrow = smh * 16 + frow;                            // row of the 64-row half image
                     const int m = mw0 + sm * 16 + frow;
-                    float row_s = 0.f, row_q = 0.f;
+                    f32x2_t rs2 = {0.f, 0.f}, rq2 = {0.f, 0.f};
                     float nm = 0.f, ln_rstd = 1.f;
                     if (RLN) {
                         const float2 mr = *reinterpret_cast<const float2*>(tail + TAIL_STAT + (wm * 128 + sm * 16 + frow) * 8);
@@ -1327,7 +1334,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                     }
 #pragma unroll
                     for (int sn = 0; sn < 4; ++sn) {
-                        uint2* const at = reinterpret_cast<uint2*>(img + lrow * 128 + (((sn * 2 + (fq >> 1)) ^ (lrow & 7)) << 4) + (fq & 1) * 8);
+                        uint2* const at = reinterpret_cast<uint2*>(img + lrow * 128 + (((sn * 2 + (fq >> 1)) ^ ((lrow >> 1) & 7)) << 4) + (fq & 1) * 8);
                         const uint2 rq = *at;
                         float r0_ = __uint_as_float(rq.x << 16), r1_ = __uint_as_float(rq.x & 0xFFFF0000u);
                         float r2_ = __uint_as_float(rq.y << 16), r3_ = __uint_as_float(rq.y & 0xFFFF0000u);
@@ -1341,15 +1348,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                         const float v2 = (acc[sn][sm][2] + bv[sn].z) + r2_, v3 = (acc[sn][sm][3] + bv[sn].w) + r3_;
                         const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                         *at = pk;
-                        if (STATS) {
-                            const float keep = (m < p.M && nw0 + sn * 16 + fq * 4 < p.N) ? 1.f : 0.f;
-                            const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xFFFF0000u);
-                            const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xFFFF0000u);
-                            row_s = fmaf(keep, (r0 + r1) + (r2 + r3), row_s);
-                            row_q = fmaf(keep, (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3), row_q);
+                        if (STATS) {   // (the same packed partial sums, in the same order, as wave_epilogue)
+                            f32x2_t ra = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xFFFF0000u)};
+                            f32x2_t rb = {__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xFFFF0000u)};
+                            if (edge_tile) {
+                                const float keep = (m < p.M && nw0 + sn * 16 + fq * 4 < p.N) ? 1.f : 0.f;
+                                const f32x2_t k2 = {keep, keep};
+                                ra *= k2; rb *= k2;
+                            }
+                            rs2 += ra + rb;
+                            rq2 = __builtin_elementwise_fma(rb, rb, __builtin_elementwise_fma(ra, ra, rq2));
                         }
                     }
                     if (STATS) {
+                        float row_s = rs2.x + rs2.y, row_q = rq2.x + rq2.y;
                         row_s = quad_rows_sum(row_s); row_q = quad_rows_sum(row_q);
                         if (fq == 0) *reinterpret_cast<float2*>(part + (sm * 16 + frow) * 8) = make_float2(row_s, row_q);
                     }
@@ -1358,7 +1370,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int rr = i * 8 + (le >> 3), ch = le & 7;
-                    const uint4 val = *reinterpret_cast<const uint4*>(img + rr * 128 + ((ch ^ (rr & 7)) << 4));
+                    const uint4 val = *reinterpret_cast<const uint4*>(img + rr * 128 + ((ch ^ ((rr >> 1) & 7)) << 4));
                     const int mm = mw0 + h * 64 + rr;
                     if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
                         uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
