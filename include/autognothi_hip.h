@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define AG_ABI_VERSION 3   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
-                            * 3: ag_gemm_ex + the fused training kernels (additions only) */
+                            * 3: ag_gemm_ex + the fused training kernels + ag_gemm_resid_split (additions only) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
