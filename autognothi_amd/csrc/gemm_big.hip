@@ -1700,7 +1700,7 @@ bool split_plan(int M, int N, int K, int n_cu, SplitPlan* pl) {
         if (K % (s * 128) != 0 || ns / s < 8) continue;
         // what the split saves: (ns - ns / s) steps of ~1.45 us on the tail round; what it costs: the partial tiles written and read back
         // (m2 x N x (4 s + 4) bytes through the finishing kernel at ~4 TB/s) + ~6 us of extra prologue / epilogue / launch.  Measured
-        // (tools/r4_split_check.sh): worth it from a 1.5 x margin on.
+        // (tools/r4_ab.sh split): worth it from a 1.5 x margin on.
         const double gain_us = 1.45 * (ns - ns / s);
         const double cost_us = (double)m2 * N * (4.0 * s + 4.0) / 4.0e6 + 6.0;
         if (gain_us < 1.5 * cost_us) continue;

@@ -274,10 +274,17 @@ class Job:
         return v_s
 
 
-def timed(fn, steps, warmup, dist, dev):
+def timed(fn, steps, warmup, dist, dev, settle_s=0.25):
+    """secondary legs only (the contract's W + K steps are timed in main()).  Besides the `warmup` calls the function is kept running for
+    `settle_s` seconds before the timed region: a leg of a few milliseconds per step that starts right after seconds of host-side model
+    building otherwise measures the GPU's clock ramp (seen once: the same 4 ms step timed at 9.9 ms)."""
+    t_w = time.perf_counter()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    while time.perf_counter() - t_w < settle_s:
+        fn()
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
