@@ -119,6 +119,7 @@ SIGNATURES = {
     "ag_bert_encoder_forward_pruned": (i32, [C.POINTER(ag_encoder_desc), vp, i32, i32, vp, vp, vp, sz, vp, vp]),
     "ag_bert_layers_forward_packed": (i32, [C.POINTER(ag_encoder_desc), vp, vp, i32, i32, vp, vp, sz, vp, vp]),
     "ag_reload_knobs": (i32, []),
+    "ag_set_stream_cus": (i32, [vp, i32]),
     "ag_seq_compact_plan": (i32, [vp, i32, i32, vp, vp, vp]),
     "ag_gather_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp]),
     "ag_masked_attention_varlen": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

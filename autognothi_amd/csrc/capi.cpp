@@ -3,6 +3,8 @@
 #include <string.h>
 
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 static thread_local std::string g_last_error;
 
@@ -22,6 +24,22 @@ extern "C" int ag_abi_version(void) { return AG_ABI_VERSION; }
 
 long long g_ag_launch_count = 0;
 extern "C" int64_t ag_launch_count(void) { return (int64_t)g_ag_launch_count; }
+
+// CU-partitioned streams (hipExtStreamCreateWithCUMask): how many CUs a stream may run on.  Consulted by the persistent large-M GEMM
+// (one resident workgroup per CU of ITS stream); everything else launches ordinary grids and needs no hint.
+static std::mutex g_stream_cus_mu;
+static std::unordered_map<void*, int> g_stream_cus;
+extern "C" int ag_set_stream_cus(void* stream, int n_cu) {
+    std::lock_guard<std::mutex> lk(g_stream_cus_mu);
+    if (n_cu > 0) g_stream_cus[stream] = n_cu; else g_stream_cus.erase(stream);
+    return AG_OK;
+}
+int ag_stream_cus(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_stream_cus_mu);
+    if (g_stream_cus.empty()) return 0;
+    auto it = g_stream_cus.find((void*)s);
+    return it == g_stream_cus.end() ? 0 : it->second;
+}
 
 int g_ag_knob_epoch = 1;
 extern "C" int ag_reload_knobs(void) {

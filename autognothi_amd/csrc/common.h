@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // ---- error plumbing (host) ----------------------------------------------------------------
 void ag_set_error(const std::string& msg);
 int ag_fail(int code, const char* fmt, ...);
+int ag_stream_cus(hipStream_t s);   // capi.cpp: CUs of a CU-masked stream registered with ag_set_stream_cus (0: not registered)
 #define AG_HIP_CHECK(expr)                                                                         \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \

@@ -1467,7 +1467,11 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         n_cu_of[dev] = cu >= 8 ? (cu & ~7) : (cu > 0 ? cu : 1);
         attr_set[dev] = true;
     }
-    const int n_cu = n_cu_of[dev];
+    int n_cu = n_cu_of[dev];
+    {   // a CU-masked stream (ag_set_stream_cus): one resident workgroup per CU of ITS partition (a multiple of the 8 XCDs)
+        const int sc = ag_stream_cus(s);
+        if (sc > 0 && sc < n_cu) n_cu = sc >= 8 ? (sc & ~7) : sc;
+    }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT) * ((EPI == AG_EPI_BIAS_F32 && VAR == 0) ? a.nbatch : 1);
     hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();

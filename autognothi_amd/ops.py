@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 from torch import Tensor
@@ -612,6 +614,39 @@ def seq_compact_plan(mask_bits: Tensor, t: int, sync: bool = True):
     with L.on(mask_bits.device):
         L.check(L.lib().ag_seq_compact_plan(L.ptr(mask_bits.contiguous()), rows, t, L.ptr(cu), L.ptr(src), L.stream()))
     return cu, src, (int(cu[rows].item()) if sync else rows * t)
+
+
+_HIP_RT = None
+
+
+def cu_partition_streams(device, cus_per_xcd_first: int):
+    """Two HIP streams that share the device's CUs without overlapping: the first runs on CUs [0, c) of EVERY XCD, the second on the
+    rest (hipExtStreamCreateWithCUMask; on MI355X mask bit i is CU i // 8 of XCD i % 8, measured with tools/probe/cumask_probe.cpp).
+    The library is told each stream's CU count (ag_set_stream_cus: the persistent GEMM sizes its grid by it).
+    -> (torch stream A, torch stream B, CUs of A, CUs of B)."""
+    global _HIP_RT
+    dev = torch.device(device)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    per_xcd = n_cu // 8
+    c = int(cus_per_xcd_first)
+    if not (0 < c < per_xcd) or n_cu % 8 != 0:
+        raise ValueError(f"cu_partition_streams: need 0 < {c} < {per_xcd} CUs per XCD on a device whose CU count is a multiple of 8")
+    if _HIP_RT is None:
+        _HIP_RT = C.CDLL("libamdhip64.so")
+    words = (n_cu + 31) // 32
+    out = []
+    with torch.cuda.device(dev):
+        for lo, hi in ((0, 8 * c), (8 * c, n_cu)):
+            mask = (C.c_uint32 * words)()
+            for i in range(lo, hi):
+                mask[i // 32] |= 1 << (i % 32)
+            handle = C.c_void_p()
+            rc = _HIP_RT.hipExtStreamCreateWithCUMask(C.byref(handle), C.c_uint32(words), mask)
+            if rc != 0 or not handle.value:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            L.check(L.lib().ag_set_stream_cus(handle, hi - lo))
+            out.append(torch.cuda.ExternalStream(handle.value, device=dev))
+    return out[0], out[1], 8 * c, n_cu - 8 * c
 
 
 def reload_knobs() -> None:
