@@ -120,7 +120,8 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                          ag_gemm_supports_ln_fold(Mo, H, I, I, ld_tok, H, AG_EPI_BIAS_RESID, dt);
         }
         // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
-        static const bool trim_off = getenv("AG_LAST_Q_TRIM") && atoi(getenv("AG_LAST_Q_TRIM")) == 0;
+        static AgKnob k_trim("AG_LAST_Q_TRIM");     // 0: the last layer projects queries for every token (A/B, parity tests)
+        const bool trim_off = (int)k_trim.get(1) == 0;
         if (fold1 && last_cls && in_share == 1 && !trim_off && w.ln1_g &&
             ag_gemm_supports_ln_fold(Min, 2 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt)) {
             // the last layer's attention reads the CLS query only (cls_only_last): keys and values of every token (the [H, 3H) rows of the

@@ -88,3 +88,21 @@ def test_encoder_small_batch_split_on_off(cuda_device, ag_knobs):
         np.testing.assert_allclose(on[k], off[k], rtol=0, atol=2e-2, err_msg=k)     # (two bf16 runs with different rounding decisions)
         np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
     assert np.abs(on["v_s"] - off["v_s"]).max() > 0      # (the split path did run: another summation order)
+
+
+def test_last_layer_query_trim_on_off(cuda_device, ag_knobs):
+    """cls_only_last: the last layer computes keys / values for every token and queries for the CLS rows only (AG_LAST_Q_TRIM, default) —
+    against the untrimmed projection on the full-depth ViT-base fixture: the same surrogate outputs up to bf16 rounding of one query row per
+    sequence (the CLS query goes through the LayerNorm kernel + the unfolded weights instead of the folded GEMM)."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case("vit_base_l12")
+    try:
+        on = run_fixture_case(c, cuda_device, "bf16")
+        ag_knobs(AG_LAST_Q_TRIM=0)
+        off = run_fixture_case(c, cuda_device, "bf16")
+    finally:
+        engine.set_precision("fp32")
+    for k in ("v_s", "v_1", "v_0"):
+        np.testing.assert_allclose(on[k], off[k], rtol=0, atol=5e-3, err_msg=k)
+        np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
