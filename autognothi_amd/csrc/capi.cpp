@@ -25,8 +25,8 @@ extern "C" int ag_abi_version(void) { return AG_ABI_VERSION; }
 long long g_ag_launch_count = 0;
 extern "C" int64_t ag_launch_count(void) { return (int64_t)g_ag_launch_count; }
 
-// CU-partitioned streams (hipExtStreamCreateWithCUMask): how many CUs a stream may run on.  Consulted by the persistent large-M GEMM
-// (one resident workgroup per CU of ITS stream); everything else launches ordinary grids and needs no hint.
+// How many CUs the persistent large-M GEMM may take on a stream (ag_set_stream_cus: the two-stream training epoch, CU-masked streams).
+// Everything else launches ordinary grids and needs no hint.
 static std::mutex g_stream_cus_mu;
 static std::unordered_map<void*, int> g_stream_cus;
 extern "C" int ag_set_stream_cus(void* stream, int n_cu) {

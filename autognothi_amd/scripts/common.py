@@ -1,7 +1,8 @@
 """Small helpers shared by the pipeline bodies."""
 from __future__ import annotations
 
-from typing import Any, Callable, Optional
+import os
+from typing import Any, Callable, Iterable, Optional
 
 import torch
 
@@ -106,3 +107,104 @@ def shard(xs, zs=None):
     if lo == 0 and hi == n:
         return xs, zs, n, lo, hi
     return xs[lo:hi], (zs[lo:hi] if zs is not None else None), n, lo, hi
+
+
+# ---------------------------------------------------------------------------------------------- two-stream training epoch
+class TrainPartition:
+    """The second stream of an explainer training epoch.  The reference runs the K-mask target forward and the explainer's own step
+    back to back (scripts/train_explainer.py:153-198); the surrogate is frozen, so the targets of group g + 1 depend on nothing the
+    steps of group g do, and the two want different things from the chip: the target forward is the hot path (feed-bound: it loses
+    6-13 % on 7/8 - 3/4 of the CUs, throughput ~ CUs^0.43), the step is 400 launches on 1.5 k token rows that fill a quarter of the CUs
+    at best.  ``fwd`` is an ordinary (non-blocking) stream on which the persistent large-M GEMM is told to launch only ``n_fwd``
+    workgroups (ag_set_stream_cus: one per CU, an equal number on every XCD and shader engine), so the other CUs are free for the step's
+    kernels on the caller's stream at any moment.  No CU masks: hipExtStreamCreateWithCUMask streams are blocking streams — every
+    null-stream operation of the process becomes a barrier across them (measured: a step-bound epoch on the null stream 2x slower
+    while two such streams merely exist) — and masking the step's side buys less (+14 % against +18 %; profiles/HISTORY.md §10)."""
+
+    def __init__(self, device: torch.device, cus_per_xcd_fwd: int):
+        from .. import _lib as L
+        # from the HIGH-priority pool: HIP multiplexes a process's streams onto a few hardware queues, and a stream that shares its queue
+        # with the step's stream (or its dW side stream) runs nothing beside it — with a normal-priority stream the gain came and went with
+        # the pool index the stream happened to get (duo BERT: +10 % or 0).  The other pool has queues of its own; and priority is what
+        # this stream should have: its few long kernels take their CUs first, the step's many short ones fill the rest.
+        self.fwd = torch.cuda.Stream(device, priority=-1)
+        self.n_fwd = 8 * int(cus_per_xcd_fwd)
+        with torch.cuda.device(device):
+            L.check(L.lib().ag_set_stream_cus(self.fwd.cuda_stream, self.n_fwd))
+
+
+_PARTITIONS = {}
+
+
+def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartition]:
+    """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: "0" off; an integer = CUs per XCD the target forward's persistent
+    GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32 for a ViT explainer whose backbone trains, 28 for a
+    frozen backbone (a short step) and for BERT explainers (a step-dominated epoch).  One rank only (RCCL's kernels need CUs at moments of their own), never under the hipGraph step."""
+    from .. import distributed, training16
+    mode = os.environ.get("AG_TRAIN_PARTITION", "auto")
+    if mode == "0" or device.type != "cuda" or distributed.world()[1] > 1 or training16.GRAPH_STEP:
+        return None
+    if mode == "auto":
+        # measured (tools/train_step_bench.py, 36 steps of 8 images x 32 masks, images/s off -> on): vanilla ViT-base 553 -> 638 at 24 (601 at
+        # 28, 608 at 20); froyo ViT-base (frozen backbone: a short step) 726 -> 790 at 28 (748 at 24, 688 at 20); duo BERT-base 920 -> 950-1015 at 28
+        vit = getattr(m_explainer, "vit", None)
+        c = 24 if (vit is not None and any(q.requires_grad for q in vit.parameters())) else 28
+    else:
+        c = int(mode)
+    props = torch.cuda.get_device_properties(device)
+    if props.multi_processor_count % 32 != 0 or not (0 < c < props.multi_processor_count // 8) or c % 4 != 0:
+        return None
+    key = (str(device), c)
+    if key not in _PARTITIONS:
+        _PARTITIONS[key] = TrainPartition(device, c)
+    return _PARTITIONS[key]
+
+
+def _cuda_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _cuda_tensors(o)
+
+
+def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Optional[TrainPartition]):
+    """yield (group, compute(group)) for every group; the caller runs the group's steps on its own stream.  With ``part`` the targets of
+    group g + 1 are issued on ``part.fwd`` BEFORE the caller issues the steps of group g, so the two run side by side (the first
+    group's targets have nothing to run beside: they are computed on the caller's stream, with every CU).  Events order producers
+    and consumers, ``record_stream`` tells the caching allocator about the second stream of every tensor that crosses.  Masks are
+    still drawn group by group, batch by batch, from the one generator: the same masks, targets and steps as without ``part``."""
+    if part is None:
+        for g in groups:
+            yield g, compute(g)
+        return
+    main = torch.cuda.current_stream()
+
+    def launch(g):
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # the group's inputs were made on the caller's stream
+        with torch.cuda.stream(part.fwd):
+            part.fwd.wait_event(ready)
+            for t in _cuda_tensors(list(g)):
+                t.record_stream(part.fwd)
+            tg = compute(g)
+            done = torch.cuda.Event()
+            done.record(part.fwd)
+        for t in _cuda_tensors(tg):
+            t.record_stream(main)
+        return tg, done
+
+    it = iter(groups)
+    cur = next(it, None)
+    if cur is None:
+        return
+    cur_t = (compute(cur), None)
+    while cur is not None:
+        nxt = next(it, None)
+        nxt_t = launch(nxt) if nxt is not None else None
+        if cur_t[1] is not None:
+            main.wait_event(cur_t[1])
+        yield cur, cur_t[0]
+        cur, cur_t = nxt, nxt_t
+    main.wait_stream(part.fwd)

@@ -12,7 +12,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard_auto
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard_auto, pipelined_targets, train_partition
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -60,9 +60,14 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
         if group:
             yield group
 
-    for group in grouped(d_items):
-        tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
-                                         spans=[g_[3] for g_ in group])
+    # (one rank: the targets of the NEXT group on a second stream beside this group's steps, scripts/common.TrainPartition)
+    part = train_partition(device, m_explainer) if reducer is None else None
+
+    def compute(group):
+        return surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
+                                           spans=[g_[3] for g_ in group])
+
+    for group, tg in pipelined_targets(grouped(d_items), compute, part):
         for (batch_idx, xs, zs, sp), (bits, v_s, v_1) in zip(group, tg):
             optimizer.zero_grad()
             n_tot, lo, hi = sp.astuple()

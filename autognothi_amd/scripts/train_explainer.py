@@ -10,6 +10,7 @@ training kernels (``autognothi_amd/training.py``) and the reference's own ``torc
 """
 from __future__ import annotations
 
+
 from typing import Any, Callable, Iterable, Optional, Tuple
 
 import torch
@@ -17,7 +18,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, shard, shard_auto
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, pipelined_targets, shard, shard_auto, train_partition
 from .common import mask_source as common_mask_source
 
 
@@ -213,14 +214,20 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         if group:
             yield group
 
+    # one rank on a GPU: the target forward of the NEXT group runs on a second stream (its persistent GEMM on 3/4 of every XCD's CUs)
+    # while this group's steps run on the caller's (common.TrainPartition / pipelined_targets); otherwise the two alternate
+    part = train_partition(device, m_explainer) if reducer is None else None
+
     def batches():
-        for group in grouped(d_items):
-            tg = surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
-                                             spans=[g_[3] for g_ in group])
+        def compute(group):
+            return surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,
+                                               spans=[g_[3] for g_ in group])
+        for group, tg in pipelined_targets(grouped(d_items), compute, part):
             for (idx, xs_, zs_, span), t_ in zip(group, tg):
                 yield idx, xs_, zs_, span, t_
 
-    for batch_idx, xs, zs, sp, (bits, v_s, v_1) in batches():
+    def one_step(batch_idx, xs, zs, sp, bits, v_s, v_1):
+        nonlocal total
         optimizer.zero_grad()
         n_tot, lo, hi = sp.astuple()
         if sp.by_mask:
@@ -230,7 +237,7 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
             optimizer.step()
             losses.append(loss.reshape(()) / n_ranks)
             total += n_tot / float(n_ranks)
-            continue
+            return
         weight = (hi - lo) / float(n_tot)
         ragged = n_tot < n_ranks                  # some rank holds no input of this batch: un-instrumented exchange for all
         if reducer is not None:
@@ -252,6 +259,9 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         total += hi - lo
         if getattr(env, "log_every_step", False) and n_ranks == 1:  # the reference logs the loss of every batch (a host read per step)
             env.log(f"  > epoch {epoch} :{batch_idx}:train // loss: shap {float(loss.item()) / xs.shape[0]:.6f}, fin {total}")
+
+    for batch_idx, xs, zs, sp, (bits, v_s, v_1) in batches():
+        one_step(batch_idx, xs, zs, sp, bits, v_s, v_1)
     reg_loss = float(torch.stack(losses).sum().item()) if losses else 0.0
     reg_loss, total = distributed.reduce_scalars([reg_loss, total], device)
     total = int(round(total))

@@ -306,10 +306,25 @@ def timed(fn, steps, warmup, dist, dev, settle_s=0.25):
 LAST_TRAIN_LAUNCHES = [0.0]   # kernels of this library per training step in the last train_step_rate call (targets + grand + fwd/bwd)
 
 
-def train_step_rate(job, dist, n_train, tb, precision, graph=False):
+def train_step_rate(job, dist, n_train, tb, precision, graph=False, partition=None):
     """One reference _explainer_epoch_train body per step (scripts/train_explainer.py:128-207) = K-mask surrogate targets
     (inference path) + the all-ones grand forward + explainer forward/backward + AdamW.  -> (images/s, flops per step).
-    ``graph``: the explainer forward + loss + backward replayed from a hipGraph (training16.GRAPH_STEP; one rank only)."""
+    ``graph``: the explainer forward + loss + backward replayed from a hipGraph (training16.GRAPH_STEP; one rank only).
+    ``partition``: AG_TRAIN_PARTITION for this measurement (None: the product default, "0": everything on one stream)."""
+    keep_part = os.environ.get("AG_TRAIN_PARTITION")
+    if partition is not None:
+        os.environ["AG_TRAIN_PARTITION"] = partition
+    try:
+        return _train_step_rate(job, dist, n_train, tb, precision, graph)
+    finally:
+        if partition is not None:
+            if keep_part is None:
+                os.environ.pop("AG_TRAIN_PARTITION", None)
+            else:
+                os.environ["AG_TRAIN_PARTITION"] = keep_part
+
+
+def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     from autognothi_amd import training as _tr
     from autognothi_amd import training16 as _tr16
     from autognothi_amd.scripts import train_explainer as te
@@ -748,16 +763,22 @@ def main():
     c5 = {}
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        rate, f_step, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision)
+        n_steps_train = 36        # six look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
+        rate, f_step, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision)
         launches_eager = LAST_TRAIN_LAUNCHES[0]
-        rate_graph = None
+        rate_graph = rate_one = None
         if world == 1 and args.precision == "bf16" and not args.no_secondary:
-            rate_graph, _, _ = train_step_rate(job, dist, 12, args.train_batch, args.precision, graph=True)
+            rate_graph, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, graph=True)
+            rate_one, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, partition="0")
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
-                       "steps": 12, "library_launches_per_step": round(launches_eager, 1),
+                       "steps": n_steps_train, "library_launches_per_step": round(launches_eager, 1),
                        "launch": "eager (the epoch body keeps the GPU busy with the K-mask target forward of the next batches while the host "
                                  "issues the step)",
+                       "one_stream_value": None if rate_one is None else round(rate_one, 1),
+                       "schedule": "one rank: the K-mask target forward of the NEXT group of batches on a second stream, its persistent GEMM confined "
+                                   "to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition); one_stream_value = "
+                                   "AG_TRAIN_PARTITION=0: the two back to back on one stream, which is also what N > 1 ranks run",
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
                        "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
                                        "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
@@ -775,9 +796,11 @@ def main():
         if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16":
             for wl in ("duo_bert_base", "froyo_vit_base"):
                 j5 = Job(wl, dev, rank, world, args.train_batch, 0, args.precision)
-                r5, f5, frozen = train_step_rate(j5, dist, 12, args.train_batch, args.precision)
+                r5, f5, frozen = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision)
+                r5_one = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision, partition="0")[0] if world == 1 else None
                 tf5 = r5 / world / args.train_batch * f5 / 1e12
-                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
+                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "one_stream_value": None if r5_one is None else round(r5_one, 1),
+                          "unit": "images/s", "masks_per_image": j5.K,
                           "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,
                           "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
                           "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
@@ -788,7 +811,7 @@ def main():
             for wl in (() if lean else ("duo_bert_base", "froyo_vit_base")):
                 for tb_ in (2, 4):
                     j5 = Job(wl, dev, rank, world, tb_, 0, args.precision)
-                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision)
+                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision, partition="0")   # (what one of N > 1 ranks runs)
                     l5 = LAST_TRAIN_LAUNCHES[0]
                     r5g = train_step_rate(j5, dist, 12, tb_, args.precision, graph=True)[0] if world == 1 else None
                     tf5 = r5 / world / tb_ * f5 / 1e12

@@ -485,10 +485,12 @@ int ag_bert_encoder_forward_pruned(const ag_encoder_desc* desc, const void* d_h0
 /* Experiment / test knobs (AG_GEMM_*, AG_SIDE_MLP, AG_BERT_LN_FOLD, ...) are read from the environment ONCE per process, never on
  * the launch path; a test that changes one calls this to have them read again. */
 int ag_reload_knobs(void);
-/* CU-partitioned streams.  A stream created with hipExtStreamCreateWithCUMask runs on a subset of the CUs; the persistent large-M GEMM
- * launches one resident workgroup per CU and must be told how many its stream has (n_cu > 0 registers, n_cu <= 0 forgets).  Used by the
- * explainer training epoch: the K-mask target forward of the NEXT batches on most CUs of every XCD, the explainer's own under-filled
- * step on the rest, at the same time (scripts/train_explainer.py:153-198 run them back to back). */
+/* How many CUs the persistent large-M GEMM may take on a given stream (n_cu > 0 registers, n_cu <= 0 forgets; default: every CU).  The
+ * kernel launches one resident workgroup per CU; a stream registered with n_cu = 8 c launches 8 c workgroups — c on every XCD, an equal
+ * number on every shader engine when c is a multiple of 4 — and leaves the other CUs to whatever else is queued on the device.  Used by
+ * the explainer training epoch (scripts/common.TrainPartition): the K-mask target forward of the NEXT batches on a second stream with
+ * 24-28 of every XCD's 32 CUs while the explainer's own, under-filled step runs on the caller's stream (the reference runs the two back
+ * to back: scripts/train_explainer.py:153-198).  Also what a stream created with hipExtStreamCreateWithCUMask has to be registered with. */
 int ag_set_stream_cus(void* stream, int n_cu);
 
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but

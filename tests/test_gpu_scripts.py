@@ -206,3 +206,47 @@ def test_target_lookahead_equals_batch_by_batch(cuda_device):
         gen = lambda a, b_: (lambda x: (x, torch.zeros(x.shape[0], dtype=torch.long, device=dev)))(next(it))  # noqa: E731
         losses.append(te.explainer_epoch_train(None, dev, k, p, v0, items, recipe, srg, e2, opt, 1, gen, seed=5, target_rows=rows))
     np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,cus", [("vit_tiny_c1", "24"), ("vit_tiny_c1", "28")])
+def test_partitioned_epoch_equals_one_stream(cuda_device, monkeypatch, tag, cus):
+    """The explainer training epoch on two streams (common.TrainPartition: the K-mask targets of the NEXT group of batches on a second
+    stream, its persistent GEMM confined to `cus` CUs of every XCD, beside this group's steps) against the same epoch on the caller's
+    stream alone: the same masks, the same epoch loss and bit-identical parameters after two epochs of AdamW with dropout on (only
+    the schedule differs)."""
+    import copy
+    from autognothi_amd import engine, training
+    from autognothi_amd.scripts import common, train_explainer as te
+    from autognothi_amd.utils import synth
+    if torch.cuda.get_device_properties(cuda_device).multi_processor_count % 32 != 0:
+        pytest.skip("CU partitions need a CU count that is a multiple of 32")
+    engine.set_precision("bf16")                     # the bf16 step (training16.py) is bit-reproducible; the fp32 step's LayerNorm backward
+    monkeypatch.setattr(training, "MIXED_BF16", True)   # adds its per-wave partials with LDS float atomics (last-bit run-to-run noise)
+    c = build_case(tag)
+    dev, recipe = cuda_device, c["recipe"]
+    srg = c["surrogate"].to(dev).eval()
+    prm = c["meta"]["params"]
+    sizes = (2, 3, 1, 2, 4, 2, 3)
+    data = [torch.from_numpy(synth.synth_images(n, prm["img_px_size"], prm["img_channels"], seed=70 + i)).to(dev) for i, n in enumerate(sizes)]
+    k, p = 6, c["P"]
+    v0 = torch.from_numpy(c["g"]["v_0"]).to(dev)
+    out = {}
+    for mode in ("0", cus):
+        monkeypatch.setenv("AG_TRAIN_PARTITION", mode)
+        exp = copy.deepcopy(c["explainer"]).to(dev)
+        opt = torch.optim.AdamW(exp.parameters(), lr=1e-3)
+        losses = []
+        for epoch in (1, 2):
+            it = iter(data)
+            gen = lambda a, b_: (lambda x: (x, torch.zeros(x.shape[0], dtype=torch.long, device=dev)))(next(it))  # noqa: E731
+            # target_rows = 20 masked rows: three groups per epoch (the pipeline has a group in flight while another one trains)
+            losses.append(te.explainer_epoch_train(None, dev, k, p, v0, [(None, None)] * len(data), recipe, srg, exp, opt, epoch, gen,
+                                                   seed=11, target_rows=20))
+        torch.cuda.synchronize()
+        out[mode] = (losses, [q.detach().clone() for q in exp.parameters()])
+        part = common.train_partition(dev, exp)
+        assert (part is None) == (mode == "0")
+    engine.set_precision("fp32")
+    assert out["0"][0] == out[cus][0]
+    for a, b in zip(out["0"][1], out[cus][1]):
+        assert torch.equal(a, b)

@@ -52,7 +52,14 @@ seq = wall(lambda: (job.step(), [estep() for _ in range(n_e)]), 3)
 print(json.dumps({"default_stream": {"forward_ms": round(base_f, 3), "explainer_step_ms": round(base_e, 3), "steps_per_forward": n_e,
                                      "back_to_back_ms_per_group": round(seq, 3), "ms_per_training_step": round(seq / n_e, 3)}}), flush=True)
 for c in [int(x) for x in os.environ.get("CP_SPLITS", "28,26,24,22").split(",")]:
-    sa, sb, na, nb = ops.cu_partition_streams(dev, c)
+    if os.environ.get("CP_GRID_ONLY", "0") == "1":
+        # no CU masks: two ordinary (non-blocking) streams; the forward's persistent GEMM is only told to launch 8 c workgroups
+        # (one per CU: the other CUs stay free for whatever else is queued)
+        from autognothi_amd import _lib as L
+        sa, sb, na, nb = torch.cuda.Stream(dev), torch.cuda.Stream(dev), 8 * c, 256 - 8 * c
+        L.check(L.lib().ag_set_stream_cus(sa.cuda_stream, na))
+    else:
+        sa, sb, na, nb = ops.cu_partition_streams(dev, c)
 
     def fwd_a():
         with torch.cuda.stream(sa):
