@@ -131,6 +131,12 @@ class TrainPartition:
         self.n_fwd = 8 * int(cus_per_xcd_fwd)
         with torch.cuda.device(device):
             L.check(L.lib().ag_set_stream_cus(self.fwd.cuda_stream, self.n_fwd))
+        # None: not measured yet; True / False: two streams beat / do not beat one stream in THIS process.  It has to be measured: HIP
+        # multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per priority, assigned as streams are created; a
+        # second stream whose queue is shared with a stream of the step runs in submission order behind or in front of it, and the
+        # same code is then 20 % slower instead of 15 % faster (seen with one more hipGraph capture earlier in the process).
+        self.verdict: Optional[bool] = None
+        self.measured = None      # (sequential estimate, overlapped) ms of the deciding group, for logs / tests
 
 
 _PARTITIONS = {}
@@ -169,17 +175,26 @@ def _cuda_tensors(obj):
             yield from _cuda_tensors(o)
 
 
-def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Optional[TrainPartition]):
+def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Optional[TrainPartition], size: Callable[[Any], float] = len):
     """yield (group, compute(group)) for every group; the caller runs the group's steps on its own stream.  With ``part`` the targets of
     group g + 1 are issued on ``part.fwd`` BEFORE the caller issues the steps of group g, so the two run side by side (the first
     group's targets have nothing to run beside: they are computed on the caller's stream, with every CU).  Events order producers
     and consumers, ``record_stream`` tells the caching allocator about the second stream of every tensor that crosses.  Masks are
-    still drawn group by group, batch by batch, from the one generator: the same masks, targets and steps as without ``part``."""
-    if part is None:
+    still drawn group by group, batch by batch, from the one generator: the same masks, targets and steps as without ``part``.
+
+    Whether two streams pay in this process is MEASURED once per process (``part.verdict``), with events on the caller's stream that are never waited
+    for: the period of a group on one stream against the period of a group in the two-stream steady state (an epoch of seven groups or
+    more decides; until then, and from a two-stream period above 97 % of the other on, the schedule is / falls back to what was measured)."""
+    if part is None or part.verdict is False:
         for g in groups:
             yield g, compute(g)
         return
     main = torch.cuda.current_stream()
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(main)
+        return e
 
     def launch(g):
         ready = torch.cuda.Event()
@@ -199,12 +214,44 @@ def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Opt
     cur = next(it, None)
     if cur is None:
         return
-    cur_t = (compute(cur), None)
+    probe = part.verdict is None
+    # probe: groups 0-2 run alone on the caller's stream, targets then steps (groups 0 and 1 warm up; the period of group 2 — end of group
+    # 1's steps to end of its own — is the one-stream figure); from group 3 on the next group's targets run beside the steps, and the
+    # period of group 5 — its targets were computed beside group 4's steps, group 6's are being computed beside its own — is the
+    # two-stream figure
+    ev = {}                                                  # group index -> event after its steps
+    sizes = {}
+
+    def decide(wait: bool) -> None:
+        if part.verdict is not None or 5 not in ev:
+            return
+        if wait:
+            ev[5].synchronize()
+        elif not ev[5].query():
+            return
+        seq = ev[1].elapsed_time(ev[2]) * sizes[5] / sizes[2]
+        ovl = ev[4].elapsed_time(ev[5])
+        part.measured = (seq, ovl)
+        part.verdict = bool(ovl <= 0.97 * seq)
+
+    idx = 0
+    cur_t = "later"
     while cur is not None:
+        if probe:
+            decide(False)
         nxt = next(it, None)
-        nxt_t = launch(nxt) if nxt is not None else None
+        overlap = part.verdict is not False and not (probe and idx < 3) and nxt is not None
+        if cur_t == "later":
+            cur_t = (compute(cur), None)
+        nxt_t = launch(nxt) if overlap else "later"          # "later": on the caller's stream, when its turn comes
         if cur_t[1] is not None:
             main.wait_event(cur_t[1])
         yield cur, cur_t[0]
+        if probe and part.verdict is None and idx <= 5 and (idx < 5 or nxt is not None):
+            ev[idx] = mark()
+            sizes[idx] = float(size(cur))
         cur, cur_t = nxt, nxt_t
+        idx += 1
     main.wait_stream(part.fwd)
+    if probe:
+        decide(True)

@@ -27,6 +27,8 @@ import subprocess
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (before the HIP runtime comes up: see autognothi_amd/__init__.py)
+
 import numpy as np
 import torch
 
@@ -345,7 +347,11 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     gen = lambda a, b_: (tx, labels)  # noqa: E731
     # warm-up: one whole look-ahead group (the K-mask targets of consecutive batches run as ONE forward of >= 1 536 rows), so that the
     # workspace of that forward exists before the timed epoch (its hipMalloc of several GB takes anything from 1 to 100+ ms)
-    n_warm = max(2, -(-1536 // max(1, tb * job.K)))
+    # ... TWO groups: with the two-stream schedule the second group's targets are the first thing the second stream computes (its own
+    # allocator pool: the same hipMallocs again)
+    # ... EIGHT groups: the two-stream schedule (scripts/common.pipelined_targets) measures in its first seven groups whether the
+    # second stream pays in this process and keeps the verdict; the second stream's allocator pool fills here as well
+    n_warm = 8 * max(2, -(-1536 // max(1, tb * job.K)))
     te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * n_warm, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
     torch.cuda.synchronize()
     if dist is not None:
@@ -379,6 +385,15 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     _tr.MIXED_BF16 = False
     _tr16.GRAPH_STEP = keep_graph
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
+
+
+def two_stream_verdicts():
+    """what scripts/common.pipelined_targets measured in this process: per (device, CUs per XCD of the target forward) whether the second
+    stream beat one stream, with the two group periods (ms) it compared."""
+    from autognothi_amd.scripts import common
+    return {f"{k[0]}:{k[1]}": {"two_streams_pay": p_.verdict,
+                               "group_ms_one_stream_estimate_vs_two_streams": None if p_.measured is None else [round(x, 2) for x in p_.measured]}
+            for k, p_ in common._PARTITIONS.items()}
 
 
 def grad_exchange_overlap(job, dev, tb, steps=6):
@@ -575,6 +590,7 @@ def main():
     # N > 1 ranks (the driver's scaling runs): the timed hot path, the attribution metric and the training steps with their gradient
     # exchange; the single-GPU studies (batch sweep, fp32 mode, other configs, accuracy ledger, strong-scaling shards) belong to the N = 1 line
     lean = world > 1
+    skip = set(filter(None, os.environ.get("AG_BENCH_SKIP", "").split(",")))    # (development: leave secondary legs out by name)
     if args.no_secondary:
         args.attr_batch = args.train_batch = 0
 
@@ -617,7 +633,7 @@ def main():
 
     # ---- SURVEY C2 sweep: the reference's own operating point is 2-4 inputs x K masks per GPU (experiments/*/.hparams.json):
     # eager launches vs one hipGraph replay per step
-    if not args.no_secondary and args.precision == "bf16" and not lean:
+    if not args.no_secondary and args.precision == "bf16" and not lean and "sweep" not in skip:
         sweep = []
         for b_s in (1, 4, 16, 48):
             job.set_batch(b_s)
@@ -633,7 +649,7 @@ def main():
                                           "(one hipGraphLaunch per step: sampler + forward)", "points": sweep}
 
     # ---- fp32 parity mode (exact-fp32 MFMA): the mode the 1e-4 Shapley criterion is checked in
-    if not args.no_secondary and args.precision == "bf16" and not lean:
+    if not args.no_secondary and args.precision == "bf16" and not lean and "fp32" not in skip:
         engine.set_precision("fp32")
         job.set_batch(8)
         el32, _ = timed(job.step, 3, 1, dist, dev)
@@ -660,7 +676,7 @@ def main():
 
     # ---- calibration, not a product path: the vendor library (torch.matmul -> hipBLASLt) on the same four encoder GEMM shapes,
     # bf16 in / bf16 out, NO bias / GELU / residual / LayerNorm-fold epilogue, against this library's kernels WITH theirs
-    if not args.no_secondary and args.precision == "bf16" and rank == 0 and not lean:
+    if not args.no_secondary and args.precision == "bf16" and rank == 0 and not lean and "vendor" not in skip:
         hidden, inter = params["hidden_size"], params["intermediate_size"]
         m_rows = R * T
         cal = {}
@@ -687,7 +703,7 @@ def main():
                                                 "shapes": cal}
 
     # ---- the other BASELINE configs that fit one GPU (configs 3 and 4), compact, same step function
-    if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16" and not lean:
+    if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16" and not lean and "configs" not in skip:
         cfgs = {}
         cfgs["bert_base_tayp_vanilla_seq128_K32"] = compact_config_line("bert_base", dev, rank, world, 48, dist)
         cfgs["bert_base_tayp_vanilla_seq128_K32_token_pruning_off"] = compact_config_line("bert_base", dev, rank, world, 48, dist, prune=False)
@@ -705,7 +721,7 @@ def main():
                                          "configs": cfgs}
 
     # ---- what the throughput mode costs in accuracy, from the committed reference fixtures (rank 0)
-    if not args.no_secondary and args.precision == "bf16" and rank == 0 and not lean:
+    if not args.no_secondary and args.precision == "bf16" and rank == 0 and not lean and "ledger" not in skip:
         dev_blocks = {}
         for wl in ([args.workload] + (["bert_base", "vit_large"] if args.workload == "vit_base" else [])):
             blk = bf16_vs_reference(wl, dev)
@@ -763,7 +779,7 @@ def main():
     c5 = {}
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        n_steps_train = 36        # six look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
+        n_steps_train = 72        # twelve look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
         rate, f_step, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision)
         launches_eager = LAST_TRAIN_LAUNCHES[0]
         rate_graph = rate_one = None
@@ -779,6 +795,7 @@ def main():
                        "schedule": "one rank: the K-mask target forward of the NEXT group of batches on a second stream, its persistent GEMM confined "
                                    "to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition); one_stream_value = "
                                    "AG_TRAIN_PARTITION=0: the two back to back on one stream, which is also what N > 1 ranks run",
+                       "two_stream_verdict": two_stream_verdicts(),
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
                        "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
                                        "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
