@@ -35,6 +35,7 @@ BF16, F32 = L.AG_BF16, L.AG_F32
 VIT, BERT = L.AG_MASK_VIT_MUL, L.AG_MASK_BERT_ADD
 SIDE_STREAM = os.environ.get("AG_TRAIN_SIDE", "1") != "0"
 N_SIDE = max(1, int(os.environ.get("AG_TRAIN_SIDE", "1") or 1))     # number of side streams (AG_TRAIN_SIDE=0: none)
+SIDE_MIN_ROWS = int(os.environ.get("AG_TRAIN_SIDE_MIN_ROWS", "1024"))   # token rows of a step below which the dW products stay on the main stream
 # hipGraph capture of the explainer step (forward + loss + backward, both streams): "1" on, "0" off (the default: the epoch bodies
 # keep the GPU busy with the K-mask target forward while the host issues the step, so eager launches cost nothing there; it pays at
 # 2-4 images per step, where the ~420 launches are host-bound).  Never used while a gradient sink is installed (N > 1 ranks: the
@@ -65,6 +66,10 @@ class _Side:
         self.keep: List[Tensor] = []
         self.finals: List[Tensor] = []     # parameters whose gradient was produced on the MAIN stream since the last fork
         self.dirty = False
+        # this backward runs its dW products in line (set per step by the trainers): under hipGraph capture — a one-branch graph replays at
+        # the eager rate whatever GPU_MAX_HW_QUEUES is, a forked one at half of it with 8 queues (vanilla ViT-base 524 vs 353 images/s) —
+        # and below SIDE_MIN_ROWS token rows, where fork and join cost more than the products they move (duo BERT at 2 images: 259 -> 337)
+        self.inline = False
 
     @classmethod
     def of(cls, device) -> "_Side":
@@ -74,7 +79,7 @@ class _Side:
         return cls._per_device[key]
 
     def run(self, fn, *keep: Tensor) -> None:
-        if not self.streams:
+        if not self.streams or self.inline:
             fn()
             self._report()
             return
@@ -711,6 +716,7 @@ class ExplainerTrainer16:
         b, t, h, c, ph, s_exp, duo_saved, o_last = self.saved
         self.saved = None
         side = self.side
+        side.inline = self.use_graph or b * t < SIDE_MIN_ROWS
         dev = dphi.device
         dz_extra = None
         if self.duo and dbase is not None:
@@ -861,6 +867,7 @@ class SurrogateTrainer16:
                 dzc = self.pool.backward(ops.tanh_bwd(pooled, dp))
         dz = torch.zeros((b, t, h), dtype=torch.float32, device=dprobs.device)
         dz[:, 0, :].copy_(dzc)
+        self.side.inline = b * t < SIDE_MIN_ROWS
         if not self.backbone.frozen:
             self.backbone.backward(self.side, dz.view(b * t, h))
         self.side.join()
