@@ -109,50 +109,44 @@ def shard(xs, zs=None):
     return xs[lo:hi], (zs[lo:hi] if zs is not None else None), n, lo, hi
 
 
-# ---------------------------------------------------------------------------------------------- two-stream training epoch
+# ---------------------------------------------------------------------------------------------- two-stream training epoch (opt-in)
 class TrainPartition:
-    """The second stream of an explainer training epoch.  The reference runs the K-mask target forward and the explainer's own step
-    back to back (scripts/train_explainer.py:153-198); the surrogate is frozen, so the targets of group g + 1 depend on nothing the
-    steps of group g do, and the two want different things from the chip: the target forward is the hot path (feed-bound: it loses
-    6-13 % on 7/8 - 3/4 of the CUs, throughput ~ CUs^0.43), the step is 400 launches on 1.5 k token rows that fill a quarter of the CUs
-    at best.  ``fwd`` is an ordinary (non-blocking) stream on which the persistent large-M GEMM is told to launch only ``n_fwd``
-    workgroups (ag_set_stream_cus: one per CU, an equal number on every XCD and shader engine), so the other CUs are free for the step's
-    kernels on the caller's stream at any moment.  No CU masks: hipExtStreamCreateWithCUMask streams are blocking streams — every
-    null-stream operation of the process becomes a barrier across them (measured: a step-bound epoch on the null stream 2x slower
-    while two such streams merely exist) — and masking the step's side buys less (+14 % against +18 %; profiles/HISTORY.md §10)."""
+    """The second stream of an explainer training epoch (opt-in: ``AG_TRAIN_PARTITION``).  The reference runs the K-mask target forward
+    and the explainer's own step back to back (scripts/train_explainer.py:153-198); the surrogate is frozen, so the targets of group
+    g + 1 depend on nothing the steps of group g do, and the two want different things from the chip: the target forward is the hot path
+    (feed-bound: it loses 6-13 % on 7/8 - 3/4 of the CUs, throughput ~ CUs^0.43), the step is 400 launches on 1.5 k token rows that fill
+    a quarter of the CUs at best.  ``fwd`` is an ordinary (non-blocking, high-priority) stream on which the persistent large-M GEMM is
+    told to launch only ``n_fwd`` workgroups (ag_set_stream_cus: one per CU, an equal number on every XCD and shader engine), so the
+    other CUs are free for the step's kernels on the caller's stream at any moment.  No CU masks: hipExtStreamCreateWithCUMask streams
+    are blocking streams — every null-stream operation of the process becomes a barrier across them — and buy less (+14 % against +18 %).
+
+    Why opt-in (profiles/HISTORY.md §10): HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per priority,
+    assigned as streams are created; when the second stream shares a queue with a stream of the step, the same code runs 20-50 %
+    SLOWER than one stream instead of 15 % faster, and which of the two it is depends on how many streams the process created before.
+    In a fresh process with GPU_MAX_HW_QUEUES=8 the gain is reproducible (vanilla ViT-base 8 images x 32 masks: 553 -> 638 images/s)."""
 
     def __init__(self, device: torch.device, cus_per_xcd_fwd: int):
         from .. import _lib as L
-        # from the HIGH-priority pool: HIP multiplexes a process's streams onto a few hardware queues, and a stream that shares its queue
-        # with the step's stream (or its dW side stream) runs nothing beside it — with a normal-priority stream the gain came and went with
-        # the pool index the stream happened to get (duo BERT: +10 % or 0).  The other pool has queues of its own; and priority is what
-        # this stream should have: its few long kernels take their CUs first, the step's many short ones fill the rest.
         self.fwd = torch.cuda.Stream(device, priority=-1)
         self.n_fwd = 8 * int(cus_per_xcd_fwd)
         with torch.cuda.device(device):
             L.check(L.lib().ag_set_stream_cus(self.fwd.cuda_stream, self.n_fwd))
-        # None: not measured yet; True / False: two streams beat / do not beat one stream in THIS process.  It has to be measured: HIP
-        # multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per priority, assigned as streams are created; a
-        # second stream whose queue is shared with a stream of the step runs in submission order behind or in front of it, and the
-        # same code is then 20 % slower instead of 15 % faster (seen with one more hipGraph capture earlier in the process).
-        self.verdict: Optional[bool] = None
-        self.measured = None      # (sequential estimate, overlapped) ms of the deciding group, for logs / tests
 
 
 _PARTITIONS = {}
 
 
 def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartition]:
-    """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: "0" off; an integer = CUs per XCD the target forward's persistent
-    GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32 for a ViT explainer whose backbone trains, 28 for a
-    frozen backbone (a short step) and for BERT explainers (a step-dominated epoch).  One rank only (RCCL's kernels need CUs at moments of their own), never under the hipGraph step."""
+    """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: unset / "0" = off (default); an integer = CUs per XCD the target
+    forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto": 24 of 32 for a ViT explainer whose backbone
+    trains, 28 for a frozen backbone or a BERT explainer.  One rank only, never under the hipGraph step."""
     from .. import distributed, training16
-    mode = os.environ.get("AG_TRAIN_PARTITION", "auto")
-    if mode == "0" or device.type != "cuda" or distributed.world()[1] > 1 or training16.GRAPH_STEP:
+    mode = os.environ.get("AG_TRAIN_PARTITION", "0")
+    if mode in ("0", "") or device.type != "cuda" or distributed.world()[1] > 1 or training16.GRAPH_STEP:
         return None
     if mode == "auto":
-        # measured (tools/train_step_bench.py, 36 steps of 8 images x 32 masks, images/s off -> on): vanilla ViT-base 553 -> 638 at 24 (601 at
-        # 28, 608 at 20); froyo ViT-base (frozen backbone: a short step) 726 -> 790 at 28 (748 at 24, 688 at 20); duo BERT-base 920 -> 950-1015 at 28
+        # measured in a fresh process with 8 hardware queues (tools/train_step_bench.py, 36 steps of 8 images x 32 masks, images/s off -> on):
+        # vanilla ViT-base 553 -> 638 at 24 (601 at 28, 608 at 20); froyo ViT-base 726 -> 790 at 28 (748 at 24, 688 at 20); duo BERT-base 920 -> 950-1 015 at 28
         vit = getattr(m_explainer, "vit", None)
         c = 24 if (vit is not None and any(q.requires_grad for q in vit.parameters())) else 28
     else:
@@ -175,26 +169,18 @@ def _cuda_tensors(obj):
             yield from _cuda_tensors(o)
 
 
-def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Optional[TrainPartition], size: Callable[[Any], float] = len):
+def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Optional[TrainPartition]):
     """yield (group, compute(group)) for every group; the caller runs the group's steps on its own stream.  With ``part`` the targets of
     group g + 1 are issued on ``part.fwd`` BEFORE the caller issues the steps of group g, so the two run side by side (the first
     group's targets have nothing to run beside: they are computed on the caller's stream, with every CU).  Events order producers
     and consumers, ``record_stream`` tells the caching allocator about the second stream of every tensor that crosses.  Masks are
-    still drawn group by group, batch by batch, from the one generator: the same masks, targets and steps as without ``part``.
-
-    Whether two streams pay in this process is MEASURED once per process (``part.verdict``), with events on the caller's stream that are never waited
-    for: the period of a group on one stream against the period of a group in the two-stream steady state (an epoch of seven groups or
-    more decides; until then, and from a two-stream period above 97 % of the other on, the schedule is / falls back to what was measured)."""
-    if part is None or part.verdict is False:
+    still drawn group by group, batch by batch, from the one generator: the same masks, targets and steps as without ``part``
+    (tests/test_gpu_scripts.py: bit-identical parameters after two epochs)."""
+    if part is None:
         for g in groups:
             yield g, compute(g)
         return
     main = torch.cuda.current_stream()
-
-    def mark():
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(main)
-        return e
 
     def launch(g):
         ready = torch.cuda.Event()
@@ -214,44 +200,12 @@ def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Opt
     cur = next(it, None)
     if cur is None:
         return
-    probe = part.verdict is None
-    # probe: groups 0-2 run alone on the caller's stream, targets then steps (groups 0 and 1 warm up; the period of group 2 — end of group
-    # 1's steps to end of its own — is the one-stream figure); from group 3 on the next group's targets run beside the steps, and the
-    # period of group 5 — its targets were computed beside group 4's steps, group 6's are being computed beside its own — is the
-    # two-stream figure
-    ev = {}                                                  # group index -> event after its steps
-    sizes = {}
-
-    def decide(wait: bool) -> None:
-        if part.verdict is not None or 5 not in ev:
-            return
-        if wait:
-            ev[5].synchronize()
-        elif not ev[5].query():
-            return
-        seq = ev[1].elapsed_time(ev[2]) * sizes[5] / sizes[2]
-        ovl = ev[4].elapsed_time(ev[5])
-        part.measured = (seq, ovl)
-        part.verdict = bool(ovl <= 0.97 * seq)
-
-    idx = 0
-    cur_t = "later"
+    cur_t = (compute(cur), None)
     while cur is not None:
-        if probe:
-            decide(False)
         nxt = next(it, None)
-        overlap = part.verdict is not False and not (probe and idx < 3) and nxt is not None
-        if cur_t == "later":
-            cur_t = (compute(cur), None)
-        nxt_t = launch(nxt) if overlap else "later"          # "later": on the caller's stream, when its turn comes
+        nxt_t = launch(nxt) if nxt is not None else None
         if cur_t[1] is not None:
             main.wait_event(cur_t[1])
         yield cur, cur_t[0]
-        if probe and part.verdict is None and idx <= 5 and (idx < 5 or nxt is not None):
-            ev[idx] = mark()
-            sizes[idx] = float(size(cur))
         cur, cur_t = nxt, nxt_t
-        idx += 1
     main.wait_stream(part.fwd)
-    if probe:
-        decide(True)

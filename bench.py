@@ -27,8 +27,6 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (before the HIP runtime comes up: see autognothi_amd/__init__.py)
-
 import numpy as np
 import torch
 
@@ -349,9 +347,7 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     # workspace of that forward exists before the timed epoch (its hipMalloc of several GB takes anything from 1 to 100+ ms)
     # ... TWO groups: with the two-stream schedule the second group's targets are the first thing the second stream computes (its own
     # allocator pool: the same hipMallocs again)
-    # ... EIGHT groups: the two-stream schedule (scripts/common.pipelined_targets) measures in its first seven groups whether the
-    # second stream pays in this process and keeps the verdict; the second stream's allocator pool fills here as well
-    n_warm = 8 * max(2, -(-1536 // max(1, tb * job.K)))
+    n_warm = 2 * max(2, -(-1536 // max(1, tb * job.K)))
     te.explainer_epoch_train(None, dev, job.K, job.P, v0, [(None, None)] * n_warm, recipe, job.surrogate, m_exp, opt, 1, gen, seed=7)
     torch.cuda.synchronize()
     if dist is not None:
@@ -387,13 +383,28 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
-def two_stream_verdicts():
-    """what scripts/common.pipelined_targets measured in this process: per (device, CUs per XCD of the target forward) whether the second
-    stream beat one stream, with the two group periods (ms) it compared."""
-    from autognothi_amd.scripts import common
-    return {f"{k[0]}:{k[1]}": {"two_streams_pay": p_.verdict,
-                               "group_ms_one_stream_estimate_vs_two_streams": None if p_.measured is None else [round(x, 2) for x in p_.measured]}
-            for k, p_ in common._PARTITIONS.items()}
+def two_stream_child(tb, steps):
+    """The opt-in two-stream training epoch (scripts/common.TrainPartition: the K-mask target forward of the NEXT group of batches on a second
+    stream, its persistent GEMM confined to 24-28 of every XCD's 32 CUs, beside this group's steps) measured where it is reproducible: a
+    FRESH process with GPU_MAX_HW_QUEUES=8 (tools/train_step_bench.py; which hardware queue a stream lands on depends on the streams the
+    process created before, and this process has created dozens).  -> {workload: images/s, fraction of peak} or an error note."""
+    env = {k_: v_ for k_, v_ in os.environ.items()
+           if not (k_.startswith("TORCHELASTIC_") or k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))}
+    env.update(GPU_MAX_HW_QUEUES="8", AG_TRAIN_PARTITION="auto", STEPS=str(steps), TB=str(tb))
+    out = {"what": "AG_TRAIN_PARTITION=auto GPU_MAX_HW_QUEUES=8 python tools/train_step_bench.py (fresh process; same epoch body, masks, steps and "
+                   "parameters as `value`, bit for bit: tests/test_gpu_scripts.py; one rank only)"}
+    try:
+        r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_bench.py"), "vit_base", "froyo_vit_base"],
+                            capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
+        for ln in r_.stdout.splitlines():
+            if ln.startswith("{"):
+                d_ = json.loads(ln)
+                out[d_["workload"]] = {"value": d_["images_per_s"], "unit": "images/s", "frac": d_["frac"], "ms_per_step": d_["ms_per_step"]}
+        if len(out) == 1:
+            out["error"] = (r_.stderr or r_.stdout)[-300:]
+    except Exception as exc:
+        out["error"] = repr(exc)[:200]
+    return out
 
 
 def grad_exchange_overlap(job, dev, tb, steps=6):
@@ -782,20 +793,16 @@ def main():
         n_steps_train = 72        # twelve look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
         rate, f_step, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision)
         launches_eager = LAST_TRAIN_LAUNCHES[0]
-        rate_graph = rate_one = None
+        rate_graph, two_stream = None, None
         if world == 1 and args.precision == "bf16" and not args.no_secondary:
             rate_graph, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, graph=True)
-            rate_one, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, partition="0")
+            two_stream = two_stream_child(args.train_batch, n_steps_train)
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
                        "steps": n_steps_train, "library_launches_per_step": round(launches_eager, 1),
                        "launch": "eager (the epoch body keeps the GPU busy with the K-mask target forward of the next batches while the host "
                                  "issues the step)",
-                       "one_stream_value": None if rate_one is None else round(rate_one, 1),
-                       "schedule": "one rank: the K-mask target forward of the NEXT group of batches on a second stream, its persistent GEMM confined "
-                                   "to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition); one_stream_value = "
-                                   "AG_TRAIN_PARTITION=0: the two back to back on one stream, which is also what N > 1 ranks run",
-                       "two_stream_verdict": two_stream_verdicts(),
+                       "two_stream_opt_in": two_stream,
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
                        "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
                                        "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
@@ -814,10 +821,8 @@ def main():
             for wl in ("duo_bert_base", "froyo_vit_base"):
                 j5 = Job(wl, dev, rank, world, args.train_batch, 0, args.precision)
                 r5, f5, frozen = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision)
-                r5_one = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision, partition="0")[0] if world == 1 else None
                 tf5 = r5 / world / args.train_batch * f5 / 1e12
-                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "one_stream_value": None if r5_one is None else round(r5_one, 1),
-                          "unit": "images/s", "masks_per_image": j5.K,
+                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
                           "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,
                           "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
                           "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
@@ -828,7 +833,7 @@ def main():
             for wl in (() if lean else ("duo_bert_base", "froyo_vit_base")):
                 for tb_ in (2, 4):
                     j5 = Job(wl, dev, rank, world, tb_, 0, args.precision)
-                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision, partition="0")   # (what one of N > 1 ranks runs)
+                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision)
                     l5 = LAST_TRAIN_LAUNCHES[0]
                     r5g = train_step_rate(j5, dist, 12, tb_, args.precision, graph=True)[0] if world == 1 else None
                     tf5 = r5 / world / tb_ * f5 / 1e12
