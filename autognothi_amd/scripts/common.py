@@ -120,10 +120,11 @@ class TrainPartition:
     other CUs are free for the step's kernels on the caller's stream at any moment.  No CU masks: hipExtStreamCreateWithCUMask streams
     are blocking streams — every null-stream operation of the process becomes a barrier across them — and buy less (+14 % against +18 %).
 
-    Why opt-in (profiles/HISTORY.md §10): HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues per priority,
-    assigned as streams are created; when the second stream shares a queue with a stream of the step, the same code runs 20-50 %
-    SLOWER than one stream instead of 15 % faster, and which of the two it is depends on how many streams the process created before.
-    In a fresh process with GPU_MAX_HW_QUEUES=8 the gain is reproducible (vanilla ViT-base 8 images x 32 masks: 553 -> 638 images/s)."""
+    Why opt-in (profiles/HISTORY.md §10): in a fresh process with GPU_MAX_HW_QUEUES=8 the gain is reproducible (vanilla ViT-base 8 images x
+    32 masks: 553 -> 638 images/s); inside bench.py, after its batch sweep and with HIP's default 4 hardware queues, the same schedule runs
+    10-50 % SLOWER than one stream.  What the process did before decides, through HIP's multiplexing of streams onto hardware queues,
+    whether the two streams run beside or behind each other; neither stream priorities nor more queues nor an in-epoch probe made the
+    outcome predictable."""
 
     def __init__(self, device: torch.device, cus_per_xcd_fwd: int):
         from .. import _lib as L
