@@ -790,7 +790,7 @@ def main():
     c5 = {}
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        n_steps_train = 72        # twelve look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
+        n_steps_train = 36        # six look-ahead groups at 8 images x 32 masks
         rate, f_step, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision)
         launches_eager = LAST_TRAIN_LAUNCHES[0]
         rate_graph, two_stream = None, None
