@@ -183,10 +183,33 @@ def ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_BACKGROUND = {}     # device index -> the device's background stream, created AND used at this library's first launch on the device
+
+
+def background_stream(index: int):
+    """The device's second stream for work that runs BESIDE the caller's (the two-stream training epoch: scripts/common.TrainPartition):
+    a torch high-priority stream that is created and given one trivial kernel at the library's FIRST launch on the device, and kept.
+    Measured (profiles/HISTORY.md §10): a HIP stream takes its hardware queue at its first submission, and a second stream that does
+    so after the process has captured hipGraphs / made its other streams runs its kernels behind the caller's instead of beside them
+    (the same two-stream schedule: 420 instead of 635 images/s, against 550 on one stream); one that did so first never does."""
+    import torch
+    st = _BACKGROUND.get(index)
+    if st is None:
+        dev = torch.device("cuda", index)
+        st = _BACKGROUND[index] = torch.cuda.Stream(dev, priority=-1)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev).add_(1)
+        st.synchronize()
+    return st
+
+
 def stream() -> int:
     """raw hipStream_t of torch's current stream on the current device (the C accessors: this runs once per kernel launch)."""
     import torch
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    d = torch._C._cuda_getDevice()
+    if d not in _BACKGROUND:
+        background_stream(d)
+    return torch._C._cuda_getCurrentRawStream(d)
 
 
 class _NoGuard:

@@ -111,42 +111,45 @@ def shard(xs, zs=None):
 
 # ---------------------------------------------------------------------------------------------- two-stream training epoch (opt-in)
 class TrainPartition:
-    """The second stream of an explainer training epoch (opt-in: ``AG_TRAIN_PARTITION``).  The reference runs the K-mask target forward
-    and the explainer's own step back to back (scripts/train_explainer.py:153-198); the surrogate is frozen, so the targets of group
-    g + 1 depend on nothing the steps of group g do, and the two want different things from the chip: the target forward is the hot path
-    (feed-bound: it loses 6-13 % on 7/8 - 3/4 of the CUs, throughput ~ CUs^0.43), the step is 400 launches on 1.5 k token rows that fill
-    a quarter of the CUs at best.  ``fwd`` is an ordinary (non-blocking, high-priority) stream on which the persistent large-M GEMM is
-    told to launch only ``n_fwd`` workgroups (ag_set_stream_cus: one per CU, an equal number on every XCD and shader engine), so the
-    other CUs are free for the step's kernels on the caller's stream at any moment.  No CU masks: hipExtStreamCreateWithCUMask streams
-    are blocking streams — every null-stream operation of the process becomes a barrier across them — and buy less (+14 % against +18 %).
-
-    Why opt-in (profiles/HISTORY.md §10): in a fresh process with GPU_MAX_HW_QUEUES=8 the gain is reproducible (vanilla ViT-base 8 images x
-    32 masks: 553 -> 638 images/s); inside bench.py, after its batch sweep and with HIP's default 4 hardware queues, the same schedule runs
-    10-50 % SLOWER than one stream.  What the process did before decides, through HIP's multiplexing of streams onto hardware queues,
-    whether the two streams run beside or behind each other; neither stream priorities nor more queues nor an in-epoch probe made the
-    outcome predictable."""
+    """The second stream of an explainer training epoch.  The reference runs the K-mask target forward and the explainer's own step
+    back to back (scripts/train_explainer.py:153-198); the surrogate is frozen, so the targets of group g + 1 depend on nothing the
+    steps of group g do, and the two want different things from the chip: the target forward is the hot path (feed-bound: it loses
+    6-13 % on 7/8 - 3/4 of the CUs, throughput ~ CUs^0.43), the step is 400 launches on 1.5 k token rows that fill a quarter of the CUs
+    at best.  ``fwd`` is the device's background stream (``_lib.background_stream``: an ordinary non-blocking stream that took its
+    hardware queue at the library's first launch — what makes the two streams run beside, not behind, each other) on which the
+    persistent large-M GEMM is told to launch only ``n_fwd`` workgroups (ag_set_stream_cus: one per CU, an equal number on every XCD
+    and shader engine), so the other CUs are free for the step's kernels on the caller's stream at any moment.  No CU masks:
+    hipExtStreamCreateWithCUMask streams are blocking streams — every null-stream operation of the process becomes a barrier across
+    them — and buy less (+14 % against +18 %; profiles/HISTORY.md §10)."""
 
     def __init__(self, device: torch.device, cus_per_xcd_fwd: int):
         from .. import _lib as L
-        self.fwd = torch.cuda.Stream(device, priority=-1)
+        self.device = device
+        self.fwd = L.background_stream(device.index if device.index is not None else torch.cuda.current_device())
         self.n_fwd = 8 * int(cus_per_xcd_fwd)
-        with torch.cuda.device(device):
+
+    def arm(self) -> "TrainPartition":
+        """(the background stream is shared by every partition of the device: tell the library THIS one's CU count)"""
+        from .. import _lib as L
+        with torch.cuda.device(self.device):
             L.check(L.lib().ag_set_stream_cus(self.fwd.cuda_stream, self.n_fwd))
+        return self
 
 
 _PARTITIONS = {}
 
 
 def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartition]:
-    """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: unset / "0" = off (default); an integer = CUs per XCD the target
-    forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto": 24 of 32 for a ViT explainer whose backbone
-    trains, 28 for a frozen backbone or a BERT explainer.  One rank only, never under the hipGraph step."""
+    """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: "0" = off (targets and steps back to back on the caller's stream); an
+    integer = CUs per XCD the target forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32
+    for a ViT explainer whose backbone trains, 28 for a frozen backbone or a BERT explainer.  One rank only (N > 1: RCCL's kernels want
+    CUs at moments of their own; not measured), never under the hipGraph step."""
     from .. import distributed, training16
-    mode = os.environ.get("AG_TRAIN_PARTITION", "0")
+    mode = os.environ.get("AG_TRAIN_PARTITION", "auto")
     if mode in ("0", "") or device.type != "cuda" or distributed.world()[1] > 1 or training16.GRAPH_STEP:
         return None
     if mode == "auto":
-        # measured in a fresh process with 8 hardware queues (tools/train_step_bench.py, 36 steps of 8 images x 32 masks, images/s off -> on):
+        # measured (tools/train_step_bench.py and inside bench.py, 36-72 steps of 8 images x 32 masks, images/s off -> on):
         # vanilla ViT-base 553 -> 638 at 24 (601 at 28, 608 at 20); froyo ViT-base 726 -> 790 at 28 (748 at 24, 688 at 20); duo BERT-base 920 -> 950-1 015 at 28
         vit = getattr(m_explainer, "vit", None)
         c = 24 if (vit is not None and any(q.requires_grad for q in vit.parameters())) else 28
@@ -158,7 +161,7 @@ def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartitio
     key = (str(device), c)
     if key not in _PARTITIONS:
         _PARTITIONS[key] = TrainPartition(device, c)
-    return _PARTITIONS[key]
+    return _PARTITIONS[key].arm()
 
 
 def _cuda_tensors(obj):

@@ -383,30 +383,6 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
-def two_stream_child(tb, steps):
-    """The opt-in two-stream training epoch (scripts/common.TrainPartition: the K-mask target forward of the NEXT group of batches on a second
-    stream, its persistent GEMM confined to 24-28 of every XCD's 32 CUs, beside this group's steps) measured where it is reproducible: a
-    FRESH process with GPU_MAX_HW_QUEUES=8 (tools/train_step_bench.py; which hardware queue a stream lands on depends on the streams the
-    process created before, and this process has created dozens).  -> {workload: images/s, fraction of peak} or an error note."""
-    env = {k_: v_ for k_, v_ in os.environ.items()
-           if not (k_.startswith("TORCHELASTIC_") or k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))}
-    env.update(GPU_MAX_HW_QUEUES="8", AG_TRAIN_PARTITION="auto", STEPS=str(steps), TB=str(tb))
-    out = {"what": "AG_TRAIN_PARTITION=auto GPU_MAX_HW_QUEUES=8 python tools/train_step_bench.py (fresh process; same epoch body, masks, steps and "
-                   "parameters as `value`, bit for bit: tests/test_gpu_scripts.py; one rank only)"}
-    try:
-        r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_bench.py"), "vit_base", "froyo_vit_base"],
-                            capture_output=True, text=True, timeout=420, cwd=ROOT, env=env)
-        for ln in r_.stdout.splitlines():
-            if ln.startswith("{"):
-                d_ = json.loads(ln)
-                out[d_["workload"]] = {"value": d_["images_per_s"], "unit": "images/s", "frac": d_["frac"], "ms_per_step": d_["ms_per_step"]}
-        if len(out) == 1:
-            out["error"] = (r_.stderr or r_.stdout)[-300:]
-    except Exception as exc:
-        out["error"] = repr(exc)[:200]
-    return out
-
-
 def grad_exchange_overlap(job, dev, tb, steps=6):
     """Exposed time of the gradient exchange of one explainer training step at ONE rank: every gradient of the vanilla explainer
     (ViT-base: 104.7 M fp32 = 419 MB) goes through distributed.GradBucketReducer — 64 MiB buckets, each an asynchronous RCCL all-reduce —
@@ -790,19 +766,23 @@ def main():
     c5 = {}
     if args.train_batch > 0:
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-        n_steps_train = 36        # six look-ahead groups at 8 images x 32 masks
+        n_steps_train = 72        # twelve look-ahead groups at 8 images x 32 masks (an epoch of the reference's datasets is hundreds of groups)
         rate, f_step, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision)
         launches_eager = LAST_TRAIN_LAUNCHES[0]
-        rate_graph, two_stream = None, None
+        rate_graph, rate_one = None, None
         if world == 1 and args.precision == "bf16" and not args.no_secondary:
             rate_graph, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, graph=True)
-            two_stream = two_stream_child(args.train_batch, n_steps_train)
+            rate_one, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, partition="0")
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
                        "steps": n_steps_train, "library_launches_per_step": round(launches_eager, 1),
                        "launch": "eager (the epoch body keeps the GPU busy with the K-mask target forward of the next batches while the host "
                                  "issues the step)",
-                       "two_stream_opt_in": two_stream,
+                       "one_stream_value": None if rate_one is None else round(rate_one, 1),
+                       "schedule": "one rank: the K-mask target forward of the NEXT group of batches on the device's background stream, its persistent GEMM "
+                                   "confined to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition; "
+                                   "same masks, steps and parameters bit for bit: tests/test_gpu_scripts.py); one_stream_value = AG_TRAIN_PARTITION=0: the two "
+                                   "back to back on one stream, which is also what N > 1 ranks run",
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
                        "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
                                        "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
@@ -821,8 +801,9 @@ def main():
             for wl in ("duo_bert_base", "froyo_vit_base"):
                 j5 = Job(wl, dev, rank, world, args.train_batch, 0, args.precision)
                 r5, f5, frozen = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision)
+                r5_one = train_step_rate(j5, dist, n_steps_train, args.train_batch, args.precision, partition="0")[0] if world == 1 else None
                 tf5 = r5 / world / args.train_batch * f5 / 1e12
-                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "unit": "images/s", "masks_per_image": j5.K,
+                c5[wl] = {"workload": WORKLOAD_LABEL[wl], "value": round(r5, 1), "one_stream_value": None if r5_one is None else round(r5_one, 1), "unit": "images/s", "masks_per_image": j5.K,
                           "images_per_gpu_per_step": args.train_batch, "backbone_frozen": frozen,
                           "library_launches_per_step": round(LAST_TRAIN_LAUNCHES[0], 1),
                           "roofline": {"gflop_per_step": round(f5 / 1e9, 1), "achieved": round(tf5, 1), "peak": peak, "unit": "TFLOP/s",
@@ -833,7 +814,7 @@ def main():
             for wl in (() if lean else ("duo_bert_base", "froyo_vit_base")):
                 for tb_ in (2, 4):
                     j5 = Job(wl, dev, rank, world, tb_, 0, args.precision)
-                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision)
+                    r5, f5, frozen = train_step_rate(j5, dist, 12, tb_, args.precision, partition="0")   # (what one of N > 1 ranks runs)
                     l5 = LAST_TRAIN_LAUNCHES[0]
                     r5g = train_step_rate(j5, dist, 12, tb_, args.precision, graph=True)[0] if world == 1 else None
                     tf5 = r5 / world / tb_ * f5 / 1e12
