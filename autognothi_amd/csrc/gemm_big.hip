@@ -1473,7 +1473,19 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         if (sc > 0 && sc < n_cu) n_cu = sc >= 8 ? (sc & ~7) : sc;
     }
     const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT) * ((EPI == AG_EPI_BIAS_F32 && VAR == 0) ? a.nbatch : 1);
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(tiles < n_cu ? tiles : n_cu), dim3(NT), STREAM_LDS_BYTES, s, a);
+    // resident workgroups: every CU — unless the same number of rounds is done by fewer: 297 tiles are two rounds on 256 CUs (the second with 41
+    // busy) and two rounds on 152 (both full), and a tile is faster the fewer CUs share an XCD's L2 feed (the forward confined to 224 / 192 CUs:
+    // 7 % / 15 % less time per tile, tools/gemm_cus_sweep.py).  Large launches (14+ rounds) come out at every CU.
+    int grid = tiles < n_cu ? tiles : n_cu;
+    if (tiles > n_cu) {
+        static AgKnob k_bal("AG_GEMM_BALANCE");            // 0: always every CU (A/B)
+        if ((int)k_bal.get(1) != 0) {
+            const int rounds = ceil_div(tiles, n_cu);
+            grid = (ceil_div(tiles, rounds) + 7) & ~7;
+            if (grid > n_cu) grid = n_cu;
+        }
+    }
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(grid), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
