@@ -51,6 +51,7 @@ SIGNATURES = {
     "ag_pack_mask": (i32, [vp, i32, i32, vp, vp]),
     "ag_perturbed_masks": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "ag_cast_f32": (i32, [vp, vp, i64, i32, vp]),
+    "ag_pack_folded_linear": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp]),
     "ag_layernorm": (i32, [vp, i32, i64, i32, i32, vp, vp, f32, vp, vp, i32, vp, vp]),
     "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
     "ag_gemm_ex": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "ag_colsum_bf16_scratch_floats": (sz, [i32, i32]),
     "ag_colsum_bf16": (i32, [vp, i32, i32, i64, vp, i32, vp, vp]),
     "ag_cast_f32_many": (i32, [vp, vp, vp, vp, i32, vp]),
+    "ag_pack_f32_many": (i32, [vp, vp, vp, vp, i32, f32, vp]),
     "ag_set_dropout_salt": (i32, [u32, vp]),
     "ag_pad_cols_f32": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, vp]),
     "ag_masked_attention_train_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
@@ -71,6 +73,9 @@ SIGNATURES = {
     "ag_gemm_resid_ln_supported": (i32, [i32, i32, i32, i64, i64, i64]),
     "ag_gemm_resid_split_scratch_bytes": (C.c_size_t, [i32, i32, i32]),
     "ag_gemm_resid_split": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, C.c_size_t, vp]),
+    "ag_gemm_ws_scratch_bytes": (C.c_size_t, [i32, i32, i32, i32]),
+    "ag_gemm_ws": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, f32, vp, i32, vp, vp, i32, i32,
+                         vp, C.c_size_t, vp]),
     "ag_side_mlp_supported": (i32, [i32, i32, i32]),
     "ag_side_mlp": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp, i64, vp, vp]),
     "ag_side_linear_supported": (i32, [i32, i32, i32, i32]),
@@ -108,6 +113,7 @@ SIGNATURES = {
     "ag_masked_attention_bwd_mixed": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u32, vp]),
     "ag_mc_shapley_reduce": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "ag_probe_mfma": (i32, [i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
+    "ag_probe_spin": (i32, [i32, vp]),
     "ag_probe_dma": (i32, [i32, i32, i32, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_probe_store": (i32, [i32, i32, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_launch_count": (i64, []),
@@ -203,11 +209,29 @@ def background_stream(index: int):
     return st
 
 
+def streams_overlap(a, b, microseconds: int = 150) -> bool:
+    """Do torch streams ``a`` and ``b`` (same device) run their kernels BESIDE each other?  One idle wave of ``microseconds`` on each,
+    started together: one kernel's wall time = beside, two = behind (HIP multiplexes a process's streams onto a few hardware queues, and
+    two streams on one queue serialise: profiles/HISTORY.md §10).  A yes / no observable, ~0.5 ms, synchronises both streams."""
+    import time
+    import torch
+    a.synchronize(); b.synchronize()
+    best = 1e9
+    with torch.cuda.device(a.device):
+        for _ in range(3):
+            t0 = time.perf_counter()
+            check(lib().ag_probe_spin(microseconds, a.cuda_stream))
+            check(lib().ag_probe_spin(microseconds, b.cuda_stream))
+            a.synchronize(); b.synchronize()
+            best = min(best, (time.perf_counter() - t0) * 1e6)
+    return best < 1.6 * microseconds
+
+
 def stream() -> int:
     """raw hipStream_t of torch's current stream on the current device (the C accessors: this runs once per kernel launch)."""
     import torch
     d = torch._C._cuda_getDevice()
-    if d not in _BACKGROUND:
+    if d not in _BACKGROUND and not torch.cuda.is_current_stream_capturing():   # (never inside a capture: stream creation + synchronize)
         background_stream(d)
     return torch._C._cuda_getCurrentRawStream(d)
 

@@ -229,3 +229,32 @@ bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                 const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue,
                 const float* d_ln_stats, const float* d_ln_colsum, float ln_eps, float* d_stats_out, const int* d_rows, hipStream_t s);
+// the plan of ag_gemm_resid_split for a shape on the current device (false: the shape does not split): rows [0, m1) as full rounds of
+// the persistent kernel, rows [m1, m1 + m2) as `splits` contraction ranges side by side
+bool ag_resid_split_plan(int M, int N, int K, int* m1, int* m2, int* splits);
+int ag_device_cus();   // CUs of the current device, rounded down to a multiple of the 8 XCDs
+
+// gemm_tn.hip — the route of one masked-forward GEMM (ag_gemm_ws; csrc/encoder.cpp plans whole layers with it).
+//   AG_WS_GEMM       ag_gemm as it is (the persistent 256^2 kernel when the shape fills it, else the 128 / 64-tile kernel)
+//   AG_WS_BIG_SPLIT  ag_gemm_resid_split (bias + residual, identity residual rows)
+//   AG_WS_EX         128^2 units, one per workgroup, epilogue in the GEMM (bias [+ LayerNorm fold] [+ GELU], or bias + residual
+//                    [+ row statistics over 128-column slabs])
+//   AG_WS_EX_SLABS   128^2 units x `splits` contraction ranges -> fp32 slabs in the scratch + one row kernel (bias + residual
+//                    [+ row statistics over 256-column slabs])
+enum { AG_WS_GEMM = 0, AG_WS_BIG_SPLIT = 1, AG_WS_EX = 2, AG_WS_EX_SLABS = 3 };
+struct AgWsPlan {
+    int route, splits;
+    int stats_out_cols;     // columns per slab of the row statistics this route writes (256 / 128; 0: none asked for)
+    size_t scratch_bytes;   // of d_scratch (fp32 slabs / partial tiles)
+    double cost_us;         // the planner's estimate
+    bool valid;
+};
+// fold_in: the call reads d_ln_stats (slabs of `stats_in_cols` columns); stats_out: it writes d_stats_out, and `out_cols_ok` says which
+// slab widths its consumer can read (bit 0: 256, bit 1: 128); route < 0: the cheapest valid route, else that route (valid = false when
+// it cannot serve the call)
+AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype, bool dyn_rows, bool fold_in,
+                    int stats_in_cols, bool stats_out, int out_cols_ok, int resid_share, int route = -1, int splits = 0);
+int ag_gemm_ws_run(const AgWsPlan& plan, const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                   const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue, int dtype,
+                   const float* d_ln_stats, int stats_in_cols, const float* d_ln_colsum, float ln_eps, float* d_stats_out,
+                   const int* d_rows, void* d_scratch, size_t scratch_bytes, hipStream_t s);

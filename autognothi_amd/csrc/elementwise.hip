@@ -388,6 +388,40 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 
 }  // namespace
 
+// Linear(LayerNorm(x)) folded for the GEMM epilogue (PackedFoldedLinear, engine.py): one wave per output row n:
+//   w'[n,k] = store(w[n,k] * gamma[k]),   b'[n] = b[n] + sum_k w[n,k] * beta[k],   s[n] = sum_k float(w'[n,k])  (of the ROUNDED w')
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int N, int K, T* __restrict__ w_out,
+                                                           float* __restrict__ b_out, float* __restrict__ s_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* wr = w + (long)n * K;
+    float dot = 0.f, sum = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float x = wr[k];
+        dot = fmaf(x, beta[k], dot);
+        const float y = x * gamma[k];
+        Store<T>::store(w_out + (long)n * K + k, y);
+        sum += Store<T>::load(w_out + (long)n * K + k);
+    }
+    dot = wave_sum(dot); sum = wave_sum(sum);
+    if (lane == 0) { b_out[n] = (b ? b[n] : 0.f) + dot; s_out[n] = sum; }
+}
+
+extern "C" int ag_pack_folded_linear(const float* d_w, const float* d_b, const float* d_gamma, const float* d_beta, int N, int K,
+                                     void* d_w_out, int dtype, float* d_b_out, float* d_s_out, void* stream) {
+    AG_REQUIRE(d_w && d_gamma && d_beta && d_w_out && d_b_out && d_s_out && N > 0 && K > 0, "ag_pack_folded_linear: bad arguments");
+    AG_REQUIRE(dtype == AG_BF16 || dtype == AG_F32, "ag_pack_folded_linear: bad dtype %d", dtype);
+    const dim3 grid(ceil_div(N, 4)), block(256);
+    if (dtype == AG_BF16)
+        hipLaunchKernelGGL(fold_ln_pack_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, d_w, d_b, d_gamma, d_beta, N, K, (bf16_t*)d_w_out, d_b_out, d_s_out);
+    else
+        hipLaunchKernelGGL(fold_ln_pack_kernel<float>, grid, block, 0, (hipStream_t)stream, d_w, d_b, d_gamma, d_beta, N, K, (float*)d_w_out, d_b_out, d_s_out);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
 extern "C" int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream) {
     AG_REQUIRE(d_src && d_dst && n >= 0, "ag_cast_f32: bad arguments");
     if (n == 0) return AG_OK;

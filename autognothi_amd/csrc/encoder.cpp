@@ -45,12 +45,17 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     char* inter = take(M * d->I * es);
     char* hx = take(M * d->H * es);
     char* ha = d->kind == AG_MASK_BERT_ADD ? take(M * d->H * es) : nullptr;
-    const size_t S = ((size_t)d->H + 255) / 256;
+    const size_t S = ((size_t)d->H + 127) / 128;   // (slabs of 256 columns, or of 128: the 128-tile producers of ag_gemm_ws)
     char* st1 = take(S * M * 2 * sizeof(float));
     char* st2 = take(S * M * 2 * sizeof(float));
     char* idx = take((M + (size_t)R + 1) * sizeof(int));   // token pruning: cu_seqlens [R+1] + packed-row sources [M]
     // under-filled fc2 (the reference's own batch sizes: one to four inputs x K masks): the tail round's rows as contraction ranges side by side
-    const size_t split_bytes = (d->dtype == AG_BF16 && M <= 0x7FFFFFFF) ? ag_gemm_resid_split_scratch_bytes((int)M, d->H, d->I) : 0;
+    // ... and the fp32 slabs of the planned 128-tile routes (ag_gemm_ws): the widest of both residual Linears
+    size_t split_bytes = 0;
+    if (d->dtype == AG_BF16 && M <= 0x7FFFFFFF) {
+        const size_t b1 = ag_gemm_ws_scratch_bytes((int)M, d->H, d->I, AG_EPI_BIAS_RESID), b2 = ag_gemm_ws_scratch_bytes((int)M, d->H, d->H, AG_EPI_BIAS_RESID);
+        split_bytes = b1 > b2 ? b1 : b2;
+    }
     char* split = split_bytes ? take(split_bytes) : nullptr;
     if (ws) { ws->split = (float*)split; ws->split_bytes = split_bytes; }
     if (ws) ws->idx = (int*)idx;
@@ -93,12 +98,44 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
     const bool side_lin_o = !side_off && ag_side_linear_supported(H, H, 1, dt);
     if (chain_stats) ws.st1 = chain_stats;
     if (stats_written) *stats_written = 0;
-
     const char* h_in = (const char*)d_h0;  // residual stream entering the layer (storage dtype)
     int in_share = share;                  // how many rows share one h_in sequence
-    bool st1_ready = chain_stats && stats_in_ready && share == 1;   // ws.st1 holds the row statistics of h_in (written by the previous fc2)
+    // ws.st1 holds the row statistics of h_in (written by the previous fc2 / the previous call): their slab width (256 / 128 columns;
+    // 0: not there)
+    int fmt1 = (chain_stats && stats_in_ready && share == 1) ? 256 : 0;
     hipStream_t hs = (hipStream_t)stream;
     const int* const dyn = nullptr;        // every row count of this entry is exact on the host
+    const bool bf = dt == AG_BF16;
+    // Every Linear is PLANNED (ag_ws_plan, gemm_tn.hip): the persistent 256^2 kernel where the launch fills it, 128^2 units (epilogue in the
+    // GEMM, or split-K slabs + a row kernel) where it would leave most of a round idle — the reference's own batch sizes and the 8-GPU
+    // shards.  A producer of row statistics and the folded consumer that reads them are planned together: the 128-tile producer writes
+    // 128-column slabs, which only the 128-tile consumer reads.
+    auto plan_w = [&](int M_, int N_, int K_, int64_t lda_, int64_t ldc_, int epi, bool fold_in, int in_cols) {
+        return ag_ws_plan(M_, N_, K_, lda_, ldc_, 0, epi, dt, false, fold_in, in_cols, false, 0, 1);
+    };
+    auto plan_r = [&](int M_, int N_, int K_, int64_t lda_, int64_t ldc_, int64_t ldr_, bool stats_out, int cols_ok, int share_) {
+        return ag_ws_plan(M_, N_, K_, lda_, ldc_, ldr_, AG_EPI_BIAS_RESID, dt, false, false, 0, stats_out, cols_ok, share_);
+    };
+    auto run = [&](const AgWsPlan& pl, const void* A, int64_t lda_, const void* W, const float* b, void* C, int64_t ldc_, const void* Rr,
+                   int64_t ldr_, int tq, int sh, int M_, int N_, int K_, int epi, const float* st_in, int in_cols, const float* colsum,
+                   float* st_out) {
+        return ag_gemm_ws_run(pl, A, lda_, W, b, C, ldc_, Rr, ldr_, tq, sh, M_, N_, K_, epi, dt, st_in, in_cols, colsum, d->ln_eps, st_out,
+                              nullptr, ws.split, ws.split_bytes, hs);
+    };
+    // a statistics producer (bias + residual) and its folded consumer (bias / bias + GELU), planned together over the slab widths the
+    // pair can agree on; false: no valid pair (the LayerNorm stays a kernel)
+    auto plan_pair = [&](int Mp, int Np, int Kp, int64_t ldap, int64_t ldcp, int64_t ldrp, int sharep, int Mc, int Nc, int Kc_, int64_t ldac,
+                         int64_t ldcc, int epic, bool only256, AgWsPlan* prod, AgWsPlan* cons, int* cols) {
+        double best = 1e30;
+        for (int c = 256; c >= 128; c -= 128) {
+            if (c == 128 && only256) continue;
+            const AgWsPlan a = plan_r(Mp, Np, Kp, ldap, ldcp, ldrp, true, c == 256 ? 1 : 2, sharep);
+            const AgWsPlan b = plan_w(Mc, Nc, Kc_, ldac, ldcc, epic, true, c);
+            if (a.valid && b.valid && a.cost_us + b.cost_us < best) { best = a.cost_us + b.cost_us; *prod = a; *cons = b; *cols = c; }
+        }
+        return best < 1e30;
+    };
+    static AgKnob k_trim("AG_LAST_Q_TRIM");     // 0: the last layer projects queries for every token (A/B, parity tests)
     for (int l = 0; l < d->n_layers; ++l) {
         const ag_layer_weights& w = d->layers[l];
         const bool last_cls = cls_only_last && (l == d->n_layers - 1);
@@ -106,37 +143,31 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         const int Mo = last_cls ? R : M;     // rows processed after attention: all tokens, or only token 0 of each row
         const int Tq = last_cls ? 1 : T;
         const int64_t ld_tok = last_cls ? (int64_t)T * H : H;  // stride between processed rows inside [R,T,H] buffers
-        // LayerNorm folding (ViT, bf16, large GEMMs): the LN kernels disappear; row statistics come from the
-        // producing GEMM's epilogue (or ag_row_stats_bf16 for the embeddings) and are applied in the consumer's.
-        const bool fold1 = vit && w.ln1_g && w.w_qkv_ln && ag_gemm_supports_ln_fold(Min, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt);
-        const bool fold2 = vit && w.w_fc1_ln && ag_gemm_supports_ln_fold(Mo, I, H, H, I, 0, AG_EPI_BIAS_GELU, dt) &&
-                           ag_gemm_supports_ln_fold(Mo, H, H, ld_tok, H, ld_tok, AG_EPI_BIAS_RESID, dt);
-        // will the NEXT layer fold its LN1?  then this layer's fc2 accumulates the statistics of what it writes
-        bool next_fold1 = false;
-        const bool chain_out = chain_stats && want_stats_out && l + 1 == d->n_layers;   // the consumer is the next CALL (same shape)
-        if (vit && (l + 1 < d->n_layers || chain_out) && !last_cls) {
-            const ag_layer_weights& wn = chain_out ? d->layers[l] : d->layers[l + 1];
-            next_fold1 = wn.ln1_g && wn.w_qkv_ln && ag_gemm_supports_ln_fold(M, 3 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt) &&
-                         ag_gemm_supports_ln_fold(Mo, H, I, I, ld_tok, H, AG_EPI_BIAS_RESID, dt);
-        }
-        // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
-        static AgKnob k_trim("AG_LAST_Q_TRIM");     // 0: the last layer projects queries for every token (A/B, parity tests)
         const bool trim_off = (int)k_trim.get(1) == 0;
-        if (fold1 && last_cls && in_share == 1 && !trim_off && w.ln1_g &&
-            ag_gemm_supports_ln_fold(Min, 2 * H, H, H, 3 * H, 0, AG_EPI_BIAS, dt)) {
+        const bool chain_out = chain_stats && want_stats_out && l + 1 == d->n_layers;   // the consumer is the next CALL (same shape)
+        // LayerNorm folding (ViT, bf16): the LN kernels disappear; row statistics come from the producing GEMM's epilogue (or
+        // ag_row_stats_bf16 for the embeddings) and are applied in the consumer's.
+        // -- attention input: ViT LN1(h_in) (pre-LN; Identity for explainer_attn.0) / BERT h_in itself --
+        const int cols1 = fmt1 ? fmt1 : 256;   // (no statistics yet: ag_row_stats_bf16 writes 256-column slabs)
+        AgWsPlan pq{}, pq_trim{};
+        const bool can_fold1 = vit && bf && w.ln1_g && w.w_qkv_ln && !side_qkv;
+        if (can_fold1) pq = plan_w(Min, 3 * H, H, H, 3 * H, AG_EPI_BIAS, true, cols1);
+        const bool fold1 = can_fold1 && pq.valid;
+        if (fold1 && last_cls && in_share == 1 && !trim_off) pq_trim = plan_w(Min, 2 * H, H, H, 3 * H, AG_EPI_BIAS, true, cols1);
+        if (fold1 && pq_trim.valid) {
             // the last layer's attention reads the CLS query only (cls_only_last): keys and values of every token (the [H, 3H) rows of the
             // fused projection), queries of the R CLS rows — a third of this layer's QKV product is never computed.  The CLS rows are
             // normalised by the LayerNorm kernel (strided: one row per sequence) and projected with the unfolded query rows.
-            if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
-            TRY(ag_gemm(h_in, H, (const char*)w.w_qkv_ln + (size_t)H * H * es, w.b_qkv_ln + H, ws.qkv + (size_t)H * es, 3 * H, nullptr, 0, 0, 0,
-                        Min, 2 * H, H, AG_EPI_BIAS, dt, ws.st1, w.s_qkv_ln + H, d->ln_eps, nullptr, dyn, stream));
+            if (!fmt1) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
+            TRY(run(pq_trim, h_in, H, (const char*)w.w_qkv_ln + (size_t)H * H * es, w.b_qkv_ln + H, ws.qkv + (size_t)H * es, 3 * H, nullptr, 0, 0, 0,
+                    Min, 2 * H, H, AG_EPI_BIAS, ws.st1, cols1, w.s_qkv_ln + H, nullptr));
             TRY(ag_layernorm(h_in, dt, (int64_t)T * H, R, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
             TRY(ag_gemm(ws.xs, H, w.w_qkv, w.b_qkv, ws.qkv, (int64_t)T * 3 * H, nullptr, 0, 0, 0, R, H, H, AG_EPI_BIAS, dt,
                         nullptr, nullptr, 0.f, nullptr, dyn, stream));
         } else if (fold1) {
-            if (!st1_ready) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
-            TRY(ag_gemm(h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
-                        ws.st1, w.s_qkv_ln, d->ln_eps, nullptr, dyn, stream));
+            if (!fmt1) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
+            TRY(run(pq, h_in, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, ws.st1, cols1, w.s_qkv_ln,
+                    nullptr));
         } else if (side_qkv) {
             // narrow layer (LTT ladder): (LN1 +) QKV in one register-resident kernel
             TRY(ag_side_linear(h_in, H, Min, H, 3 * H, w.w_qkv, w.b_qkv, vit ? w.ln1_g : nullptr, vit ? w.ln1_b : nullptr,
@@ -147,24 +178,30 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                 TRY(ag_layernorm(h_in, dt, H, Min, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
                 att_in = ws.xs;
             }
-            TRY(ag_gemm(att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min, 3 * H, H, AG_EPI_BIAS, dt,
-                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
+            TRY(run(plan_w(Min, 3 * H, H, H, 3 * H, AG_EPI_BIAS, false, 0), att_in, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, Min,
+                    3 * H, H, AG_EPI_BIAS, nullptr, 0, nullptr, nullptr));
         }
-        st1_ready = false;
+        fmt1 = 0;
         TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
         // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
         // narrow layer: out-proj + residual (+ BERT's attention-output LayerNorm) fused; needs row-aligned residual rows
         const bool side_o = side_lin_o && in_share == 1 && !last_cls;
         bool ln1_done = false;
+        // ViT: LN2 folded into fc1 when the out-projection can hand on the statistics of what it writes
+        AgWsPlan po{}, pf1{};
+        int cols2 = 0;
+        const bool fold2 = vit && bf && w.w_fc1_ln && !side_mlp && !side_o &&
+                           plan_pair(Mo, H, H, ld_tok, H, ld_tok, in_share, Mo, I, H, H, I, AG_EPI_BIAS_GELU, false, &po, &pf1, &cols2);
         if (side_o) {
             const bool post = !vit && w.ln1_g;
             TRY(ag_side_linear(ws.ctx, H, Mo, H, H, w.w_o, w.b_o, nullptr, nullptr, h_in, H, post ? w.ln1_g : nullptr,
                                post ? w.ln1_b : nullptr, d->ln_eps, post ? ws.ha : ws.hx, H, dyn, stream));
             ln1_done = post;
         } else {
-        TRY(ag_gemm(ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, dt,
-                    nullptr, nullptr, 0.f, fold2 ? ws.st2 : nullptr, dyn, stream));
+            if (!fold2) po = plan_r(Mo, H, H, ld_tok, H, ld_tok, false, 0, in_share);
+            TRY(run(po, ws.ctx, ld_tok, w.w_o, w.b_o, ws.hx, H, h_in, ld_tok, Tq, in_share, Mo, H, H, AG_EPI_BIAS_RESID, nullptr, 0, nullptr,
+                    fold2 ? ws.st2 : nullptr));
         }
         if (vit) {
             if (side_mlp && !fold2) {
@@ -172,23 +209,36 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                 TRY(ag_side_mlp(ws.hx, H, Mo, H, I, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2, w.ln2_g, w.ln2_b, d->ln_eps, 0, d_h, ld_tok, dyn, stream));
             } else {
             if (fold2) {
-                TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                            ws.st2, w.s_fc1_ln, d->ln_eps, nullptr, dyn, stream));
+                TRY(run(pf1, ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, ws.st2, cols2, w.s_fc1_ln,
+                        nullptr));
             } else {
                 TRY(ag_layernorm(ws.hx, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
-                TRY(ag_gemm(ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                            nullptr, nullptr, 0.f, nullptr, dyn, stream));
+                TRY(run(plan_w(Mo, I, H, H, I, AG_EPI_BIAS_GELU, false, 0), ws.xs, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H,
+                        AG_EPI_BIAS_GELU, nullptr, 0, nullptr, nullptr));
             }
-            // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only)
-            if (ws.split && Mo == M) {
-                TRY(ag_gemm_resid_split(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, Mo, H, I, next_fold1 ? ws.st1 : nullptr,
-                                        ws.split, ws.split_bytes, stream));
-            } else
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
-                        nullptr, nullptr, 0.f, next_fold1 ? ws.st1 : nullptr, dyn, stream));
+            // h_out = fc2(inter) + hx -> d_h (strided to token 0 when cls-only); will the NEXT layer fold its LN1?  then this fc2 hands on
+            // the statistics of what it writes, in the slab width that layer's QKV projection reads
+            AgWsPlan p2{}, pq_next{};
+            int cols_next = 0;
+            bool next_fold1 = false;
+            if (bf && (l + 1 < d->n_layers || chain_out) && !last_cls) {
+                const ag_layer_weights& wn = chain_out ? d->layers[l] : d->layers[l + 1];
+                if (wn.ln1_g && wn.w_qkv_ln && !side_qkv) {
+                    // (the last layer of a CLS-only forward projects keys and values only: see above)
+                    const bool next_trim = !chain_out && cls_only_last && l + 2 == d->n_layers && !trim_off;
+                    next_fold1 = plan_pair(Mo, H, I, I, ld_tok, H, 1, M, next_trim ? 2 * H : 3 * H, H, H, 3 * H, AG_EPI_BIAS,
+                                           chain_stats != nullptr, &p2, &pq_next, &cols_next);
+                    if (!next_fold1 && next_trim)
+                        next_fold1 = plan_pair(Mo, H, I, I, ld_tok, H, 1, M, 3 * H, H, H, 3 * H, AG_EPI_BIAS, chain_stats != nullptr, &p2, &pq_next,
+                                               &cols_next);
+                }
             }
-            st1_ready = next_fold1;
+            if (!next_fold1) p2 = plan_r(Mo, H, I, I, ld_tok, H, false, 0, 1);
+            TRY(run(p2, ws.inter, I, w.w_fc2, w.b_fc2, d_h, ld_tok, ws.hx, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, nullptr, 0, nullptr,
+                    next_fold1 ? ws.st1 : nullptr));
+            fmt1 = next_fold1 ? cols_next : 0;
             if (chain_out && stats_written) *stats_written = next_fold1 ? 1 : 0;
+            }
         } else {
             const char* a = ws.hx;  // explainer_attn.0: attention.output.LayerNorm = Identity (models/vanilla_bert.py:107,:550-553)
             if (ln1_done) {
@@ -210,14 +260,11 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                 in_share = 1;
                 continue;
             }
-            TRY(ag_gemm(a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H, AG_EPI_BIAS_GELU, dt,
-                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
+            TRY(run(plan_w(Mo, I, H, H, I, AG_EPI_BIAS_GELU, false, 0), a, H, w.w_fc1, w.b_fc1, ws.inter, I, nullptr, 0, 0, 0, Mo, I, H,
+                    AG_EPI_BIAS_GELU, nullptr, 0, nullptr, nullptr));
             char* pre = (a == ws.hx) ? ws.ha : ws.hx;
-            if (ws.split && Mo == M) {
-                TRY(ag_gemm_resid_split(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, Mo, H, I, nullptr, ws.split, ws.split_bytes, stream));
-            } else
-            TRY(ag_gemm(ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, dt,
-                        nullptr, nullptr, 0.f, nullptr, dyn, stream));
+            TRY(run(plan_r(Mo, H, I, I, H, H, false, 0, 1), ws.inter, I, w.w_fc2, w.b_fc2, pre, H, a, H, 1, 1, Mo, H, I, AG_EPI_BIAS_RESID, nullptr, 0,
+                    nullptr, nullptr));
             if (last_cls) {
                 // LayerNorm the compact [R,H] rows, then scatter them to token 0 of d_h
                 TRY(ag_layernorm(pre, dt, H, Mo, H, w.ln2_g, w.ln2_b, d->ln_eps, ws.ctx, nullptr, dt, dyn, stream));

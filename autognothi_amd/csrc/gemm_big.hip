@@ -295,11 +295,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 const int rr = i * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
                 const int mm = mw0 + (sm - 1) * 16 + rr;
-#ifdef AG_ABL_NOSTORE   // (ablation build, wrong results: the epilogue without its global stores)
-                if (mm < 0) {
-#else
                 if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
-#endif
                     uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (p.nt_store) {
@@ -397,31 +393,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t ldsA_w = lds0 + wave * 2048, ldsW_w = ldsA_w + HALF_OP_BYTES;   // this wave's piece pair inside a slot
     auto refill4 = [&](int jn, int slot) {  // this wave's A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of half-step jn into ring slot `slot`
-#if defined(AG_EXP_PLAIN_LOADS)   // experiment (wrong results): the same four 1 KiB requests as plain loads into (dead) registers
-        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-        u32x4v d0, d1, d2, d3;
-        asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %9\n\tglobal_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %9"
-                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-                     : "v"(offA[0]), "v"(offW[0]), "v"(offA[1]), "v"(offW[1]), "s"(tileA + jn * HROWB), "s"(tileW + jn * HROWB) : "memory");
-#elif defined(AG_EXP_NO_DMA)
-        (void)jn; (void)slot;
-#elif defined(AG_EXP_DWORD_DMA)   // experiment (wrong results): the same four LDS-DMA instructions moving 4 B per lane instead of 16
-        {
-            uint32_t keep;
-            const uint32_t ldsA0 = ldsA_w + slot * SLOT_BYTES, ldsW0 = ldsW_w + slot * SLOT_BYTES;
-            asm volatile("s_mov_b32 %0, m0\n\t"
-                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\t"
-                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %2, %6\n\t"
-                         "s_add_u32 m0, %7, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, %5\n\t"
-                         "s_add_u32 m0, %8, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %4, %6\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(offA[0]), "v"(offW[0]), "v"(offA[1]), "v"(offW[1]), "s"(tileA + jn * HROWB), "s"(tileW + jn * HROWB),
-                           "s"(ldsA0), "s"(ldsW0) : "memory", "scc");
-        }
-#else
         glds16b_s_x4(tileA + jn * HROWB, tileW + jn * HROWB, offA[0], offW[0], offA[1], offW[1],
                      ldsA_w + slot * SLOT_BYTES, ldsW_w + slot * SLOT_BYTES);
-#endif
     };
     // ---- tile constants: requested BEFORE the ring's first fill (so that they are the oldest loads in flight) and parked in the
     // LDS tail once the prologue's counted wait has let them land; the epilogue then needs nothing from memory but the residual
@@ -522,27 +495,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
         const char* sA = smem + slot * SLOT_BYTES;
         const char* sW = sA + HALF_OP_BYTES;
         uint4 fw[4], fx[8];
-#if defined(AG_EXP_DMA_FIRST)     // experiment: the refills requested BEFORE the fragment reads of the phase
-        if (do_refill) refill4(j + 3, (slot + 3) & 3);
-#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) fw[s] = frag_half(sW, wn * 64 + s * 16, lane);
-#if defined(AG_EXP_FEWER_READS)   // experiment (wrong results): 8 instead of 12 fragment reads per wave and half-step
-#pragma unroll
-        for (int s = 0; s < 4; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-#pragma unroll
-        for (int s = 4; s < 8; ++s) fx[s] = fx[s - 4];
-#else
 #pragma unroll
         for (int s = 0; s < 8; ++s) fx[s] = frag_half(sA, wm * 128 + s * 16, lane);
-#endif
-#if defined(AG_EXP_HALF_DMA)      // experiment (wrong results): every other refill skipped
-        if (do_refill && (j & 1)) refill4(j + 3, (slot + 3) & 3);
-        else if (do_refill) { }
-#elif defined(AG_EXP_DMA_IN_MFMA) || defined(AG_EXP_DMA_FIRST)
-#else
         if (do_refill) refill4(j + 3, (slot + 3) & 3);                  // into the slot read one half-step ago
-#endif
         AG_STAMP(2)
         __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my fragments are in registers (the builtin,
         asm volatile("" ::: "memory");                                  // so hipcc does not add its own per-MFMA lgkmcnt waits)
@@ -556,27 +513,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
         // ---- MFMA phase: nothing but the 32 MFMAs (splitting the refills 2/2 across the phases measured slower) ----
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#if defined(AG_EXP_DMA_IN_MFMA)   // experiment: the four LDS-DMA requests issued from inside the MFMA phase (after the 8th MFMA)
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-#pragma unroll
-            for (int sm = 0; sm < 8; ++sm)
-                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
-                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
-            if (sn == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (do_refill) refill4(j + 3, (slot + 3) & 3);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#else
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn)
 #pragma unroll
             for (int sm = 0; sm < 8; ++sm)
                 acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
                                                                       __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
-#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         AG_STAMP(5)
@@ -650,10 +592,6 @@ constexpr int LROWB = 128;                       // bytes of K per row per step 
 constexpr int LOP_BYTES = BT * LROWB;            // 32 KiB per operand per step
 constexpr int LW_BASE = 2 * LOP_BYTES;           // W slots behind the two A slots
 // defaults = what measured best (round 3, tools/exp_variants.sh): L2 prefetch ON, for the A stream only (group 0), two steps ahead
-#if !defined(AG_LINE_NO_PF) && !defined(AG_LINE_PF)
-#define AG_LINE_PF
-#define AG_LINE_PF_A_ONLY
-#endif
 #ifndef AG_LINE_PF_AHEAD
 #define AG_LINE_PF_AHEAD 2
 #endif
@@ -744,13 +682,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int ns = p.K / 64;                          // steps
-#if defined(AG_LINE_HOT)          // experiment (wrong results): every tile stages the SAME panels (always L2 hits): latency vs issue cost
-    const char* tileA = p.A;
-    const char* tileW = p.W;
-#else
     const char* tileA = p.A + (long)m0 * p.lda_b;
     const char* tileW = p.W + (long)n0 * p.ldw_b;
-#endif
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // ---- this wave's pieces: group 0 (waves 0-3) stages A, group 1 (waves 4-7) stages W; wave g of a group owns rows
     // [64 g, 64 g + 64) of its operand = 8 pieces of 8 rows.  Piece q = 2 k + par: rows 64 g + 16 k + 8 par + (lane >> 3); its
@@ -843,13 +776,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         }
     }
     // ---- prologue: L2 prefetch of step 2, then steps 0 and 1 into slots 0 and 1
-#if defined(AG_LINE_PF)
-#if defined(AG_LINE_PF_A_ONLY)
     if (stA) prefetch(2);
-#else
-    prefetch(2);
-#endif
-#endif
     refill4(0, 0, 0); refill4(0, 0, 1);
     refill4(1, 1, 0); refill4(1, 1, 1);                 // (ns >= 2)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -893,27 +820,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         asm volatile("s_barrier" ::: "memory");                        // "a"
         // requests first (their address temporaries die before the fragments arrive): group 0 four pieces in each half, group 1 all
         // eight in the lower half
-#if !defined(AG_LINE_NO_REFILL) && !defined(AG_LINE_ISSUE_IN_MFMA)
         if (refill) {
-#if defined(AG_LINE_SYMMETRIC)      // experiment: both groups request four pieces in each half
-            refill4(s + 1, slot ^ 1, kh);
-#else
-#if defined(AG_LINE_G0_EARLY)       // experiment: group 0 (the A stream: HBM latency) requests all eight pieces in its read-lo phase too
-            if (kh == 0) { refill4(s + 1, slot ^ 1, 0); refill4(s + 1, slot ^ 1, 1); }
-#else
             if (grp == 0) refill4(s + 1, slot ^ 1, kh);
             else if (kh == 0) { refill4(s + 1, slot ^ 1, 0); refill4(s + 1, slot ^ 1, 1); }
-#endif
-#endif
         }
-#endif
-#if defined(AG_LINE_PF)           // (L2 prefetch; for both operands it cost more than it gave: A only by default)
-#if defined(AG_LINE_PF_A_ONLY)
         if (kh == 1 && stA && !last) prefetch(s + PF_AHEAD);
-#else
-        if (kh == 1 && !last) prefetch(s + PF_AHEAD);
-#endif
-#endif
         uint32_t x64 = kh ? 64u : 0u;
         asm volatile("" : "+s"(x64));                                  // (made here, two temporaries: not hoisted into two more registers)
         typedef __attribute__((address_space(3))) const char* lds_cptr;
@@ -930,51 +841,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
         asm volatile("" ::: "memory");
         // group 1 meets the barrier that opens step s+1 at the end of THIS read phase (upper half): its pieces of step s+1
         // (requested two phases ago) must have landed; the prefetch just issued stays in flight
-#if defined(AG_LINE_PF) && !defined(AG_LINE_PF_A_ONLY)
-        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#else
         if (grp == 1 && kh == 1 && !last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (last step: nothing was requested)
-#endif
         asm volatile("s_barrier" ::: "memory");                        // "b"
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#if defined(AG_LINE_ISSUE_IN_MFMA)
-        // experiment: the requests are issued from inside the MFMA phases, spread out (one or two after every eight MFMAs), where the
-        // texture-address unit is not shared with another wave's burst and an issue slot costs about one MFMA's shadow:
-        //   group 0 (A): all eight pieces of step s+1 in its MFMA-lo phase (barrier interval 2 of step s);
-        //   group 1 (W): pieces 4..7 of step s+1 in its MFMA-lo phase (interval 3), pieces 0..3 of step s+2 in its MFMA-hi phase
-        //   (interval 1 of step s+1), into the slot both groups have just finished reading.
-        const bool g0_issue = grp == 0 && kh == 0 && refill;
-        const bool g1_issue_lo = grp == 1 && kh == 0 && refill;
-        const bool g1_issue_hi = grp == 1 && kh == 1 && s + 2 < ns;
-#pragma unroll
-        for (int sn = 0; sn < 4; ++sn) {
-#pragma unroll
-            for (int sm = 0; sm < 8; ++sm)
-                acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
-                                                                      __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g0_issue) { piece1(s + 1, slot ^ 1, 2 * sn); piece1(s + 1, slot ^ 1, 2 * sn + 1); }
-            if (g1_issue_lo) piece1(s + 1, slot ^ 1, 4 + sn);
-            if (g1_issue_hi) piece1(s + 2, slot, sn);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
 #pragma unroll
         for (int sn = 0; sn < 4; ++sn)
 #pragma unroll
             for (int sm = 0; sm < 8; ++sm)
                 acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]),
                                                                       __builtin_bit_cast(bf16x8_t, fx[sm]), acc[sn][sm], 0, 0, 0);
-#endif
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // group 0 meets that barrier after this MFMA phase (upper half): its 8 pieces of step s+1 had at least a phase to land
-#if defined(AG_LINE_PF)
         if (grp == 0 && kh == 1 && !last) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-#else
-        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     };
     auto step = [&](const int s, const int slot, const bool refill, const bool last) {
         half(s, slot, 0, refill, last);
@@ -1782,6 +1662,16 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const float* __restri
 }
 
 }  // namespace
+
+bool ag_resid_split_plan(int M, int N, int K, int* m1, int* m2, int* splits) {
+    SplitPlan pl;
+    if (!ag_gemm_big_eligible(M, N, K, K, N, N, AG_EPI_BIAS_RESID) || !split_plan(M, N, K, device_cus(), &pl)) return false;
+    if (m1) *m1 = pl.m1;
+    if (m2) *m2 = pl.m2;
+    if (splits) *splits = pl.splits;
+    return true;
+}
+int ag_device_cus() { return device_cus(); }
 
 extern "C" size_t ag_gemm_resid_split_scratch_bytes(int M, int N, int K) {
     SplitPlan pl;

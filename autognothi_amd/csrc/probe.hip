@@ -340,3 +340,18 @@ extern "C" int ag_probe_mfma(int iters, int zero_operands, double* tflops, doubl
     (void)hipFree(sink); (void)hipFree(clocks);
     return AG_OK;
 }
+
+// One wave that does nothing for `microseconds` (s_memrealtime: the 100 MHz constant clock): the yes/no probe of whether two HIP streams
+// run their kernels BESIDE each other (two such kernels, one per stream, take one kernel's time) or behind each other (two kernels' time) —
+// scripts/common.TrainPartition checks its second stream with it before an epoch relies on the overlap.
+__global__ void spin_kernel(int ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int ag_probe_spin(int microseconds, void* stream) {
+    AG_REQUIRE(microseconds > 0 && microseconds <= 100000, "ag_probe_spin: 1 .. 100000 us");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}

@@ -363,6 +363,7 @@ struct CastTable {
     int64_t n[CAST_MAX];
     unsigned char f32[CAST_MAX];     // destination dtype: 0 bf16, 1 fp32 (a plain copy: fused q | k | v biases)
     int count;
+    float scale;                     // every element times this (1: as it is; ag_pack_f32_many: a rank's share of the global batch)
 };
 __global__ __launch_bounds__(256) void cast_many_kernel(const CastTable t) {
     int lo = 0, hi = t.count;
@@ -372,14 +373,17 @@ __global__ __launch_bounds__(256) void cast_many_kernel(const CastTable t) {
     }
     const float* src = t.src[lo];
     const int64_t n = t.n[lo];
+    const float sc = t.scale;        // (x * 1.0f is x: one code path)
     const int64_t i0 = ((int64_t)(blockIdx.x - t.first_block[lo]) * 256 + threadIdx.x) * 16;
     if (t.f32[lo]) {
         float* dstf = reinterpret_cast<float*>(t.dst[lo]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t i = i0 + 4 * j;
-            if (i + 4 <= n) *reinterpret_cast<float4*>(dstf + i) = *reinterpret_cast<const float4*>(src + i);
-            else for (int64_t k = i; k < n && k < i + 4; ++k) dstf[k] = src[k];
+            if (i + 4 <= n) {
+                const float4 a = *reinterpret_cast<const float4*>(src + i);
+                *reinterpret_cast<float4*>(dstf + i) = make_float4(a.x * sc, a.y * sc, a.z * sc, a.w * sc);
+            } else for (int64_t k = i; k < n && k < i + 4; ++k) dstf[k] = src[k] * sc;
         }
         return;
     }
@@ -389,9 +393,10 @@ __global__ __launch_bounds__(256) void cast_many_kernel(const CastTable t) {
         const int64_t i = i0 + 8 * j;
         if (i + 8 <= n) {
             const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
-            *reinterpret_cast<uint4*>(dst + i) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+            *reinterpret_cast<uint4*>(dst + i) = make_uint4(pack_bf16x2(a.x * sc, a.y * sc), pack_bf16x2(a.z * sc, a.w * sc),
+                                                            pack_bf16x2(b.x * sc, b.y * sc), pack_bf16x2(b.z * sc, b.w * sc));
         } else {
-            for (int64_t k = i; k < n && k < i + 8; ++k) dst[k] = f32_to_bf16(src[k]);
+            for (int64_t k = i; k < n && k < i + 8; ++k) dst[k] = f32_to_bf16(src[k] * sc);
         }
     }
 }
@@ -515,12 +520,23 @@ extern "C" int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float*
     return AG_OK;
 }
 
+static int cast_many_impl(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, float scale,
+                          void* stream);
 extern "C" int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count,
                                 void* stream) {
+    return cast_many_impl(h_src, h_dst, h_n, h_dst_dtype, count, 1.0f, stream);
+}
+extern "C" int ag_pack_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count,
+                                float scale, void* stream) {
+    return cast_many_impl(h_src, h_dst, h_n, h_dst_dtype, count, scale, stream);
+}
+static int cast_many_impl(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, float scale,
+                          void* stream) {
     AG_REQUIRE(count >= 0 && (count == 0 || (h_src && h_dst && h_n && h_dst_dtype)), "ag_cast_f32_many: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     for (int base = 0; base < count; base += CAST_MAX) {
         CastTable t;
+        t.scale = scale;
         t.count = count - base < CAST_MAX ? count - base : CAST_MAX;
         int blocks = 0;
         for (int i = 0; i < t.count; ++i) {

@@ -178,27 +178,42 @@ def allreduce_grads(params: Iterable[Tensor], average: bool = True, bucket_bytes
 class GradBucketReducer:
     """Gradient exchange of explainer / surrogate training, overlapped with the backward pass.
 
-    The manual backward of ``autognothi_amd/training.py`` walks the graph from the head down and reports every parameter
-    whose gradient is final (``ready(p)``: the trainers call it through ``training.GRAD_SINK``).  Ready gradients are packed
-    into a flat bucket; as soon as a bucket holds ``bucket_bytes`` it is summed over the ranks with an ASYNCHRONOUS
-    all-reduce — RCCL runs it on its own stream, over all seven xGMI links of the GPU, while the backward kernels of the
-    layers below keep the compute stream busy — and ``finish()`` (before ``optimizer.step()``) flushes the tail bucket,
-    waits for the collectives in issue order, averages and scatters the results back into ``.grad``.
-    Bucket size: xGMI is point-to-point, a ring step is per-link bound, so buckets are large (default 64 MiB: the vanilla
+    The manual backward of ``autognothi_amd/training.py`` / ``training16.py`` walks the graph from the head down and reports every
+    parameter whose gradient is final (``ready(p)``: the trainers call it through ``training.GRAD_SINK``).  Ready gradients fill a
+    bucket; a full bucket is PACKED — one ``ag_pack_f32_many`` launch for all its tensors, weighted by this rank's share of the
+    global batch on the way — into the bucket's persistent flat buffer, every ``.grad`` becomes a view into that buffer (no
+    ``torch.cat``, no copy back after the exchange: the optimiser reads the exchanged values in place), and the buffer's collective
+    is issued ASYNCHRONOUSLY on RCCL's stream while the backward kernels of the layers below keep the compute stream busy.
+    ``finish()`` (before ``optimizer.step()``) flushes the tail bucket and waits for the collectives.
+
+    Exchange (``mode`` / ``AG_GRAD_EXCHANGE``):
+      * ``fp32`` (default): reduce-scatter + all-gather in place on RCCL (xGMI is a full mesh of 7 point-to-point links per GPU: every
+        link carries a shard, where a single ring is bound by one link), all-reduce on gloo; exact to the order of the sum.
+      * ``bf16``: the bucket is packed as bf16, exchanged by all-to-all (each rank receives every rank's piece of ITS shard), summed
+        in fp32 on receipt, and the fp32 shard is all-gathered: half the reduce-scatter bytes with no bf16 accumulation; the gradient
+        every rank ends with is the fp32 sum of bf16-rounded contributions.
+    Bucket size: xGMI is point-to-point, a collective step is per-link bound, so buckets are large (default 64 MiB: the vanilla
     ViT-base explainer's 419 MB of fp32 gradients are 7 collectives, the first one in flight after the head + 2 layers).
     Every parameter must be reported at most once per step; ``finish()`` also reduces trainable parameters that were never
     reported but hold a gradient (callers that do not instrument their backward lose the overlap, not the result)."""
 
-    def __init__(self, params: Iterable[Tensor], bucket_bytes: int = 64 << 20, average: bool = True):
+    PAD = 8      # elements: every segment of a bucket starts 16-byte aligned in the bf16 form too
+
+    def __init__(self, params: Iterable[Tensor], bucket_bytes: int = 64 << 20, average: bool = True, mode: Optional[str] = None):
+        import os
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes, self.average = int(bucket_bytes), average
+        self.mode = (mode or os.environ.get("AG_GRAD_EXCHANGE", "fp32")).lower()
+        if self.mode not in ("fp32", "bf16", "allreduce"):
+            raise ValueError(f"GradBucketReducer: unknown exchange mode {self.mode!r} (fp32 | bf16 | allreduce)")
         self._pending: List[Tensor] = []
         self._pending_bytes = 0
-        self._inflight: List[Tuple[object, Tensor, List[Tensor]]] = []
+        self._inflight: List[Tuple] = []
         self._seen = set()
         self.collectives = 0
         self._weight: Optional[float] = None
         self._known = None            # ids of the parameters that received a gradient in the last regular (non-ragged) step
+        self._bufs = {}               # bucket index of the step -> (flat fp32 buffer, bf16 send / receive buffers or None)
 
     def begin(self, weight: Optional[float] = None) -> None:
         """Start a step.  ``weight`` = this rank's share of the step's global batch (inputs of this rank / inputs of all ranks):
@@ -213,24 +228,88 @@ class GradBucketReducer:
         if id(p) in self._seen:
             raise RuntimeError("GradBucketReducer.ready: a parameter was reported twice in one step")
         self._seen.add(id(p))
-        if self._pending and self._pending[0].grad.dtype != p.grad.dtype:
-            self._flush()
         self._pending.append(p)
-        self._pending_bytes += p.grad.numel() * p.grad.element_size()
+        self._pending_bytes += p.grad.numel() * 4
         if self._pending_bytes >= self.bucket_bytes:
             self._flush()
+
+    # ---- one bucket: pack -> views -> collective
+    def _buffers(self, index: int, n: int, device, bf16: bool, w: int):
+        have = self._bufs.get(index)
+        if have is None or have[0].numel() < n or have[0].device != device or (bf16 and have[1] is None):
+            flat = torch.empty(n, dtype=torch.float32, device=device)
+            send = torch.empty(n, dtype=torch.bfloat16, device=device) if bf16 else None
+            recv = torch.empty(n, dtype=torch.bfloat16, device=device) if bf16 else None
+            have = (flat, send, recv)
+            self._bufs[index] = have
+        return have
 
     def _flush(self) -> None:
         if not self._pending:
             return
+        w = dist.get_world_size()                                # (the group's real size: shapes of the collectives)
         ps = self._pending
-        flat = torch.cat([q.grad.reshape(-1) for q in ps])
-        if self._weight is not None:
-            flat *= self._weight
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self._inflight.append((work, flat, ps))
+        pad = self.PAD
+        offs, n = [], 0
+        for q in ps:
+            offs.append(n)
+            n += -(-q.grad.numel() // pad) * pad
+        n = -(-n // (pad * w)) * (pad * w)                       # equal, aligned shards
+        dev = ps[0].grad.device
+        bf16 = self.mode == "bf16" and dev.type == "cuda"
+        flat, send, recv = self._buffers(self.collectives, n, dev, bf16, w)
+        flat, send, recv = flat[:n], (send[:n] if bf16 else None), (recv[:n] if bf16 else None)
+        scale = 1.0 if self._weight is None else float(self._weight)
+        target = send if bf16 else flat
+        views = [flat[o:o + q.grad.numel()].view_as(q.grad) for q, o in zip(ps, offs)]
+        grads = [q.grad if (q.grad.dtype == torch.float32 and q.grad.is_contiguous()) else q.grad.float().contiguous() for q in ps]
+        if dev.type == "cuda":
+            from . import ops
+            pairs = [(g, target[o:o + g.numel()]) for g, o in zip(grads, offs) if bf16 or g.data_ptr() != flat[o:].data_ptr() or scale != 1.0]
+            ops.pack_many(pairs, scale)                          # ONE launch (per 96 tensors) for the whole bucket
+        else:                                                    # (CPU / gloo: the sharding contract's tests)
+            for g, v in zip(grads, views):
+                if g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+                if scale != 1.0:
+                    v.mul_(scale)
+        for q, v in zip(ps, views):                              # the gradient IS the bucket's slice from here on
+            q.grad = v
+        backend = dist.get_backend()
+        if bf16:
+            # all-to-all of bf16 pieces, fp32 sum on receipt, all-gather of the fp32 shard — behind the a2a on a side stream, so that the
+            # backward's stream never waits for a collective
+            side = self._side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                dist.all_to_all_single(recv, send)
+                r = dist.get_rank()
+                shard = flat[r * (n // w):(r + 1) * (n // w)]
+                torch.sum(recv.view(w, n // w).float(), dim=0, out=shard)
+                work = dist.all_gather_into_tensor(flat, shard, async_op=True)
+            for t_ in (flat, send, recv):
+                t_.record_stream(side)
+            self._inflight.append((work, flat, side))
+        elif self.mode == "fp32" and backend == "nccl":
+            r = dist.get_rank()
+            shard = flat[r * (n // w):(r + 1) * (n // w)]
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+            work = dist.all_gather_into_tensor(flat, shard, async_op=True)     # (same communicator stream: ordered behind the reduce-scatter)
+            self._inflight.append((work, flat, None))
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            self._inflight.append((work, flat, None))
         self._pending, self._pending_bytes = [], 0
         self.collectives += 1
+
+    _SIDE = {}
+
+    @classmethod
+    def _side_stream(cls, dev):
+        key = str(dev)
+        if key not in cls._SIDE:
+            cls._SIDE[key] = torch.cuda.Stream(device=dev)
+        return cls._SIDE[key]
 
     def finish(self, fill_missing: bool = False) -> int:
         """-> number of collectives of this step.  ``fill_missing``: trainable parameters without a gradient take part as
@@ -240,25 +319,20 @@ class GradBucketReducer:
         if w > 1:
             if not fill_missing:                  # a regular step: remember which parameters a backward gives a gradient to
                 self._known = {id(p) for p in self.params if p.grad is not None}
-            filled = []
             for p in self.params:                 # gradients nobody reported (un-instrumented backward)
                 if p.grad is None and fill_missing and (self._known is None or id(p) in self._known):
                     # (only parameters a backward DOES reach: a zero gradient for, e.g., a head outside the loss would make AdamW
                     # decay it and start its moments on ragged steps only — the single-process run leaves it untouched)
-                    p.grad = torch.zeros_like(p)
-                    filled.append(p)
+                    p.grad = torch.zeros_like(p, dtype=torch.float32)
                 if p.grad is not None and id(p) not in self._seen:
                     self.ready(p)
             self._flush()
-            for work, flat, ps in self._inflight:
+            for work, flat, side in self._inflight:
                 work.wait()
+                if side is not None:
+                    torch.cuda.current_stream(flat.device).wait_stream(side)
                 if self.average and self._weight is None:
                     flat /= w
-                off = 0
-                for q in ps:
-                    n = q.grad.numel()
-                    q.grad.copy_(flat[off:off + n].view_as(q.grad))
-                    off += n
         n_coll = self.collectives
         self._inflight, self._seen, self.collectives, self._weight = [], set(), 0, None
         return n_coll

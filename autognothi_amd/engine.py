@@ -156,13 +156,8 @@ class PackedFoldedLinear:
     def get(self, dtype: int) -> Tuple[Tensor, Tensor, Tensor]:
         key = (dtype, _versions(self.weights + self.biases + [self.ln.weight, self.ln.bias]))
         if key != self.key:
-            with torch.no_grad():
-                w = torch.cat([x.detach() for x in self.weights], dim=0).float()
-                b = torch.cat([x.detach().float() for x in self.biases], dim=0)
-                g, beta = self.ln.weight.detach().float(), self.ln.bias.detach().float()
-                self.w = ops.cast((w * g[None, :]).contiguous(), dtype)
-                self.b = (b + w @ beta).contiguous()
-                self.s = self.w.float().sum(dim=1).contiguous()
+            with torch.no_grad():   # one launch per weight (q | k | v side by side): gamma * W rounded, b + W.beta, column sums of the rounded W'
+                self.w, self.b, self.s = ops.pack_folded_linear(self.weights, self.biases, self.ln.weight, self.ln.bias, dtype)
             self.key = key
         _log_pack(self, key, (self.w, self.b, self.s))
         return self.w, self.b, self.s

@@ -210,6 +210,29 @@ def cast(src: Tensor, dtype: int) -> Tensor:
     return out
 
 
+def pack_folded_linear(weights, biases, gamma: Tensor, beta: Tensor, dtype: int):
+    """Linear(LayerNorm(x)) folded for the GEMM epilogue (ag_pack_folded_linear): the [N_i, K] fp32 weights (and [N_i] biases, entries
+    may be None) land side by side -> (W' = gamma * W in the storage dtype [N, K], b' = b + W.beta [N], colsum of the rounded W' [N])."""
+    L.require_gpu(gamma, beta, *weights)
+    k = weights[0][0].numel()
+    n_tot = sum(int(w_.shape[0]) for w_ in weights)
+    dev = gamma.device
+    w_out = torch.empty((n_tot, k), dtype=storage_dtype(dtype), device=dev)
+    b_out = torch.empty(n_tot, dtype=torch.float32, device=dev)
+    s_out = torch.empty(n_tot, dtype=torch.float32, device=dev)
+    g, bt = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    n0 = 0
+    with L.on(dev):
+        for w_, b_ in zip(weights, biases):
+            n = int(w_.shape[0])
+            wf = w_.detach().reshape(n, -1).float().contiguous()
+            bf = None if b_ is None else b_.detach().float().contiguous()
+            L.check(L.lib().ag_pack_folded_linear(L.ptr(wf), L.ptr(bf), L.ptr(g), L.ptr(bt), n, k, L.ptr(w_out[n0:]), dtype,
+                                                  L.ptr(b_out[n0:]), L.ptr(s_out[n0:]), L.stream()))
+            n0 += n
+    return w_out, b_out, s_out
+
+
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, dtype: int, rows: Optional[int] = None,
               ldx: Optional[int] = None, want_store: bool = True, want_f32: bool = False, rows_dev: Optional[Tensor] = None):
     """x [..., H] fp32 or bf16 (or a strided view described by rows/ldx); statistics in fp32.  ``rows_dev`` (here and in gemm /
@@ -398,6 +421,25 @@ def cast_many(pairs) -> None:
         L.check(L.lib().ag_cast_f32_many(src, dst, cnt, dty, n, L.stream()))
 
 
+def pack_many(pairs, scale: float = 1.0) -> None:
+    """cast_many with every element scaled on the way (ag_pack_f32_many): the gradients of one exchange bucket -> its flat send buffer."""
+    import ctypes as C
+    pairs = [(s_, d_) for s_, d_ in pairs if s_.numel() > 0]
+    if not pairs:
+        return
+    n = len(pairs)
+    L.require_gpu(*[t_ for pr in pairs for t_ in pr])
+    for s_, d_ in pairs:
+        if s_.dtype != torch.float32 or not s_.is_contiguous() or not d_.is_contiguous() or d_.numel() != s_.numel():
+            raise ValueError("pack_many: sources must be contiguous fp32, destinations contiguous with the same element count")
+    src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
+    dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
+    cnt = (C.c_int64 * n)(*[s_.numel() for s_, _ in pairs])
+    dty = (C.c_int * n)(*[(F32 if d_.dtype == torch.float32 else BF16) for _, d_ in pairs])
+    with L.on(pairs[0][0].device):
+        L.check(L.lib().ag_pack_f32_many(src, dst, cnt, dty, n, float(scale), L.stream()))
+
+
 def set_dropout_salt(salt: int, device) -> None:
     """ag_set_dropout_salt on the current stream of ``device`` (0 = the eager default: seeds as given)."""
     with L.on(device):
@@ -473,6 +515,35 @@ def gemm_resid_split(a: Tensor, w: Tensor, bias: Optional[Tensor], resid: Tensor
         L.check(L.lib().ag_gemm_resid_split(L.ptr(a), a.stride(0), L.ptr(w), L.ptr(bias), L.ptr(out), out.stride(0), L.ptr(resid), resid.stride(0),
                                             m, n, k, L.ptr(stats_out), L.ptr(scratch), scratch.numel() * 4, L.stream()))
     return out
+
+
+WS_GEMM, WS_BIG_SPLIT, WS_EX, WS_EX_SLABS = 0, 1, 2, 3   # routes of ag_gemm_ws (csrc/common.h)
+
+
+def gemm_ws(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: Optional[int] = None, lda: Optional[int] = None,
+            resid: Optional[Tensor] = None, ldr: Optional[int] = None, rows_per_seq: int = 1, resid_share: int = 1,
+            out: Optional[Tensor] = None, ldc: Optional[int] = None, ln_stats: Optional[Tensor] = None, stats_in_cols: int = 256,
+            ln_colsum: Optional[Tensor] = None, ln_eps: float = 0.0, stats_out: Optional[Tensor] = None, out_cols_ok: int = 3,
+            rows_dev: Optional[Tensor] = None, route: int = -1, splits: int = 0):
+    """ag_gemm_ws: the planned Linear of the masked forward at under-filled launch sizes (bf16).  -> (out, slab width of the
+    statistics written or 0).  route < 0: planned by the library's cost model; else WS_GEMM / WS_BIG_SPLIT / WS_EX / WS_EX_SLABS."""
+    L.require_gpu(a, w, bias, resid, out, ln_stats, ln_colsum, stats_out)
+    n, k = w.shape
+    m = a.numel() // k if m is None else m
+    lda = k if lda is None else lda
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    ldc = n if ldc is None else ldc
+    ldr = (n if ldr is None else ldr) if resid is not None else 0
+    cols = C.c_int(0)
+    with L.on(a.device):
+        need = int(L.lib().ag_gemm_ws_scratch_bytes(m, n, k, epilogue))
+        scratch = _scratch(a.device, (need + 3) // 4) if need else None
+        L.check(L.lib().ag_gemm_ws(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr, rows_per_seq, resid_share,
+                                   m, n, k, epilogue, L.AG_BF16, L.ptr(ln_stats), stats_in_cols, L.ptr(ln_colsum), float(ln_eps),
+                                   L.ptr(stats_out), out_cols_ok, C.byref(cols), L.ptr(rows_dev), route, splits,
+                                   L.ptr(scratch), scratch.numel() * 4 if scratch is not None else 0, L.stream()))
+    return out, int(cols.value)
 
 
 def side_mlp(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], ln_g: Optional[Tensor],

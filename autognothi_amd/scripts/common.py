@@ -127,10 +127,30 @@ class TrainPartition:
         self.device = device
         self.fwd = L.background_stream(device.index if device.index is not None else torch.cuda.current_device())
         self.n_fwd = 8 * int(cus_per_xcd_fwd)
+        self._checked = {}          # raw handle of a caller's stream -> does ``fwd`` run beside it?
 
-    def arm(self) -> "TrainPartition":
-        """(the background stream is shared by every partition of the device: tell the library THIS one's CU count)"""
+    def arm(self) -> Optional["TrainPartition"]:
+        """(the background stream is shared by every partition of the device: tell the library THIS one's CU count.)  Before an epoch
+        relies on it, the second stream is CHECKED against the caller's stream (``_lib.streams_overlap``: one idle wave on each — one
+        kernel's time = beside, two = behind): HIP multiplexes the streams of a process onto a few hardware queues, and a host program that
+        created streams / captured graphs before this package first ran can leave the two on ONE queue, where the two-stream epoch is 24 %
+        slower than one stream (profiles/HISTORY.md §10).  Then a few fresh streams are tried (each takes the next queue at its first
+        submission); None when none runs beside the caller's: the epoch then runs on one stream."""
         from .. import _lib as L
+        main = torch.cuda.current_stream(self.device)
+        ok = self._checked.get(main.cuda_stream)
+        if ok is None:
+            ok = L.streams_overlap(main, self.fwd)
+            tries = 0
+            while not ok and tries < 6:
+                cand = torch.cuda.Stream(self.device, priority=-1)
+                ok = L.streams_overlap(main, cand)
+                if ok:
+                    self.fwd = cand
+                tries += 1
+            self._checked[main.cuda_stream] = ok
+        if not ok:
+            return None
         with torch.cuda.device(self.device):
             L.check(L.lib().ag_set_stream_cus(self.fwd.cuda_stream, self.n_fwd))
         return self
@@ -142,11 +162,12 @@ _PARTITIONS = {}
 def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartition]:
     """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: "0" = off (targets and steps back to back on the caller's stream); an
     integer = CUs per XCD the target forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32
-    for a ViT explainer whose backbone trains, 28 for a frozen backbone or a BERT explainer.  One rank only (N > 1: RCCL's kernels want
-    CUs at moments of their own; not measured), never under the hipGraph step."""
-    from .. import distributed, training16
+    for a ViT explainer whose backbone trains, 28 for a frozen backbone or a BERT explainer.  Every rank count: with N > 1 ranks RCCL's
+    kernels (the gradient exchange, on the communicator's own stream) are a third client of the CUs the target forward leaves free.  Never
+    under the hipGraph step.  None also when the second stream does not run beside the caller's (``TrainPartition.arm``)."""
+    from .. import training16
     mode = os.environ.get("AG_TRAIN_PARTITION", "auto")
-    if mode in ("0", "") or device.type != "cuda" or distributed.world()[1] > 1 or training16.GRAPH_STEP:
+    if mode in ("0", "") or device.type != "cuda" or training16.GRAPH_STEP:
         return None
     if mode == "auto":
         # measured (tools/train_step_bench.py and inside bench.py, 36-72 steps of 8 images x 32 masks, images/s off -> on):

@@ -61,7 +61,7 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
             yield group
 
     # (one rank: the targets of the NEXT group on a second stream beside this group's steps, scripts/common.TrainPartition)
-    part = train_partition(device, m_explainer) if reducer is None else None
+    part = train_partition(device, m_explainer)
 
     def compute(group):
         return surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,

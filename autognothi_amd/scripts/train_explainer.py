@@ -214,9 +214,10 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
         if group:
             yield group
 
-    # one rank on a GPU: the target forward of the NEXT group runs on a second stream (its persistent GEMM on 3/4 of every XCD's CUs)
-    # while this group's steps run on the caller's (common.TrainPartition / pipelined_targets); otherwise the two alternate
-    part = train_partition(device, m_explainer) if reducer is None else None
+    # on a GPU the target forward of the NEXT group runs on a second stream (its persistent GEMM on 3/4 of every XCD's CUs) while this
+    # group's steps run on the caller's (common.TrainPartition / pipelined_targets) — with N > 1 ranks beside the gradient exchange too;
+    # otherwise (AG_TRAIN_PARTITION=0, no second hardware queue) the two alternate
+    part = train_partition(device, m_explainer)
 
     def batches():
         def compute(group):

@@ -383,7 +383,7 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
-def grad_exchange_overlap(job, dev, tb, steps=6):
+def grad_exchange_overlap(job, dev, tb, steps=4):
     """Exposed time of the gradient exchange of one explainer training step at ONE rank: every gradient of the vanilla explainer
     (ViT-base: 104.7 M fp32 = 419 MB) goes through distributed.GradBucketReducer — 64 MiB buckets, each an asynchronous RCCL all-reduce —
     (a) from inside the backward (training.GRAD_SINK: a bucket is in flight while the layers below still run) and (b) after it,
@@ -418,10 +418,12 @@ def grad_exchange_overlap(job, dev, tb, steps=6):
         labels = torch.zeros(tb, dtype=torch.long, device=dev)
         D.world = lambda: (0, 2)         # the reducer issues its collectives (a sum over the one real rank)
 
-        def step(mode):
+        reducers = {m_: D.GradBucketReducer(params, mode=m_) for m_ in ("fp32", "bf16")}    # (persistent: the bucket buffers are reused step after step)
+
+        def step(mode, exchange="fp32"):
             for q in params:
                 q.grad = None
-            red = D.GradBucketReducer(params)
+            red = reducers[exchange]
             if mode == "overlapped":
                 red.begin(0.5)
                 _tr.GRAD_SINK = red.ready
@@ -433,26 +435,38 @@ def grad_exchange_overlap(job, dev, tb, steps=6):
                 red.begin(0.5)
             return red.finish() if mode != "none" else 0
 
-        out = {}
-        for mode in ("none", "overlapped", "after_backward"):
+        # five rounds over the legs, interleaved (a leg timed once, after the others, measured the box's drift: round 4's line had the
+        # overlapped leg slower than the serial one in one run and faster than NO exchange in the next); min and median per leg
+        legs = [("none", "fp32"), ("overlapped", "fp32"), ("after_backward", "fp32"), ("overlapped", "bf16")]
+        samples = {lg: [] for lg in legs}
+        n_coll = 0
+        for lg in legs:
             for _ in range(2):
-                n_coll = step(mode)
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            for _ in range(steps):
-                step(mode)
-            torch.cuda.synchronize()
-            out[mode] = (time.perf_counter() - t_) / steps * 1e3
-            if mode == "overlapped":
-                out["collectives"] = n_coll
+                n_coll = max(n_coll, step(*lg))
+        for _ in range(5):
+            for lg in legs:
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(steps):
+                    step(*lg)
+                torch.cuda.synchronize()
+                samples[lg].append((time.perf_counter() - t_) / steps * 1e3)
+        med = {lg: float(np.median(v)) for lg, v in samples.items()}
+        mn = {lg: float(np.min(v)) for lg, v in samples.items()}
         gbytes = sum(q.numel() for q in params) * 4 / 1e9
-        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step at ONE rank: no exchange / "
-                        "bucketed all-reduce from inside the backward / the same buckets after the backward; exposed = step - no-exchange step. "
-                        "One rank: nothing crosses xGMI, the figures are packing + RCCL launch + in-place reduction + unpacking",
-                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": out.get("collectives"),
-                "ms_no_exchange": round(out["none"], 3), "ms_overlapped": round(out["overlapped"], 3), "ms_after_backward": round(out["after_backward"], 3),
-                "exposed_ms_overlapped": round(out["overlapped"] - out["none"], 3),
-                "exposed_ms_after_backward": round(out["after_backward"] - out["none"], 3)}
+        r3 = lambda x: round(x, 3)   # noqa: E731
+        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step at ONE rank, median (min) of 5 "
+                        "interleaved rounds: no exchange / bucketed exchange from inside the backward / the same buckets after the backward; "
+                        "exposed = median - no-exchange median.  A bucket is packed by ONE launch into its persistent flat buffer, .grad becomes a "
+                        "view of it (no torch.cat, no copy back), reduce-scatter + all-gather in place (fp32) or bf16 all-to-all + fp32 sum on "
+                        "receipt + fp32 all-gather (bf16).  One rank: nothing crosses xGMI, the figures are packing + RCCL launches",
+                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": 5,
+                "ms_no_exchange": r3(med[legs[0]]), "ms_overlapped": r3(med[legs[1]]), "ms_after_backward": r3(med[legs[2]]),
+                "ms_overlapped_bf16_payload": r3(med[legs[3]]),
+                "min_ms": {"no_exchange": r3(mn[legs[0]]), "overlapped": r3(mn[legs[1]]), "after_backward": r3(mn[legs[2]]), "overlapped_bf16": r3(mn[legs[3]])},
+                "exposed_ms_overlapped": r3(med[legs[1]] - med[legs[0]]),
+                "exposed_ms_after_backward": r3(med[legs[2]] - med[legs[0]]),
+                "exposed_ms_overlapped_bf16_payload": r3(med[legs[3]] - med[legs[0]])}
     finally:
         D.world = keep_world
         _tr.MIXED_BF16 = keep_mixed
@@ -485,7 +499,7 @@ def bf16_vs_reference(workload, dev, tag=None):
     return out
 
 
-def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=None, masks=0):
+def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=None, masks=0, graph=False):
     """One BASELINE config as a compact block of the driver line: `steps` timed steps of the same step function, in-library
     event timing of its dominant kernel class.  ``masks``: K masks per input (0: the config's own K)."""
     job = Job(workload, dev, rank, world, batch, masks, "bf16")
@@ -496,15 +510,25 @@ def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=
         for _ in range(2):
             job.step()
         torch.cuda.synchronize()
+        # the timed steps run WITHOUT the in-library event timing (two hipEvents per launch: a tax of its own on steps of a few
+        # milliseconds), eagerly and replayed from one hipGraph (engine.GraphedStep: what a caller at these sizes uses — a step of 64 or 8
+        # masked rows is ~170 launches of a few microseconds); the kernel classes are timed in a separate pass
+        el_e, _ = timed(job.step, steps, 1, dist, dev)
+        el_g = None
+        if graph:
+            gstep = engine.GraphedStep(job.step)
+            el_g, _ = timed(gstep, steps, 1, dist, dev)
+            del gstep
         L.check(L.lib().ag_profile_enable(1))
         for c in EPI_NAMES:
             collect(c)
-        el, _ = timed(job.step, steps, 0, dist, dev)
+        timed(job.step, max(2, steps // 2), 0, dist, dev, settle_s=0.0)
         L.check(L.lib().ag_profile_enable(0))
         st = {c: collect(c) for c in EPI_NAMES}
         packed = engine.last_packed_rows(dev)
     finally:
         engine.PRUNE_BERT_TOKENS = keep
+    el = el_e if el_g is None else min(el_e, el_g)
     value = job.R * world * steps / el
     frac_vis = packed / float(job.R * job.T) if (job.kind in ("vanilla_bert", "duo_vanilla_bert") and packed and engine_prunes(prune)) else 1.0
     f_exec = flops_executed(job.kind, job.params, job.T, job.K, frac_vis)
@@ -512,6 +536,8 @@ def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=
     ms, fl, _, n = st[dom]
     return {"workload": WORKLOAD_LABEL[workload], "masks_per_input": job.K, "inputs_per_gpu_per_step": batch,
             "value": round(value, 1), "unit": "masked-forwards/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
+            "launch": "eager" if (el_g is None or el_e <= el_g) else "hipGraph replay (engine.GraphedStep)",
+            "eager_value": round(job.R * world * steps / el_e, 1), "graph_value": None if el_g is None else round(job.R * world * steps / el_g, 1),
             "dominant_kernel": EPI_NAMES[dom], "frac": round(fl / max(ms, 1e-9) / 1e9 / PEAK_BF16_TFLOPS, 4),
             "dominant_avg_us": round(1e3 * ms / max(1, n), 1),
             "exec_frac_of_peak": round(value / world * f_exec / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -535,6 +561,7 @@ def main():
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-child", action="store_true", help=argparse.SUPPRESS)   # (internal: grad_exchange_overlap in its own process)
+    ap.add_argument("--train-child", action="store_true", help=argparse.SUPPRESS)     # (internal: the training step as ONE rank under torch.distributed.run)
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per explainer training step of the secondary block (0 = skip)")
     # 220 images x 197 tokens = 170 M-tiles: 510 / 1530 / 2040 tiles for N = 768 / 2304 / 3072 = 1.99 / 5.98 / 7.97 rounds of 256 CUs
     # (128 images leave 42 % of the second round of the N = 768 GEMMs idle: 6.3 k -> 7.6 k attributions/s)
@@ -548,6 +575,30 @@ def main():
         engine.set_precision("bf16")
         job = Job("vit_base", dev, 0, 1, max(1, args.train_batch), 0, "bf16")
         print(json.dumps({"gradient_exchange_overlap": grad_exchange_overlap(job, dev, max(1, args.train_batch))}), flush=True)
+        return
+    if args.train_child:
+        # one rank under the launcher (RCCL initialised, the epoch body takes its N > 1 code path at world size 1): the same training step as
+        # the plain run's — its two-stream schedule included
+        import torch.distributed as tdist
+        dev = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
+        torch.cuda.set_device(dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)                                   # (RCCL's banner goes to stderr)
+        try:
+            tdist.init_process_group(backend="nccl", rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")), device_id=dev)
+            tdist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
+        engine.set_precision("bf16")
+        job = Job("vit_base", dev, 0, 1, max(1, args.train_batch), 0, "bf16")
+        job.step()
+        rate, _, _ = train_step_rate(job, tdist, 36, max(1, args.train_batch), "bf16")
+        rate_one, _, _ = train_step_rate(job, tdist, 36, max(1, args.train_batch), "bf16", partition="0")
+        print(json.dumps({"train_child": {"value": round(rate, 1), "one_stream_value": round(rate_one, 1)}}), flush=True)
+        tdist.destroy_process_group()
         return
     maybe_spawn(args)
 
@@ -697,11 +748,11 @@ def main():
         cfgs["vit_large_imagenette_vanilla_K64"] = compact_config_line("vit_large", dev, rank, world, 48, dist, steps=3)
         # the per-GPU shard of BASELINE config 4 under STRONG scaling over 8 GPUs: one ViT-large input x 64 masks per GPU (64 rows)
         cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_1_input_per_gpu"] = dict(
-            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10),
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, graph=True),
             note="what each of 8 GPUs runs when a step of 8 inputs x K = 64 is sharded by input; with ONE input per step the shard is 8 masks "
                  "per GPU (scripts/common.shard_auto: K-within-image): see ..._8_masks_per_gpu")
         cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_8_masks_per_gpu"] = dict(
-            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, masks=8),
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, masks=8, graph=True),
             note="config 4 at ONE input per step over 8 GPUs: every GPU embeds the input and runs 8 of its 64 masks")
         secondary["baseline_configs"] = {"what": "BASELINE.json configs 3 and 4 at one GPU per rank: masked-forwards/s, dominant-kernel "
                                                  "fraction of the 2.5 PF bf16 peak (in-library hipEvents), whole-step executed fraction",
@@ -773,8 +824,16 @@ def main():
         if world == 1 and args.precision == "bf16" and not args.no_secondary:
             rate_graph, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, graph=True)
             rate_one, _, _ = train_step_rate(job, dist, n_steps_train, args.train_batch, args.precision, partition="0")
+        rate_fp32 = None
+        if world == 1 and args.precision == "bf16" and not args.no_secondary:
+            # what train_explainer(env, device) runs unless AG_TRAIN_BF16=1: the exact-fp32 step (training.py), targets still from the bf16 surrogate
+            rate_fp32, _, _ = train_step_rate(job, dist, 24, args.train_batch, "fp32")
         tf = rate / world / args.train_batch * f_step / 1e12
         train_block = {"value": round(rate, 1), "unit": "images/s", "masks_per_image": K, "images_per_gpu_per_step": args.train_batch,
+                       "fp32_step_value": None if rate_fp32 is None else round(rate_fp32, 1),
+                       "fp32_step": "the exact-fp32 explainer step (training.py: fp32 operands and activations) — the DEFAULT of the entry points; `value` is "
+                                    "the bf16 step (AG_TRAIN_BF16=1 / training.MIXED_BF16), checked against CPU autograd at 12 layers "
+                                    "(tests/test_gpu_fulldepth.py) and over a 20-step trajectory against the fp32 step (tests/test_gpu_training16.py)",
                        "steps": n_steps_train, "library_launches_per_step": round(launches_eager, 1),
                        "launch": "eager (the epoch body keeps the GPU busy with the K-mask target forward of the next batches while the host "
                                  "issues the step)",
@@ -782,7 +841,7 @@ def main():
                        "schedule": "one rank: the K-mask target forward of the NEXT group of batches on the device's background stream, its persistent GEMM "
                                    "confined to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition; "
                                    "same masks, steps and parameters bit for bit: tests/test_gpu_scripts.py); one_stream_value = AG_TRAIN_PARTITION=0: the two "
-                                   "back to back on one stream, which is also what N > 1 ranks run",
+                                   "back to back on one stream; N > 1 ranks run the two-stream schedule too (one_rank_under_torch_distributed_run)",
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
                        "graph_replay": "the same step with explainer forward + loss + backward (both streams) replayed from ONE hipGraph "
                                        "(AG_TRAIN_GRAPH=1; bit-identical gradients: tests/test_gpu_graph.py); optimiser and target forward eager",
@@ -841,6 +900,27 @@ def main():
                                                        else {"error": (r_.stderr or r_.stdout)[-300:]})
                 except Exception as exc:   # (no RCCL on the box: the line still goes out)
                     c5["gradient_exchange_overlap"] = {"error": repr(exc)[:200]}
+                try:
+                    # ... and the vanilla ViT-base training step as ONE rank under the launcher (python -m torch.distributed.run --nproc-per-node 1):
+                    # RCCL up, the epoch body on its N > 1 code path, the two-stream schedule on
+                    import socket
+                    with socket.socket() as s_:
+                        s_.bind(("127.0.0.1", 0))
+                        port_ = s_.getsockname()[1]
+                    r_ = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                                         "--master-port", str(port_), os.path.abspath(__file__), "--train-child", "--train-batch", str(args.train_batch)],
+                                        capture_output=True, text=True, timeout=400, cwd=ROOT, env=env_)
+                    got = [ln for ln in r_.stdout.splitlines() if ln.startswith('{"train_child"')]
+                    if got and train_block is not None:
+                        tc = json.loads(got[-1])["train_child"]
+                        train_block["one_rank_under_torch_distributed_run"] = dict(
+                            tc, unit="images/s", vs_plain_run=round(tc["value"] / max(train_block["value"], 1e-9), 4),
+                            note="the same step with RCCL initialised (world size 1): the epoch takes its N > 1 code path, two-stream schedule on")
+                    elif train_block is not None:
+                        train_block["one_rank_under_torch_distributed_run"] = {"error": (r_.stderr or r_.stdout)[-300:]}
+                except Exception as exc:
+                    if train_block is not None:
+                        train_block["one_rank_under_torch_distributed_run"] = {"error": repr(exc)[:200]}
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed

@@ -26,8 +26,9 @@
 extern "C" {
 #endif
 
-#define AG_ABI_VERSION 3   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
-                            * 3: ag_gemm_ex + the fused training kernels + ag_gemm_resid_split (additions only) */
+#define AG_ABI_VERSION 4   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
+                            * 3: ag_gemm_ex + the fused training kernels + ag_gemm_resid_split (additions only);
+                            * 4: ag_gemm_ws (additions only) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
@@ -107,6 +108,12 @@ int ag_perturbed_masks(const float* d_attr, int n_attr, int n_players, int steps
  * ---------------------------------------------------------------------------------------------- */
 /* fp32 -> storage dtype conversion (weights packing). */
 int ag_cast_f32(const float* d_src, void* d_dst, int64_t n, int dtype, void* stream);
+/* Weight packing of a Linear that consumes a LayerNorm (LayerNorm fold of ag_gemm / ag_gemm_ws; reference models/vanilla_vit.py:369,373
+ * feed LayerNorm outputs straight into Linear layers): w [N,K], b [N] (may be NULL), gamma / beta [K] fp32 ->
+ *   w_out[n,k] = store(w[n,k] * gamma[k])  (storage dtype),  b_out[n] = b[n] + sum_k w[n,k] * beta[k],
+ *   s_out[n] = sum_k w_out[n,k]  (of the ROUNDED weights: the mean term of the fold then cancels exactly).  One wave per row, fixed order. */
+int ag_pack_folded_linear(const float* d_w, const float* d_b, const float* d_gamma, const float* d_beta, int N, int K,
+                          void* d_w_out, int dtype, float* d_b_out, float* d_s_out, void* stream);
 
 /* Device-side row counts (`d_rows`).  ag_gemm, ag_gemm_resid_ln, ag_layernorm, ag_gather_rows, ag_side_mlp, ag_side_linear and
  * ag_bert_layers_forward_packed take a `const int* d_rows` (device pointer, may be NULL).  NULL: the host-side row count (M / rows /
@@ -164,6 +171,26 @@ int ag_gemm_resid_ln_supported(int M, int N, int K, int64_t lda, int64_t ldc, in
 size_t ag_gemm_resid_split_scratch_bytes(int M, int N, int K);
 int ag_gemm_resid_split(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc, const void* d_R,
                         int64_t ldr, int M, int N, int K, float* d_stats_out, void* d_scratch, size_t scratch_bytes, void* stream);
+/* ag_gemm for launches that UNDER-FILL the chip (round 5): the masked forward at the reference's own batch sizes — one to four inputs x
+ * K masks (experiments/vit_base_imagenette_vanilla/.hparams.json:53-54; scripts/measure_faithfulness.py:195-218 runs one image at a
+ * time) — and the 8-64 masked rows per GPU of an 8-way shard of BASELINE configs 4 / 5: M = 1.5-12 k token rows, where the persistent
+ * 256 x 256 kernel works in rounds of 256 tiles and a Linear of 75 or 300 tiles wastes most of a round.  Same contract as ag_gemm (bf16:
+ * AG_EPI_BIAS / AG_EPI_BIAS_GELU with optional LayerNorm fold, AG_EPI_BIAS_RESID with optional row statistics; everything else is
+ * passed through to ag_gemm), but the call is PLANNED: a cost model picks among
+ *     route 0  ag_gemm as it is;                         route 1  ag_gemm_resid_split;
+ *     route 2  128 x 128 units of ag_gemm_ex's kernel with the forward's epilogue in the GEMM;
+ *     route 3  128 x 128 units x `splits` contraction ranges into fp32 slabs in d_scratch + one row kernel (bias + residual + statistics);
+ * Row statistics travel as slab-major partial sums as in ag_gemm, over slabs of 256 columns (routes 0, 1, 3) or of 128 columns (route 2):
+ * stats_in_cols says which layout d_ln_stats has (route 0 reads 256 only), out_cols_ok which layouts the consumer of d_stats_out can
+ * read (bit 0: 256, bit 1: 128), *stats_out_cols (host, may be NULL) returns the one written.  route < 0: planned; >= 0: that route
+ * (splits: route 3's split count, 0 = planned) — the parity tests pin every route.  d_scratch: ag_gemm_ws_scratch_bytes() bytes.
+ * Results equal ag_gemm's to fp32 rounding of the sums (routes 2, 3 add in another order); deterministic, no atomics. */
+size_t ag_gemm_ws_scratch_bytes(int M, int N, int K, int epilogue);
+int ag_gemm_ws(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+               const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue, int dtype,
+               const float* d_ln_stats, int stats_in_cols, const float* d_ln_colsum, float ln_eps,
+               float* d_stats_out, int out_cols_ok, int* stats_out_cols, const int* d_rows, int route, int splits,
+               void* d_scratch, size_t scratch_bytes, void* stream);
 /* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
  * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
  * kernel, bf16:   post_ln = 0 (ViT, models/vanilla_vit.py:373-376):  out = x + fc2(gelu(fc1(LN(x))))     (ln_g NULL: no LN)
@@ -425,6 +452,12 @@ int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int
  * weight of a model after the optimiser step, q | k | v landing side by side in their fused buffer.  HOST arrays of DEVICE pointers
  * (passed to the kernel by value: no table copy, graph-capturable); segments 16-byte aligned. */
 int ag_cast_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, void* stream);
+/* The same launch with every element scaled on the way: the gradient exchange of N > 1 ranks packs the gradients a bucket holds —
+ * each a tensor of its own — into the bucket's flat send buffer (fp32, or bf16 for the compressed exchange), weighted by this rank's
+ * share of the global batch, in ONE launch (the reference's single process has no such step: scripts/train_explainer.py:197-198 is
+ * loss.backward(); optimizer.step()).  autognothi_amd/distributed.py GradBucketReducer. */
+int ag_pack_f32_many(const float* const* h_src, void* const* h_dst, const int64_t* h_n, const int* h_dst_dtype, int count, float scale,
+                     void* stream);
 /* Dropout salt of the bf16 training step: mixed into the seed of every dropout decision of ag_rows_finish, ag_rows_ln_bwd,
  * ag_masked_attention_*_bf16 / _mixed, ag_dropout_f32 and ag_dropout_add_f32 (seed ^ salt * 0x9E3779B1).  A hipGraph-captured step has
  * its per-site seeds frozen into the kernel arguments; setting a new salt before each replay (stream-ordered, outside the graph)
@@ -500,6 +533,9 @@ int ag_set_stream_cus(void* stream, int n_cu);
  * data-dependent switching power), bit 1 issues v_mfma_f32_32x32x16_bf16 instead (same FLOPs per iteration).
  * Synchronous.  No reference counterpart. */
 int ag_probe_mfma(int iters, int zero_operands, double* tflops, double* shader_ghz, void* stream);
+/* One wave idling for `microseconds` on `stream`: two of them on two streams take one kernel's time when the streams run beside each
+ * other and two when HIP has put them on one hardware queue (the two-stream training epoch checks its second stream with it). */
+int ag_probe_spin(int microseconds, void* stream);
 
 /* Measurement aid: what the global -> LDS feed of one CU sustains when a workgroup issues nothing but the ring GEMM's staging requests
  * (32 `global_load_lds_dwordx4` pieces of 16 rows x 64 B per K=32 half-step, 4-slot ring, counted vmcnt) from `waves` (4 / 8 / 16) waves.

@@ -1,0 +1,218 @@
+"""ag_gemm_ws: the planned Linear of the masked forward at under-filled launch sizes (round 5) — every route pinned and compared with
+float64 on the bf16-rounded operands: the 128 x 128 units with the forward's epilogues in the GEMM (bias, LayerNorm fold from 256- and
+128-column slab statistics, GELU, bias + residual + 128-column statistics, the layer-0 residual row map, a device-side row count), the
+split-K slabs + row kernel, the pass-through routes; the planner's choice must equal the best pinned route's result class; and the
+encoder with the planner on / off on the full-depth fixtures.  Shapes = the Linears of ViT-base / ViT-large at 1-4 inputs x K masks and
+of an 8-masks-per-GPU shard (reference experiments/vit_base_imagenette_vanilla/.hparams.json:53-54, scripts/measure_faithfulness.py:195-218)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-2, atol=2e-2)      # bf16 storage of the result
+EPS = 1e-12
+
+
+def _r(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+def _dev(a, dev):
+    return torch.from_numpy(a).to(dev).to(torch.bfloat16)
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+def _slab_stats(x, cols, dev):
+    """slab-major (sum, sum of squares) partials of the rows of x over `cols`-column slabs: [S, M, 2] fp32"""
+    m, h = x.shape
+    s = (h + cols - 1) // cols
+    out = np.zeros((s, m, 2), dtype=np.float32)
+    for i in range(s):
+        blk = x[:, i * cols:(i + 1) * cols].astype(np.float64)
+        out[i, :, 0] = blk.sum(1)
+        out[i, :, 1] = (blk ** 2).sum(1)
+    return torch.from_numpy(out).to(dev)
+
+
+def _rows(g, m):
+    return np.unique(np.clip(np.concatenate([np.arange(0, 200), np.arange(m - 200, m), g.integers(0, m, 400)]), 0, m - 1))
+
+
+# one input x 32 masks of ViT-base (QKV / fc1) | the 8-masks-per-GPU shard of ViT-large | a ragged last tile in both dimensions
+@pytest.mark.parametrize("m,n,k", [(6304, 2304, 768), (6304, 3072, 768), (1576, 4096, 1024), (1000, 392, 320)])
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("fold_cols", [0, 256, 128])
+@pytest.mark.parametrize("tile", ["ex"])
+def test_ws_ex_wide_vs_float64(cuda_device, m, n, k, gelu, fold_cols, tile):
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    route = ops.WS_EX
+    g = np.random.default_rng(m + n + k)
+    a = _r((g.standard_normal((m, k)) * 0.8 + 0.3).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = g.standard_normal(n).astype(np.float32)
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    epi = L.AG_EPI_BIAS_GELU if gelu else L.AG_EPI_BIAS
+    rows = _rows(g, m)
+    a64, w64 = a[rows].astype(np.float64), w.astype(np.float64)
+    if fold_cols:
+        st = _slab_stats(a, fold_cols, dev)
+        colsum = torch.from_numpy(w64.sum(1).astype(np.float32)).to(dev)
+        out, _ = ops.gemm_ws(A, W, B, epi, ln_stats=st, stats_in_cols=fold_cols, ln_colsum=colsum, ln_eps=EPS, route=route)
+        mean = a64.mean(1, keepdims=True)
+        rstd = 1.0 / np.sqrt(a64.var(1, keepdims=True) + EPS)
+        ref = ((a64 - mean) * rstd) @ w64.T + b
+    else:
+        out, _ = ops.gemm_ws(A, W, B, epi, route=route)
+        ref = a64 @ w64.T + b
+    if gelu:
+        ref = _gelu(ref)
+    np.testing.assert_allclose(out.float().cpu().numpy()[rows], ref, **TOL)
+
+
+# out-projection / fc2 of ViT-base at one input | of the ViT-large shard | ragged
+@pytest.mark.parametrize("m,n,k,t,share", [(6304, 768, 768, 197, 1), (6304, 768, 3072, 197, 1), (1576, 1024, 4096, 197, 1), (6304, 768, 768, 197, 32),
+                                           (1000, 392, 320, 1, 1)])
+@pytest.mark.parametrize("route,splits", [("ex", 0), ("slabs", 1), ("slabs", 3), ("slabs", 0)])
+def test_ws_resid_vs_float64(cuda_device, m, n, k, t, share, route, splits):
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    g = np.random.default_rng(m + n + k + share)
+    a = _r((g.standard_normal((m, k)) * 0.8 + 0.1).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = g.standard_normal(n).astype(np.float32)
+    mr = (m // t // share) * t if share > 1 else m           # rows of the residual source (layer 0: one sequence per `share` rows)
+    r = _r((g.standard_normal((max(mr, 1), n)) * 1.3).astype(np.float32))
+    A, W, B, R = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), _dev(r, dev)
+    rt = {"ex": ops.WS_EX, "slabs": ops.WS_EX_SLABS}[route]
+    cols_want = 128 if route == "ex" else 256
+    s_n = (n + cols_want - 1) // cols_want
+    st = torch.full((s_n, m, 2), float("nan"), dtype=torch.float32, device=dev)
+    out, cols = ops.gemm_ws(A, W, B, L.AG_EPI_BIAS_RESID, resid=R, rows_per_seq=t, resid_share=share, stats_out=st,
+                            out_cols_ok=2 if route == "ex" else 1, route=rt, splits=splits)
+    assert cols == cols_want
+    out_n = out.float().cpu().numpy()
+    rows = _rows(g, m)
+    rrow = (rows // t // share) * t + rows % t
+    ref = a[rows].astype(np.float64) @ w.astype(np.float64).T + b + r[rrow]
+    np.testing.assert_allclose(out_n[rows], ref, **TOL)
+    got = st.cpu().numpy().astype(np.float64).sum(0)          # slabs added
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[:, 0], out_n.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
+    np.testing.assert_allclose(got[:, 1], (out_n.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    again, _ = ops.gemm_ws(A, W, B, L.AG_EPI_BIAS_RESID, resid=R, rows_per_seq=t, resid_share=share, route=rt, splits=splits)
+    np.testing.assert_array_equal(again.float().cpu().numpy(), out_n)      # deterministic, and the same without statistics
+
+
+def test_ws_device_side_row_count(cuda_device):
+    """a device-side row count below the host-side bound: rows beyond it are not touched (wide epilogue, residual epilogue, slabs)"""
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    m, n, k, act = 4096, 768, 768, 2100
+    g = np.random.default_rng(5)
+    a = _r(g.standard_normal((m, k)).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    r = _r(g.standard_normal((m, n)).astype(np.float32))
+    A, W, R = _dev(a, dev), _dev(w, dev), _dev(r, dev)
+    nrows = torch.tensor([act], dtype=torch.int32, device=dev)
+    ref = a[:act].astype(np.float64) @ w.astype(np.float64).T
+    for kind in ("wide", "ex", "slabs"):
+        out = torch.full((m, n), 7.0, dtype=torch.bfloat16, device=dev)
+        if kind.endswith("wide"):
+            ops.gemm_ws(A, W, None, L.AG_EPI_BIAS, out=out, rows_dev=nrows, route=ops.WS_EX)
+            want = ref
+        else:
+            ops.gemm_ws(A, W, None, L.AG_EPI_BIAS_RESID, resid=R, out=out, rows_dev=nrows,
+                        route={"ex": ops.WS_EX, "slabs": ops.WS_EX_SLABS}[kind], splits=0 if kind == "ex" else 2)
+            want = ref + r[:act]
+        o = out.float().cpu().numpy()
+        np.testing.assert_allclose(o[:act], want, **TOL)
+        assert (o[act:] == 7.0).all(), kind
+
+
+def test_ws_planner_routes(cuda_device):
+    """the planner's choices at the shapes it was built for (256 CUs): the persistent kernel keeps the launches that fill it, the Linears
+    that under-fill a round leave it, and a planned call returns what the pinned route returns."""
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    if torch.cuda.get_device_properties(dev).multi_processor_count < 256:
+        pytest.skip("planner constants are for the 256-CU part")
+    g = np.random.default_rng(11)
+    for (m, n, k) in [(6304, 768, 768), (1576, 1024, 1024)]:
+        a = _r(g.standard_normal((m, k)).astype(np.float32))
+        w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+        r = _r(g.standard_normal((m, n)).astype(np.float32))
+        A, W, R = _dev(a, dev), _dev(w, dev), _dev(r, dev)
+        st = torch.zeros(((n + 127) // 128, m, 2), dtype=torch.float32, device=dev)
+        out, cols = ops.gemm_ws(A, W, None, L.AG_EPI_BIAS_RESID, resid=R, stats_out=st, out_cols_ok=3)
+        assert cols in (128, 256)
+        ref = a.astype(np.float64) @ w.astype(np.float64).T + r
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref, **TOL)
+    # the benchmarked step (1 536 rows x 197 tokens) stays on the persistent kernel: bit-identical to ag_gemm
+    m, n, k = 302592 // 8, 768, 768
+    a = _dev(_r(g.standard_normal((m, k)).astype(np.float32)), dev)
+    w = _dev(_r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)), dev)
+    out, _ = ops.gemm_ws(a, w, None, L.AG_EPI_BIAS)
+    base = ops.gemm(a, w, None, L.AG_EPI_BIAS, L.AG_BF16)
+    assert torch.equal(out, base)
+
+
+@pytest.mark.parametrize("tag", ["vit_base_l12", "vit_large_l24"])
+def test_encoder_planner_on_off(cuda_device, ag_knobs, tag):
+    """the full-depth fixtures (ViT-base: one input x 32 masks = 6 304 token rows; ViT-large: 64 masks) through the recipes' fw_* callables
+    with the planner on (default) and pinned to the round-4 paths (AG_WS_ROUTE=0): same outputs up to bf16 rounding, both within the bf16
+    bound of the reference."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case(tag)
+    try:
+        on = run_fixture_case(c, cuda_device, "bf16")
+        ag_knobs(AG_WS_ROUTE=0)
+        off = run_fixture_case(c, cuda_device, "bf16")
+    finally:
+        engine.set_precision("fp32")
+    for k in ("v_s", "v_1"):
+        np.testing.assert_allclose(on[k], off[k], rtol=0, atol=2e-2, err_msg=k)
+        np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
+    if tag == "vit_base_l12":
+        assert np.abs(on["v_s"] - off["v_s"]).max() > 0      # (one input x 32 masks: the planner did leave the round-4 paths somewhere)
+
+
+def test_encoder_planner_forced_routes(cuda_device, ag_knobs):
+    """every 128-tile route forced onto the ViT-base encoder's four Linears (AG_WS_FORCE), incl. the 128-column statistics hand-over from
+    the out-projection to fc1 and from fc2 to the next QKV projection: within the bf16 bound of the reference fixture."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case("vit_base_l12")
+    try:
+        for force in ("2304:768:2:0;768:768:2:0;3072:768:2:0;768:3072:2:0", "768:768:3:2;768:3072:3:4;2304:768:2:0;3072:768:0:0",
+                      "768:768:3:1;768:3072:1:0"):
+            ag_knobs(AG_WS_FORCE=force)
+            got = run_fixture_case(c, cuda_device, "bf16")
+            for k in ("v_s", "v_1"):
+                np.testing.assert_allclose(got[k], c["g"][k], rtol=0, atol=2e-2, err_msg=f"{force}: {k}")
+    finally:
+        engine.set_precision("fp32")
+
+
+def test_pack_folded_linear_vs_float64(cuda_device):
+    """ag_pack_folded_linear (the weight packing of a LayerNorm-folded Linear, engine.PackedFoldedLinear): q | k | v side by side"""
+    from autognothi_amd import ops
+    dev = cuda_device
+    g = np.random.default_rng(3)
+    k = 768
+    ws = [g.standard_normal((n, k)).astype(np.float32) / 28 for n in (768, 768, 768)]
+    bs = [g.standard_normal(n).astype(np.float32) for n in (768, 768, 768)]
+    gamma, beta = (1 + 0.2 * g.standard_normal(k)).astype(np.float32), (0.1 * g.standard_normal(k)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+    w_o, b_o, s_o = ops.pack_folded_linear([t(w) for w in ws], [t(b) for b in bs], t(gamma), t(beta), ops.BF16)
+    w, b = np.concatenate(ws), np.concatenate(bs)
+    want_w = torch.from_numpy(w * gamma[None, :]).to(torch.bfloat16)
+    assert torch.equal(w_o.cpu(), want_w)
+    np.testing.assert_allclose(b_o.cpu().numpy(), b + w.astype(np.float64) @ beta.astype(np.float64), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(s_o.cpu().numpy(), want_w.double().sum(1).numpy(), rtol=1e-5, atol=1e-4)

@@ -366,3 +366,68 @@ def test_attention_bf16_io_matches_the_fp32_io_kernel(cuda_device, mode):
                                     rows, t, h, heads, mode, 0.1, 9, mixed=True)
     a, b = dq16.float().cpu().numpy(), dq32.view(rows * t, 3 * h).cpu().numpy()
     assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max() + 1e-3
+
+
+# 20-step trajectory of the bf16 step against the exact-fp32 step (same weights, inputs, masks and targets, dropout off, fused AdamW):
+# the loss curves stay within LOSS_BAND of each other at every step, and the two parameter vectors end closer to each other than
+# PARAM_DIST of the distance either has travelled.  Measured on MI355X (round 5) — see the printed line of the test.
+TRAJ_STEPS, TRAJ_LOSS_BAND, TRAJ_PARAM_DIST = 20, 0.05, 0.5
+
+
+@pytest.mark.parametrize("tag", ["duo_bert_base_l12", "froyo_vit_base_l12"])
+def test_bf16_trajectory_tracks_fp32_at_full_depth(cuda_device, tag):
+    """BASELINE config 5's explainers at the shipped depth (12 layers, K = 32): 20 optimiser steps in each training mode
+    (reference loop: scripts/train_duo_explainer.py:180-198)."""
+    from autognothi_amd import engine, ops, training
+    from autognothi_amd.utils import synth
+    dev = cuda_device
+    c = build_case(tag)
+    recipe, g = c["recipe"], c["g"]
+    prm = _zero_dropout(c["meta"])
+    engine.set_precision("fp32")
+    xs = torch.from_numpy(c["xs"]).to(dev)
+    v0, v1 = torch.from_numpy(g["v_0"]).to(dev), torch.from_numpy(g["v_1"]).to(dev)
+    labels = torch.tensor([1][:c["B"]], dtype=torch.long, device=dev)
+    c_ = v1.shape[-1]
+    # per-step masks and targets, the same for both runs: the device sampler's stream, targets drawn around the fixture's grand value
+    rng = ops.DeviceMT19937(dev, 3407)
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    steps = []
+    for _ in range(TRAJ_STEPS):
+        _, bits = ops.mask_shapley_new(rng, c["B"] * c["K"], c["P"])
+        vs = torch.softmax(torch.log(v1.cpu().repeat_interleave(c["K"], 0) + 1e-6) + 0.5 * torch.randn((c["B"] * c["K"], c_), generator=gen), -1)
+        steps.append((bits, vs.to(dev)))
+
+    def run(mixed):
+        keep = training.MIXED_BF16
+        training.MIXED_BF16 = mixed
+        try:
+            exp = recipe.t_explainer(recipe.t_config(**prm))
+            synth.load_synth_weights(exp, seed=1)
+            exp = exp.to(dev).train()
+            start = {n: p.detach().clone() for n, p in exp.named_parameters() if p.requires_grad}
+            tr = training.ExplainerTrainer(recipe, exp)
+            opt = torch.optim.AdamW([p for p in exp.parameters() if p.requires_grad], lr=1e-5, fused=True)
+            engine.watch_optimizer(opt)
+            losses = []
+            for bits, vs in steps:
+                opt.zero_grad()
+                loss, _ = tr.loss_and_grads(xs, bits, v0, vs, v1, c["K"], labels=labels, train=True, seed=0)
+                losses.append(float(loss))
+                opt.step()
+            torch.cuda.synchronize()
+            end = {n: p.detach().clone() for n, p in exp.named_parameters() if p.requires_grad}
+            return np.array(losses), start, end
+        finally:
+            training.MIXED_BF16 = keep
+
+    l32, s32, e32 = run(False)
+    l16, s16, e16 = run(True)
+    assert np.isfinite(l16).all() and np.isfinite(l32).all()
+    band = float(np.abs(l16 - l32).max() / np.abs(l32).max())
+    travelled = float(torch.sqrt(sum(((e32[n] - s32[n]).double() ** 2).sum() for n in e32)))
+    apart = float(torch.sqrt(sum(((e32[n] - e16[n]).double() ** 2).sum() for n in e32)))
+    print(f"{tag}: loss fp32 {l32[0]:.5f} -> {l32[-1]:.5f}, bf16 {l16[0]:.5f} -> {l16[-1]:.5f}; max |dloss| / max loss = {band:.4f}; "
+          f"parameters {apart:.4e} apart after travelling {travelled:.4e} ({apart / travelled:.3f})")
+    assert band <= TRAJ_LOSS_BAND, (band, l32, l16)
+    assert apart <= TRAJ_PARAM_DIST * travelled, (apart, travelled)
