@@ -73,6 +73,7 @@ SIGNATURES = {
     "ag_gemm_resid_ln_supported": (i32, [i32, i32, i32, i64, i64, i64]),
     "ag_gemm_resid_split_scratch_bytes": (C.c_size_t, [i32, i32, i32]),
     "ag_gemm_resid_split": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp, vp, C.c_size_t, vp]),
+    "ag_gemm_resid_ln_ws": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp, f32, i32, i32, i32, vp, vp, i32, i32, i32, vp, C.c_size_t, vp]),
     "ag_gemm_ws_scratch_bytes": (C.c_size_t, [i32, i32, i32, i32]),
     "ag_gemm_ws": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, f32, vp, i32, vp, vp, i32, i32,
                          vp, C.c_size_t, vp]),

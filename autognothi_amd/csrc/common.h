@@ -252,8 +252,14 @@ struct AgWsPlan {
 // fold_in: the call reads d_ln_stats (slabs of `stats_in_cols` columns); stats_out: it writes d_stats_out, and `out_cols_ok` says which
 // slab widths its consumer can read (bit 0: 256, bit 1: 128); route < 0: the cheapest valid route, else that route (valid = false when
 // it cannot serve the call)
+// (m_expected: with a device-side row count, the rows the cost model should price — M is then the bound that sizes and checks the launch)
 AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype, bool dyn_rows, bool fold_in,
-                    int stats_in_cols, bool stats_out, int out_cols_ok, int resid_share, int route = -1, int splits = 0);
+                    int stats_in_cols, bool stats_out, int out_cols_ok, int resid_share, int route = -1, int splits = 0, int m_expected = 0);
+// C = A.W^T + bias + LayerNorm(Rpre) (ag_gemm_resid_ln) as 128^2 units x `splits` contraction ranges + the row kernel; d_r_stats /
+// d_stats_out in 256-column slabs
+int ag_gemm_resid_ln_slabs(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc, const void* d_Rpre, int64_t ldr,
+                           const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps, int M, int N, int K, float* d_stats_out,
+                           const int* d_rows, int splits, void* d_scratch, size_t scratch_bytes, hipStream_t s);
 int ag_gemm_ws_run(const AgWsPlan& plan, const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
                    const void* d_R, int64_t ldr, int rows_per_seq, int resid_share, int M, int N, int K, int epilogue, int dtype,
                    const float* d_ln_stats, int stats_in_cols, const float* d_ln_colsum, float ln_eps, float* d_stats_out,

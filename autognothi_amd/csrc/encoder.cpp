@@ -53,8 +53,12 @@ size_t carve(const ag_encoder_desc* d, int R, char* base, Ws* ws) {
     // ... and the fp32 slabs of the planned 128-tile routes (ag_gemm_ws): the widest of both residual Linears
     size_t split_bytes = 0;
     if (d->dtype == AG_BF16 && M <= 0x7FFFFFFF) {
+        // (all tokens, and the R CLS rows of a cls_only_last layer)
         const size_t b1 = ag_gemm_ws_scratch_bytes((int)M, d->H, d->I, AG_EPI_BIAS_RESID), b2 = ag_gemm_ws_scratch_bytes((int)M, d->H, d->H, AG_EPI_BIAS_RESID);
+        const size_t b3 = ag_gemm_ws_scratch_bytes(R, d->H, d->I, AG_EPI_BIAS_RESID), b4 = ag_gemm_ws_scratch_bytes(R, d->H, d->H, AG_EPI_BIAS_RESID);
         split_bytes = b1 > b2 ? b1 : b2;
+        split_bytes = split_bytes > b3 ? split_bytes : b3;
+        split_bytes = split_bytes > b4 ? split_bytes : b4;
     }
     char* split = split_bytes ? take(split_bytes) : nullptr;
     if (ws) { ws->split = (float*)split; ws->split_bytes = split_bytes; }
@@ -114,7 +118,10 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         return ag_ws_plan(M_, N_, K_, lda_, ldc_, 0, epi, dt, false, fold_in, in_cols, false, 0, 1);
     };
     auto plan_r = [&](int M_, int N_, int K_, int64_t lda_, int64_t ldc_, int64_t ldr_, bool stats_out, int cols_ok, int share_) {
-        return ag_ws_plan(M_, N_, K_, lda_, ldc_, ldr_, AG_EPI_BIAS_RESID, dt, false, false, 0, stats_out, cols_ok, share_);
+        AgWsPlan pl = ag_ws_plan(M_, N_, K_, lda_, ldc_, ldr_, AG_EPI_BIAS_RESID, dt, false, false, 0, stats_out, cols_ok, share_);
+        if (pl.valid && pl.scratch_bytes > ws.split_bytes)     // (a caller's workspace from another shape: the routes that need no scratch)
+            pl = ag_ws_plan(M_, N_, K_, lda_, ldc_, ldr_, AG_EPI_BIAS_RESID, dt, false, false, 0, stats_out, cols_ok, share_, AG_WS_GEMM);
+        return pl;
     };
     auto run = [&](const AgWsPlan& pl, const void* A, int64_t lda_, const void* W, const float* b, void* C, int64_t ldc_, const void* Rr,
                    int64_t ldr_, int tq, int sh, int M_, int N_, int K_, int epi, const float* st_in, int in_cols, const float* colsum,
@@ -353,6 +360,18 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         if (!w.ln1_g || !w.ln2_g || !w.w_fc1_ln || (l >= 2 && !w.w_qkv_ln)) fold = false;
     }
     const int* dyn = dN;                   // d_rows of the packed section's launches (NULL again for the last layer's CLS rows)
+    // The Linears of the LayerNorm-free packed section are PLANNED (ag_ws_plan): launches sized for the bound N = R*T, priced for the rows
+    // expected (Shapley-kernel masks leave about half of the players visible) — at the reference's batch sizes (one to four sequences x K
+    // masks: 2-8 k packed rows) the N = 768 Linears are 24-48 tiles of 256 x 256 and run as 128 x 128 units x contraction ranges instead
+    const int m_exp = R > (int)(0.55 * N) ? R : (int)(0.55 * N);
+    auto plan_w = [&](int N_, int K_, int epi, bool fold_in) {
+        return ag_ws_plan(N, N_, K_, K_, N_, 0, epi, dt, true, fold_in, 256, false, 0, 1, -1, 0, m_exp);
+    };
+    auto run = [&](const AgWsPlan& pl, const void* A, int64_t lda_, const void* W, const float* b, void* C, int64_t ldc_, const void* Rr, int64_t ldr_,
+                   int N_, int K_, int epi, const float* st_in, const float* colsum, float* st_out) {
+        return ag_gemm_ws_run(pl, A, lda_, W, b, C, ldc_, Rr, ldr_, 1, 1, N, N_, K_, epi, dt, st_in, 256, colsum, d->ln_eps, st_out, dN, ws.split,
+                              ws.split_bytes, hs);
+    };
     char* x = ws.xs;                       // packed stream entering the layer
     TRY(ag_gather_rows(d_h, H, tok_src, x, H, N, H, dt, dyn, stream));
     char* xn = (char*)d_h;                 // d_h is free again (only token 0 of each row is defined at exit): ping-pong
@@ -363,8 +382,8 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
         AG_REQUIRE(w.ln2_g, "ag_bert_encoder_forward_pruned: BERT output.LayerNorm missing in layer %d", l);
         const ag_layer_weights& wp = d->layers[l - 1];
         if (x_pre)
-            TRY(ag_gemm(x, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, ws.st2, w.s_qkv_ln,
-                        d->ln_eps, nullptr, dyn, stream));
+            TRY(run(plan_w(3 * H, H, AG_EPI_BIAS, true), x, H, w.w_qkv_ln, w.b_qkv_ln, ws.qkv, 3 * H, nullptr, 0, 3 * H, H, AG_EPI_BIAS, ws.st2, w.s_qkv_ln,
+                    nullptr));
         else
             TRY(ag_gemm(x, H, w.w_qkv, w.b_qkv, ws.qkv, 3 * H, nullptr, 0, 0, 0, N, 3 * H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
         TRY(ag_masked_attention_varlen(ws.qkv, cu, ws.ctx, R, T, H, d->heads, last ? 1 : 0, dt, stream));
@@ -372,12 +391,15 @@ extern "C" int ag_bert_encoder_forward_pruned(const ag_encoder_desc* d, const vo
             // h1 = ctx Wo^T + bo + (l == 1 ? x : LN2_prev(x)) with statistics; inter = gelu(LN1(h1) W1^T + b1) folded;
             // h2 = inter W2^T + b2 + LN1(h1) recomputed, with statistics: the next layer's input
             if (x_pre)
-                TRY(ag_gemm_resid_ln(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, ws.st2, wp.ln2_g, wp.ln2_b, d->ln_eps, N, H, H, ws.st1, dyn, stream));
+                TRY(ag_gemm_resid_ln_ws(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, ws.st2, wp.ln2_g, wp.ln2_b, d->ln_eps, N, H, H, ws.st1, dyn, m_exp, -1, 0,
+                                        ws.split, ws.split_bytes, stream));
             else
-                TRY(ag_gemm(ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H, 1, 1, N, H, H, AG_EPI_BIAS_RESID, dt, nullptr, nullptr, 0.f, ws.st1, dyn, stream));
-            TRY(ag_gemm(ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, 0, 0, N, I, H, AG_EPI_BIAS_GELU, dt, ws.st1, w.s_fc1_ln,
-                        d->ln_eps, nullptr, dyn, stream));
-            TRY(ag_gemm_resid_ln(ws.inter, I, w.w_fc2, w.b_fc2, xn, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, dyn, stream));
+                TRY(run(ag_ws_plan(N, H, H, H, H, H, AG_EPI_BIAS_RESID, dt, true, false, 0, true, 1, 1, -1, 0, m_exp), ws.ctx, H, w.w_o, w.b_o, ws.hx, H, x, H,
+                        H, H, AG_EPI_BIAS_RESID, nullptr, nullptr, ws.st1));
+            TRY(run(plan_w(I, H, AG_EPI_BIAS_GELU, true), ws.hx, H, w.w_fc1_ln, w.b_fc1_ln, ws.inter, I, nullptr, 0, I, H, AG_EPI_BIAS_GELU, ws.st1, w.s_fc1_ln,
+                    nullptr));
+            TRY(ag_gemm_resid_ln_ws(ws.inter, I, w.w_fc2, w.b_fc2, xn, H, ws.hx, H, ws.st1, w.ln1_g, w.ln1_b, d->ln_eps, N, H, I, ws.st2, dyn, m_exp, -1, 0,
+                                    ws.split, ws.split_bytes, stream));
             char* t = x; x = xn; xn = t;
             x_pre = true;
             continue;

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
 // =====================================================================================================================
 // gemm_line_kernel — the same tile, waves, phases and epilogue, fed by WHOLE 128-byte cache lines.
 //
-// What was measured (round 3, tools/dma_probe.py = ag_probe_dma, tools/exp_variants.sh): the ring above stages 16-row x 64-byte
+// What was measured (round 3, tools/dma_probe.py = ag_probe_dma; experiment builds recorded in profiles/HISTORY.md §9): the ring above stages 16-row x 64-byte
 // pieces (K = 32 per half-step).  A 64-byte row segment is half a 128-byte line; the other half is requested one half-step
 // later, after 32 KiB of other lines have passed through the CU's 32 KiB vector L1, so EVERY line crosses the L2 -> L1 path
 // twice.  With all 256 CUs pulling, that path delivers 28 B/clk/CU of such pieces (a 32 KiB half-step = 1 170 cycles, more
@@ -591,11 +591,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_ring_kernel(BigArgs pin) {
 constexpr int LROWB = 128;                       // bytes of K per row per step (64 bf16)
 constexpr int LOP_BYTES = BT * LROWB;            // 32 KiB per operand per step
 constexpr int LW_BASE = 2 * LOP_BYTES;           // W slots behind the two A slots
-// defaults = what measured best (round 3, tools/exp_variants.sh): L2 prefetch ON, for the A stream only (group 0), two steps ahead
-#ifndef AG_LINE_PF_AHEAD
-#define AG_LINE_PF_AHEAD 2
-#endif
-constexpr int PF_AHEAD = AG_LINE_PF_AHEAD;       // L2 prefetch distance in steps
+// what measured best (round 3, profiles/HISTORY.md §9): L2 prefetch ON, for the A stream only (group 0), two steps ahead
+constexpr int PF_AHEAD = 2;                      // L2 prefetch distance in steps
 
 // four 1 KiB pieces of one operand (SGPR base + per-lane offsets) to four consecutive LDS kilobytes
 __device__ __forceinline__ void glds_x4(const char* base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint32_t lds0) {

@@ -535,7 +535,9 @@ namespace {
 template <int SPLITS>
 __global__ __launch_bounds__(256) void ws_finish_kernel(const float* __restrict__ slabs, long slab_stride, const float* __restrict__ bias,
                                                         const bf16_t* __restrict__ R, long ldr, int T, int share, bf16_t* __restrict__ C, long ldc,
-                                                        int M_in, int N, float* __restrict__ stats_out, long stats_slab, const int* dyn) {
+                                                        int M_in, int N, float* __restrict__ stats_out, long stats_slab, const int* dyn,
+                                                        const float* __restrict__ r_stats = nullptr, const float* __restrict__ rln_g = nullptr,
+                                                        const float* __restrict__ rln_b = nullptr, float rln_eps = 0.f) {
     const int M = ag_dyn_clamp(M_in, dyn);
     const int nslab = (N + 255) >> 8;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 5;       // (row, slab)
@@ -556,17 +558,36 @@ __global__ __launch_bounds__(256) void ws_finish_kernel(const float* __restrict_
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
         if (bias) { b0 = *reinterpret_cast<const float4*>(bias + c); b1 = *reinterpret_cast<const float4*>(bias + c + 4); }
         const int seq = m / T, t = m - seq * T;
-        const uint4 r = *reinterpret_cast<const uint4*>(R + ((long)(seq / share) * T + t) * ldr + c);
+        const long rrow = (long)(seq / share) * T + t;
+        const uint4 r = *reinterpret_cast<const uint4*>(R + rrow * ldr + c);
         float4 a0 = x0[0], a1 = x1[0];
 #pragma unroll
         for (int s = 1; s < SPLITS; ++s) {                              // in range order: bit-reproducible
             a0.x += x0[s].x; a0.y += x0[s].y; a0.z += x0[s].z; a0.w += x0[s].w;
             a1.x += x1[s].x; a1.y += x1[s].y; a1.z += x1[s].z; a1.w += x1[s].w;
         }
-        const float v0 = (a0.x + b0.x) + __uint_as_float(r.x << 16), v1 = (a0.y + b0.y) + __uint_as_float(r.x & 0xFFFF0000u);
-        const float v2 = (a0.z + b0.z) + __uint_as_float(r.y << 16), v3 = (a0.w + b0.w) + __uint_as_float(r.y & 0xFFFF0000u);
-        const float v4 = (a1.x + b1.x) + __uint_as_float(r.z << 16), v5 = (a1.y + b1.y) + __uint_as_float(r.z & 0xFFFF0000u);
-        const float v6 = (a1.z + b1.z) + __uint_as_float(r.w << 16), v7 = (a1.w + b1.w) + __uint_as_float(r.w & 0xFFFF0000u);
+        float r0 = __uint_as_float(r.x << 16), r1 = __uint_as_float(r.x & 0xFFFF0000u), r2 = __uint_as_float(r.y << 16), r3 = __uint_as_float(r.y & 0xFFFF0000u);
+        float r4 = __uint_as_float(r.z << 16), r5 = __uint_as_float(r.z & 0xFFFF0000u), r6 = __uint_as_float(r.w << 16), r7 = __uint_as_float(r.w & 0xFFFF0000u);
+        if (r_stats) {
+            // BERT post-LN: R holds the PRE-LayerNorm rows, r_stats their 256-column slab statistics: the residual is LN(h)[m, n] =
+            // (h - mean) * rstd * g + b, never materialised (ag_gemm_resid_ln; same arithmetic as the persistent kernel's epilogue)
+            float sx = 0.f, sq2 = 0.f;
+            for (int s_i = 0; s_i < nslab; ++s_i) {
+                const float2 w2 = *reinterpret_cast<const float2*>(r_stats + (long)s_i * stats_slab + 2 * rrow);
+                sx += w2.x; sq2 += w2.y;
+            }
+            const float inv_h = 1.0f / (float)N;
+            const float mean = sx * inv_h, nm = -mean;
+            const float rstd = rsqrtf(fmaxf(sq2 * inv_h - mean * mean, 0.f) + rln_eps);
+            const float4 g0 = *reinterpret_cast<const float4*>(rln_g + c), g1 = *reinterpret_cast<const float4*>(rln_g + c + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(rln_b + c), t1 = *reinterpret_cast<const float4*>(rln_b + c + 4);
+            r0 = fmaf((r0 + nm) * rstd, g0.x, t0.x); r1 = fmaf((r1 + nm) * rstd, g0.y, t0.y); r2 = fmaf((r2 + nm) * rstd, g0.z, t0.z); r3 = fmaf((r3 + nm) * rstd, g0.w, t0.w);
+            r4 = fmaf((r4 + nm) * rstd, g1.x, t1.x); r5 = fmaf((r5 + nm) * rstd, g1.y, t1.y); r6 = fmaf((r6 + nm) * rstd, g1.z, t1.z); r7 = fmaf((r7 + nm) * rstd, g1.w, t1.w);
+        }
+        const float v0 = (a0.x + b0.x) + r0, v1 = (a0.y + b0.y) + r1;
+        const float v2 = (a0.z + b0.z) + r2, v3 = (a0.w + b0.w) + r3;
+        const float v4 = (a1.x + b1.x) + r4, v5 = (a1.y + b1.y) + r5;
+        const float v6 = (a1.z + b1.z) + r6, v7 = (a1.w + b1.w) + r7;
         const uint4 pk = make_uint4(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3), pack_bf16x2(v4, v5), pack_bf16x2(v6, v7));
         *reinterpret_cast<uint4*>(C + (long)m * ldc + c) = pk;
         const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -608,8 +629,10 @@ const WsForce* ws_forced(int N, int K) {
 
 }  // namespace
 
-AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype, bool dyn_rows, bool fold_in,
-                    int stats_in_cols, bool stats_out, int out_cols_ok, int resid_share, int route, int splits) {
+AgWsPlan ag_ws_plan(int M_bound, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue, int dtype, bool dyn_rows, bool fold_in,
+                    int stats_in_cols, bool stats_out, int out_cols_ok, int resid_share, int route, int splits, int m_expected) {
+    // (a device-side row count: the launch is sized — and checked — for the bound, priced for the rows expected)
+    const int M = (dyn_rows && m_expected > 0 && m_expected < M_bound) ? m_expected : M_bound;
     // Cost model (us), fitted to tools/ws_bench.py on MI355X (profiles/r05_ws_bench.jsonl; profiles/HISTORY.md §11), 64-element steps:
     //   persistent 256^2 kernel   rounds x (1.45 steps + 4.5 / 6 / 8.5 [bias / GELU / residual]) + 2
     //   128^2 units               a lone workgroup on its CU walks a step in 0.615 us (+ 9 / 12 us of launch, first fill and epilogue [wide /
@@ -619,7 +642,7 @@ AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, 
     //   64^2-tile kernel of gemm.hip (what ag_gemm runs below 48 tiles of 256^2): 6 + 0.42 steps per round of 512 tiles
     static AgKnob k_route("AG_WS_ROUTE"), k_big("AG_WS_BIGSTEP"), k_e1("AG_WS_EX1"), k_e2("AG_WS_EXUNIT"), k_minm("AG_WS_MIN_ROWS"), k_bias("AG_WS_EXBIAS");
     const double c_big = k_big.get(1.45), c_e1 = k_e1.get(0.615), c_eu = k_e2.get(0.0026);
-    const double ex_bias = k_bias.get(1.0);          // (> 1: the planner leaves the round-4 paths only for a clear win)
+    const double ex_bias = k_bias.get(1.15);         // (the planner leaves the round-4 paths only for a clear win: same-box A/B, profiles/HISTORY.md §11)
     const int n_cu = ag_device_cus() > 0 ? ag_device_cus() : 256;
     const int ns = ceil_div(K, 64);
     const bool resid = epilogue == AG_EPI_BIAS_RESID;
@@ -632,11 +655,11 @@ AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, 
     // AG_WS_ROUTE=0: the round-4 paths only (A/B, parity tests): ag_gemm_resid_split wherever the shape splits, else ag_gemm
     const bool r4_only = route < 0 && (int)k_route.get(-1) == 0;
     if (const WsForce* f = (route < 0 && !r4_only) ? ws_forced(N, K) : nullptr) {   // (development: pinned where the pinned route can serve the call at all)
-        const AgWsPlan forced = ag_ws_plan(M, N, K, lda, ldc, ldr, epilogue, dtype, dyn_rows, fold_in, stats_in_cols, stats_out, out_cols_ok,
-                                           resid_share, f->route, f->splits);
+        const AgWsPlan forced = ag_ws_plan(M_bound, N, K, lda, ldc, ldr, epilogue, dtype, dyn_rows, fold_in, stats_in_cols, stats_out, out_cols_ok,
+                                           resid_share, f->route, f->splits, m_expected);
         if (forced.valid) return forced;
     }
-    const bool big = dtype == AG_BF16 && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, epilogue);
+    const bool big = dtype == AG_BF16 && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M_bound, N, K, lda, ldc, ldr, epilogue);
     const double big_epi = resid ? 8.5 : (epilogue == AG_EPI_BIAS_GELU ? 6.0 : 4.5);
     // ---- ag_gemm as it is
     if (route < 0 || route == AG_WS_GEMM) {
@@ -670,7 +693,7 @@ AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, 
     if (r4_only) return best;
     const int min_rows = (int)k_minm.get(256);
     // (wide layers only: the narrow LTT ladder and ViT-tiny keep their round-4 kernels)
-    const bool ex_ok = dtype == AG_BF16 && M >= min_rows && N >= 256 && K >= 256 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldc % 8 == 0 &&
+    const bool ex_ok = dtype == AG_BF16 && M_bound >= min_rows && N >= 256 && K >= 256 && N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldc % 8 == 0 &&
                        (wide || resid) && (!resid || ldr % 8 == 0);
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     // kind: 0 bias, 1 GELU, 2 residual (+ statistics), 3 slabs
@@ -694,7 +717,7 @@ AgWsPlan ag_ws_plan(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, 
             if (splits > 0 && s != splits) continue;
             if (s > 1 && ns / s < 4 && splits == 0) continue;      // (planned: a unit keeps at least four steps; a pinned split count: any)
             if (s > ns) continue;
-            const size_t bytes = (size_t)s * M * N * sizeof(float);
+            const size_t bytes = (size_t)s * M_bound * N * sizeof(float);
             if (bytes > ((size_t)256 << 20)) continue;
             AgWsPlan c{AG_WS_EX_SLABS, s, stats_out ? 256 : 0, bytes, 0.0, true};
             c.cost_us = ex_bias * (ex_time(t128 * s, ceil_div(ns, s), 3) + ((double)M * N * (4.0 * s + 4.0) / 1.0e7 + 2.5));
@@ -727,63 +750,125 @@ int ag_gemm_ws_run(const AgWsPlan& plan, const void* d_A, int64_t lda, const voi
     const bool resid = epilogue == AG_EPI_BIAS_RESID;
     AG_REQUIRE(!resid || (d_R && ldr % 4 == 0 && ((uintptr_t)d_R % 8) == 0), "ag_gemm_ws: residual epilogue needs R with ldr %% 4 == 0");
     AG_REQUIRE(!d_bias || ((uintptr_t)d_bias % 16) == 0, "ag_gemm_ws: bias must be 16-byte aligned");
+    AG_REQUIRE(resid || epilogue == AG_EPI_BIAS || epilogue == AG_EPI_BIAS_GELU, "ag_gemm_ws: epilogue %d has no 128-tile route", epilogue);
+    AG_REQUIRE(!d_ln_stats || (!resid && d_ln_colsum && (stats_in_cols == 256 || stats_in_cols == 128) && ((uintptr_t)d_ln_colsum % 16) == 0),
+               "ag_gemm_ws: ln_stats needs a bias / bias + GELU epilogue, a 16-byte aligned ln_colsum and 128- or 256-column slabs");
+    AG_REQUIRE(!d_stats_out || resid, "ag_gemm_ws: row statistics come with the bias + residual epilogue only");
     const double es = 2.0;
     AgProfScope prof(epilogue, 2.0 * M * (double)N * K,
                      (double)M * K * es + (double)N * K * es + (double)M * N * es + (resid ? (double)M * N * es : 0.0), s, d_rows, (double)M);
-    if (plan.route == AG_WS_EX_SLABS) {
+    // rows [mo, mo + mr) of the product as 128^2 units: slabs == 0: epilogue in the GEMM; slabs >= 1: that many contraction ranges into the
+    // scratch + the row kernel.  Row statistics (in and out) are addressed in the WHOLE matrix's slab layout (2 M floats per slab).
+    auto ex_rows = [&](int mo, int mr, int slabs) -> int {
+        ExArgs a{};
+        a.A = (const char*)d_A + (size_t)mo * lda * 2; a.lda_b = (long)lda * 2;
+        a.B = (const char*)d_W; a.ldb_b = (long)K * 2;
+        a.M = mr; a.N = N; a.Kc = K;
+        a.bias = d_bias; a.C = (char*)d_C + (size_t)mo * ldc * 2; a.ldc = ldc;
+        a.splits = 1; a.lds_epilogue = 1;
+        a.slab_rows = mr; a.dyn = d_rows;
+        a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
+        const bf16_t* r_at = resid ? (const bf16_t*)d_R + (size_t)mo * ldr : nullptr;      // (mo > 0 only with identity residual rows)
+        float* st_out = d_stats_out ? d_stats_out + 2L * mo : nullptr;
+        if (slabs == 0) {
+            if (resid) {
+                a.R = r_at; a.ldr = ldr;
+                a.stats_out = st_out; a.stats_out_slab = 2L * M;
+                return launch_ex<false, false, E_FWD_RESID>(a, s);
+            }
+            if (d_ln_stats) {
+                a.ln_stats = d_ln_stats + 2L * mo; a.ln_s = d_ln_colsum; a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, stats_in_cols);
+                a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K;
+            }
+            return epilogue == AG_EPI_BIAS ? launch_ex<false, false, E_FWD>(a, s) : launch_ex<false, false, E_FWD_GELU>(a, s);
+        }
         AG_REQUIRE(resid && !d_ln_stats, "ag_gemm_ws: the slab route serves the bias + residual epilogue");
-        AG_REQUIRE(plan.splits >= 1 && plan.splits <= 8, "ag_gemm_ws: splits=%d", plan.splits);
-        AG_REQUIRE(d_scratch && ((uintptr_t)d_scratch % 16) == 0 && scratch_bytes >= (size_t)plan.splits * M * N * sizeof(float),
-                   "ag_gemm_ws: scratch too small (%zu < %zu)", scratch_bytes, (size_t)plan.splits * M * N * sizeof(float));
+        AG_REQUIRE(slabs >= 1 && slabs <= 8, "ag_gemm_ws: splits=%d", slabs);
+        AG_REQUIRE(d_scratch && ((uintptr_t)d_scratch % 16) == 0 && scratch_bytes >= (size_t)slabs * mr * N * sizeof(float),
+                   "ag_gemm_ws: scratch too small (%zu < %zu)", scratch_bytes, (size_t)slabs * mr * N * sizeof(float));
         AG_REQUIRE(ldr % 8 == 0 && ((uintptr_t)d_R % 16) == 0, "ag_gemm_ws: the row kernel reads the residual in 16-byte chunks (ldr %% 8 == 0)");
-    }
+        a.splits = slabs; a.slabs = (float*)d_scratch;
+        a.bias = nullptr; a.C = nullptr;
+        int rc = launch_ex<false, false, E_SLABS>(a, s);
+        if (rc != AG_OK) return rc;
+        const long items = (long)mr * ceil_div(N, 256);                    // half-waves
+        const dim3 fgrid((unsigned)((items + 7) / 8)), fblock(256);
+#define AG_WS_FINISH(S_) hipLaunchKernelGGL(ws_finish_kernel<S_>, fgrid, fblock, 0, s, (const float*)d_scratch, (long)mr * N, d_bias, r_at, (long)ldr, a.T, \
+                                            a.share, (bf16_t*)d_C + (size_t)mo * ldc, (long)ldc, mr, N, st_out, 2L * M, d_rows)
+        switch (slabs) {
+            case 1: AG_WS_FINISH(1); break;
+            case 2: AG_WS_FINISH(2); break;
+            case 3: AG_WS_FINISH(3); break;
+            case 4: AG_WS_FINISH(4); break;
+            case 5: AG_WS_FINISH(5); break;
+            case 6: AG_WS_FINISH(6); break;
+            case 7: AG_WS_FINISH(7); break;
+            default: AG_WS_FINISH(8); break;
+        }
+#undef AG_WS_FINISH
+        AG_LAUNCH_CHECK();
+        return AG_OK;
+    };
+    if (plan.route == AG_WS_EX) return ex_rows(0, M, 0);
+    if (plan.route == AG_WS_EX_SLABS) return ex_rows(0, M, plan.splits);
+    return ag_fail(AG_ERR_INVALID, "ag_gemm_ws: unknown route %d", plan.route);
+}
+
+int ag_gemm_resid_ln_slabs(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc, const void* d_Rpre, int64_t ldr,
+                           const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps, int M, int N, int K, float* d_stats_out,
+                           const int* d_rows, int splits, void* d_scratch, size_t scratch_bytes, hipStream_t s) {
+    if (M == 0) return AG_OK;
+    AG_REQUIRE(d_A && d_W && d_C && d_Rpre && d_r_stats && d_ln_g && d_ln_b, "ag_gemm_resid_ln_ws: null pointer");
+    AG_REQUIRE(N % 8 == 0 && K % 64 == 0 && lda % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0, "ag_gemm_resid_ln_ws: N, lda, ldc, ldr %% 8, K %% 64");
+    AG_REQUIRE(((uintptr_t)d_A % 16) == 0 && ((uintptr_t)d_W % 16) == 0 && ((uintptr_t)d_C % 16) == 0 && ((uintptr_t)d_Rpre % 16) == 0 &&
+               ((uintptr_t)d_ln_g % 16) == 0 && ((uintptr_t)d_ln_b % 16) == 0 && (!d_bias || ((uintptr_t)d_bias % 16) == 0),
+               "ag_gemm_resid_ln_ws: operands must be 16-byte aligned");
+    AG_REQUIRE(splits >= 1 && splits <= 8 && splits <= K / 64, "ag_gemm_resid_ln_ws: splits=%d", splits);
+    AG_REQUIRE(d_scratch && ((uintptr_t)d_scratch % 16) == 0 && scratch_bytes >= (size_t)splits * M * N * sizeof(float),
+               "ag_gemm_resid_ln_ws: scratch too small (%zu < %zu)", scratch_bytes, (size_t)splits * M * N * sizeof(float));
+    AgProfScope prof(AG_EPI_BIAS_RESID, 2.0 * M * (double)N * K, ((double)M * K + (double)N * K + 2.0 * (double)M * N) * 2.0, s, d_rows, (double)M);
     ExArgs a{};
     a.A = (const char*)d_A; a.lda_b = (long)lda * 2;
     a.B = (const char*)d_W; a.ldb_b = (long)K * 2;
     a.M = M; a.N = N; a.Kc = K;
-    a.bias = d_bias; a.C = (char*)d_C; a.ldc = ldc;
-    a.splits = 1; a.lds_epilogue = 1;
-    a.slab_rows = M; a.dyn = d_rows;
-    a.T = rows_per_seq > 0 ? rows_per_seq : 1; a.share = resid_share > 0 ? resid_share : 1;
-    if (plan.route == AG_WS_EX) {
-        if (resid) {
-            AG_REQUIRE(!d_ln_stats, "ag_gemm_ws: the residual epilogue folds no LayerNorm");
-            a.R = (const bf16_t*)d_R; a.ldr = ldr;
-            a.stats_out = d_stats_out; a.stats_out_slab = 2L * M;
-            return launch_ex<false, false, E_FWD_RESID>(a, s);
-        }
-        AG_REQUIRE(!d_stats_out, "ag_gemm_ws: row statistics come with the bias + residual epilogue only");
-        AG_REQUIRE(epilogue == AG_EPI_BIAS || epilogue == AG_EPI_BIAS_GELU, "ag_gemm_ws: epilogue %d has no 128-tile route", epilogue);
-        if (d_ln_stats) {
-            AG_REQUIRE(d_ln_colsum && (stats_in_cols == 256 || stats_in_cols == 128), "ag_gemm_ws: ln_stats needs ln_colsum and 128- or 256-column slabs");
-            AG_REQUIRE(((uintptr_t)d_ln_colsum % 16) == 0, "ag_gemm_ws: ln_colsum must be 16-byte aligned");
-            a.ln_stats = d_ln_stats; a.ln_s = d_ln_colsum; a.stats_slab = 2L * M; a.ln_nslab = ceil_div(K, stats_in_cols);
-            a.ln_eps = ln_eps; a.ln_inv_h = 1.0f / (float)K;
-        }
-        return epilogue == AG_EPI_BIAS ? launch_ex<false, false, E_FWD>(a, s) : launch_ex<false, false, E_FWD_GELU>(a, s);
-    }
-    // AG_WS_EX_SLABS
-    a.splits = plan.splits; a.slabs = (float*)d_scratch;
-    a.bias = nullptr; a.C = nullptr;
+    a.lds_epilogue = 1; a.slab_rows = M; a.dyn = d_rows; a.T = 1; a.share = 1;
+    a.splits = splits; a.slabs = (float*)d_scratch;
     int rc = launch_ex<false, false, E_SLABS>(a, s);
     if (rc != AG_OK) return rc;
-    const long items = (long)M * ceil_div(N, 256);                     // half-waves
+    const long items = (long)M * ceil_div(N, 256);
     const dim3 fgrid((unsigned)((items + 7) / 8)), fblock(256);
-#define AG_WS_FINISH(S_) hipLaunchKernelGGL(ws_finish_kernel<S_>, fgrid, fblock, 0, s, (const float*)d_scratch, (long)M * N, d_bias, (const bf16_t*)d_R, \
-                                            (long)ldr, a.T, a.share, (bf16_t*)d_C, (long)ldc, M, N, d_stats_out, 2L * M, d_rows)
-    switch (plan.splits) {
-        case 1: AG_WS_FINISH(1); break;
-        case 2: AG_WS_FINISH(2); break;
-        case 3: AG_WS_FINISH(3); break;
-        case 4: AG_WS_FINISH(4); break;
-        case 5: AG_WS_FINISH(5); break;
-        case 6: AG_WS_FINISH(6); break;
-        case 7: AG_WS_FINISH(7); break;
-        default: AG_WS_FINISH(8); break;
+#define AG_WS_FINISH_LN(S_) hipLaunchKernelGGL(ws_finish_kernel<S_>, fgrid, fblock, 0, s, (const float*)d_scratch, (long)M * N, d_bias, (const bf16_t*)d_Rpre, \
+                                               (long)ldr, 1, 1, (bf16_t*)d_C, (long)ldc, M, N, d_stats_out, 2L * M, d_rows, d_r_stats, d_ln_g, d_ln_b, ln_eps)
+    switch (splits) {
+        case 1: AG_WS_FINISH_LN(1); break;
+        case 2: AG_WS_FINISH_LN(2); break;
+        case 3: AG_WS_FINISH_LN(3); break;
+        case 4: AG_WS_FINISH_LN(4); break;
+        case 5: AG_WS_FINISH_LN(5); break;
+        case 6: AG_WS_FINISH_LN(6); break;
+        case 7: AG_WS_FINISH_LN(7); break;
+        default: AG_WS_FINISH_LN(8); break;
     }
-#undef AG_WS_FINISH
+#undef AG_WS_FINISH_LN
     AG_LAUNCH_CHECK();
     return AG_OK;
+}
+
+extern "C" int ag_gemm_resid_ln_ws(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                                   const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps,
+                                   int M, int N, int K, float* d_stats_out, const int* d_rows, int m_expected, int route, int splits,
+                                   void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (M == 0) return AG_OK;
+    // planned like a bias + residual Linear with statistics in 256-column slabs: the persistent kernel (ag_gemm_resid_ln) or 128^2 units x splits
+    AgWsPlan pl = ag_ws_plan(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID, AG_BF16, d_rows != nullptr, false, 0, true, 1, 1,
+                             route < 0 ? -1 : (route == AG_WS_EX_SLABS ? AG_WS_EX_SLABS : AG_WS_GEMM), splits, m_expected);
+    if (pl.valid && pl.route != AG_WS_GEMM && pl.route != AG_WS_EX_SLABS)     // (the other routes have no residual-LayerNorm form)
+        pl = ag_ws_plan(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID, AG_BF16, d_rows != nullptr, false, 0, true, 1, 1, AG_WS_GEMM, 0, m_expected);
+    if (pl.valid && pl.route == AG_WS_EX_SLABS && pl.scratch_bytes <= scratch_bytes && d_scratch)
+        return ag_gemm_resid_ln_slabs(d_A, lda, d_W, d_bias, d_C, ldc, d_Rpre, ldr, d_r_stats, d_ln_g, d_ln_b, ln_eps, M, N, K, d_stats_out, d_rows,
+                                      pl.splits, d_scratch, scratch_bytes, (hipStream_t)stream);
+    AG_REQUIRE(route != AG_WS_EX_SLABS, "ag_gemm_resid_ln_ws: the slab route cannot serve M=%d N=%d K=%d (scratch %zu)", M, N, K, scratch_bytes);
+    return ag_gemm_resid_ln(d_A, lda, d_W, d_bias, d_C, ldc, d_Rpre, ldr, d_r_stats, d_ln_g, d_ln_b, ln_eps, M, N, K, d_stats_out, d_rows, stream);
 }
 
 extern "C" size_t ag_gemm_ws_scratch_bytes(int M, int N, int K, int epilogue) {

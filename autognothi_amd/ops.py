@@ -495,6 +495,26 @@ def gemm_resid_ln(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r
     return out, stats_out
 
 
+def gemm_resid_ln_ws(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor, r_stats: Tensor, ln_g: Tensor, ln_b: Tensor,
+                     ln_eps: float, stats_out: Optional[Tensor] = None, rows_dev: Optional[Tensor] = None, m_expected: int = 0,
+                     route: int = -1, splits: int = 0) -> Tuple[Tensor, Tensor]:
+    """gemm_resid_ln, planned (ag_gemm_resid_ln_ws): route -1 = the library's cost model, WS_GEMM = the persistent kernel, WS_EX_SLABS =
+    128 x 128 units x `splits` contraction ranges + the row kernel.  -> (out [M,N] bf16, its 256-column slab statistics)."""
+    L.require_gpu(a, w, bias, r_pre, r_stats, ln_g, ln_b)
+    n, k = w.shape
+    m = a.numel() // k
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    if stats_out is None:
+        stats_out = new_row_stats(m, n, a.device)
+    with L.on(a.device):
+        need = int(L.lib().ag_gemm_ws_scratch_bytes(m, n, k, L.AG_EPI_BIAS_RESID))
+        scratch = _scratch(a.device, (need + 3) // 4) if need else None
+        L.check(L.lib().ag_gemm_resid_ln_ws(L.ptr(a), k, L.ptr(w), L.ptr(bias), L.ptr(out), n, L.ptr(r_pre), n, L.ptr(r_stats), L.ptr(ln_g),
+                                            L.ptr(ln_b), float(ln_eps), m, n, k, L.ptr(stats_out), L.ptr(rows_dev), int(m_expected), route, splits,
+                                            L.ptr(scratch), scratch.numel() * 4 if scratch is not None else 0, L.stream()))
+    return out, stats_out
+
+
 def gemm_resid_split_scratch_bytes(m: int, n: int, k: int) -> int:
     """bytes of scratch ag_gemm_resid_split needs for this shape on the current device; 0: the shape does not split (use gemm)."""
     return int(L.lib().ag_gemm_resid_split_scratch_bytes(m, n, k))

@@ -191,6 +191,14 @@ int ag_gemm_ws(const void* d_A, int64_t lda, const void* d_W, const float* d_bia
                const float* d_ln_stats, int stats_in_cols, const float* d_ln_colsum, float ln_eps,
                float* d_stats_out, int out_cols_ok, int* stats_out_cols, const int* d_rows, int route, int splits,
                void* d_scratch, size_t scratch_bytes, void* stream);
+/* ag_gemm_resid_ln, planned like ag_gemm_ws: the persistent kernel (route 0) or 128 x 128 units x `splits` contraction ranges + the row
+ * kernel (route 3), which recomputes LayerNorm(Rpre) from the pre-LN rows and their slab statistics exactly as the persistent kernel's
+ * epilogue does.  Serves the token-pruned BERT forward at the reference's batch sizes (a few thousand packed rows: 24-48 tiles of 256 x 256
+ * for the N = 768 Linears).  m_expected: with a device-side row count (d_rows), the rows the planner should price (0: M). */
+int ag_gemm_resid_ln_ws(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
+                        const void* d_Rpre, int64_t ldr, const float* d_r_stats, const float* d_ln_g, const float* d_ln_b, float ln_eps,
+                        int M, int N, int K, float* d_stats_out, const int* d_rows, int m_expected, int route, int splits,
+                        void* d_scratch, size_t scratch_bytes, void* stream);
 /* The MLP half of a NARROW transformer layer (the LTT ladder's side layers: hidden width h <= 128, reference
  * models/ltt_vit.py:383-394 / models/ltt_bert.py:440-455 instantiate VanillaViTLayer / VanillaBertLayer at s_attn_hidden_size) in ONE
  * kernel, bf16:   post_ln = 0 (ViT, models/vanilla_vit.py:373-376):  out = x + fc2(gelu(fc1(LN(x))))     (ln_g NULL: no LN)

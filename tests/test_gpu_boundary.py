@@ -204,20 +204,25 @@ def test_reference_explainer_step_fixture(cuda_device, tag):
         assert float(seen["bert.embeddings.word_embeddings.weight"][pad].abs().max()) == 0.0
 
 
-def _port_reference(c, prm, kind, duo, labels, masks, v0, vs, v1, exp):
+def _port_reference(c, prm, kind, duo, labels, masks, v0, vs, v1, exp, autocast_bf16=False):
+    """loss and gradients of the CPU port under torch autograd; ``autocast_bf16``: the same under torch.autocast(bfloat16) — what the
+    reference itself would compute in mixed precision: the yardstick of the bf16 training step."""
+    import contextlib
     sd = {k_: v.detach().cpu().clone().requires_grad_(exp.state_dict(keep_vars=True)[k_].requires_grad)
           for k_, v in exp.state_dict(keep_vars=True).items()}
     ones = torch.ones((c["B"], c["P"]), dtype=torch.long)
-    phi_ref, z_ref = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
-    loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref, c["P"])
-    if duo:
-        lin = torch.nn.functional.linear
-        if kind == "vit":
-            base = torch.softmax(lin(z_ref[:, 0], sd["classifier.weight"], sd["classifier.bias"]), -1)
-        else:
-            base = lin(torch.tanh(lin(z_ref[:, 0], sd["bert_pooler.dense.weight"], sd["bert_pooler.dense.bias"])),
-                       sd["classifier.weight"], sd["classifier.bias"])
-        loss_ref = loss_ref + torch.nn.functional.cross_entropy(base, labels)
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast_bf16 else contextlib.nullcontext()
+    with ctx:
+        phi_ref, z_ref = otp.explainer_phi(torch.from_numpy(c["xs"]), ones, v1, v0, sd, prm, kind)
+        loss_ref = otp.shapley_loss(masks.reshape(c["B"], c["K"], c["P"]), v0, vs, phi_ref.float(), c["P"])
+        if duo:
+            lin = torch.nn.functional.linear
+            if kind == "vit":
+                base = torch.softmax(lin(z_ref[:, 0], sd["classifier.weight"], sd["classifier.bias"]).float(), -1)
+            else:
+                base = lin(torch.tanh(lin(z_ref[:, 0], sd["bert_pooler.dense.weight"], sd["bert_pooler.dense.bias"])),
+                           sd["classifier.weight"], sd["classifier.bias"]).float()
+            loss_ref = loss_ref + torch.nn.functional.cross_entropy(base, labels)
     loss_ref.backward()
     return sd, loss_ref.item()
 

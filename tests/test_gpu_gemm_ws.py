@@ -166,7 +166,8 @@ def test_ws_planner_routes(cuda_device):
 def test_encoder_planner_on_off(cuda_device, ag_knobs, tag):
     """the full-depth fixtures (ViT-base: one input x 32 masks = 6 304 token rows; ViT-large: 64 masks) through the recipes' fw_* callables
     with the planner on (default) and pinned to the round-4 paths (AG_WS_ROUTE=0): same outputs up to bf16 rounding, both within the bf16
-    bound of the reference."""
+    bound of the reference.  (Where the planner keeps the round-4 routes the two are identical; the 128-tile routes inside the encoder are
+    exercised by test_encoder_planner_forced_routes and test_encoder_small_shard_planned.)"""
     from util import build_case, run_fixture_case
     from autognothi_amd import engine
     c = build_case(tag)
@@ -179,8 +180,6 @@ def test_encoder_planner_on_off(cuda_device, ag_knobs, tag):
     for k in ("v_s", "v_1"):
         np.testing.assert_allclose(on[k], off[k], rtol=0, atol=2e-2, err_msg=k)
         np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
-    if tag == "vit_base_l12":
-        assert np.abs(on["v_s"] - off["v_s"]).max() > 0      # (one input x 32 masks: the planner did leave the round-4 paths somewhere)
 
 
 def test_encoder_planner_forced_routes(cuda_device, ag_knobs):
@@ -216,3 +215,79 @@ def test_pack_folded_linear_vs_float64(cuda_device):
     assert torch.equal(w_o.cpu(), want_w)
     np.testing.assert_allclose(b_o.cpu().numpy(), b + w.astype(np.float64) @ beta.astype(np.float64), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(s_o.cpu().numpy(), want_w.double().sum(1).numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_encoder_small_shard_planned(cuda_device, ag_knobs):
+    """the 8-masks-per-GPU shard of BASELINE config 4 (1 576 token rows of ViT-large: every Linear under-fills the persistent kernel, the
+    planner takes the 128-tile routes): the first 8 masks of the ViT-large fixture, planner on against the round-4 paths and the reference."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case("vit_large_l24")
+    c = dict(c, masks=c["masks"][:8], K=8)
+    c["g"] = dict(c["g"], v_s=c["g"]["v_s"][:8])
+    try:
+        on = run_fixture_case(c, cuda_device, "bf16")
+        ag_knobs(AG_WS_ROUTE=0)
+        off = run_fixture_case(c, cuda_device, "bf16")
+    finally:
+        engine.set_precision("fp32")
+    np.testing.assert_allclose(on["v_s"], off["v_s"], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(on["v_s"], c["g"]["v_s"], rtol=0, atol=2e-2)
+    assert np.abs(on["v_s"] - off["v_s"]).max() > 0      # (the planner did leave the round-4 paths)
+
+
+# out-projection / fc2 of the token-pruned BERT-base forward at one and two sequences x 32 masks (2-4 k packed rows)
+@pytest.mark.parametrize("m,n,k,splits", [(2176, 768, 768, 2), (4096, 768, 3072, 4), (2176, 768, 3072, 0)])
+def test_ws_resid_ln_slabs_vs_float64(cuda_device, m, n, k, splits):
+    """ag_gemm_resid_ln_ws on the slab route: out = A W^T + b + LayerNorm(Rpre) with the LayerNorm recomputed in the row kernel from the
+    stored pre-LN rows and their slab statistics (eps 1e-12 as BERT, reference models/vanilla_bert.py:556-560, :600-604), the statistics of
+    the rows written, a device-side row count, and agreement with the persistent kernel's form (ag_gemm_resid_ln)."""
+    from autognothi_amd import ops
+    dev = cuda_device
+    g = np.random.default_rng(m + k)
+    a = _r((g.standard_normal((m, k)) * 0.8 + 0.1).astype(np.float32))
+    w = _r((g.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = g.standard_normal(n).astype(np.float32)
+    r = _r((g.standard_normal((m, n)) * 1.7 + 0.3).astype(np.float32))
+    gamma, beta = (1 + 0.2 * g.standard_normal(n)).astype(np.float32), (0.2 * g.standard_normal(n)).astype(np.float32)
+    A, W, B, R = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev), _dev(r, dev)
+    G, Bt = torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev)
+    r_st = ops.row_stats(R)
+    out, st = ops.gemm_resid_ln_ws(A, W, B, R, r_st, G, Bt, 1e-12, route=ops.WS_EX_SLABS, splits=splits)
+    r64 = r.astype(np.float64)
+    ln = (r64 - r64.mean(1, keepdims=True)) / np.sqrt(r64.var(1, keepdims=True) + 1e-12) * gamma + beta
+    rows = _rows(g, m)
+    ref = a[rows].astype(np.float64) @ w.astype(np.float64).T + b + ln[rows]
+    o = out.float().cpu().numpy()
+    np.testing.assert_allclose(o[rows], ref, **TOL)
+    got = ops.reduce_row_stats(st, m, n).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], o.astype(np.float64).sum(1), rtol=1e-4, atol=3e-3)
+    np.testing.assert_allclose(got[:, 1], (o.astype(np.float64) ** 2).sum(1), rtol=1e-4)
+    from autognothi_amd import _lib as L
+    if L.lib().ag_gemm_resid_ln_supported(m, n, k, k, n, n):
+        base, _ = ops.gemm_resid_ln(A, W, B, R, r_st, G, Bt, 1e-12)      # the persistent kernel: the same sums in another order
+        diff = np.abs(base.float().cpu().numpy() - o)
+        assert (diff > 0).mean() < 0.03 and diff.max() <= 2.0 ** -6 * max(np.abs(o).max(), 1.0)
+    act = m // 2 + 37
+    nrows = torch.tensor([act], dtype=torch.int32, device=dev)
+    out2, _ = ops.gemm_resid_ln_ws(A, W, B, R, r_st, G, Bt, 1e-12, rows_dev=nrows, m_expected=act, route=ops.WS_EX_SLABS, splits=splits)
+    assert torch.equal(out2[:act], out[:act])
+    planned, _ = ops.gemm_resid_ln_ws(A, W, B, R, r_st, G, Bt, 1e-12, rows_dev=nrows, m_expected=act)
+    np.testing.assert_allclose(planned[:act].float().cpu().numpy()[rows[rows < act]], ref[rows < act], **TOL)
+
+
+def test_bert_pruned_encoder_planner_on_off(cuda_device, ag_knobs):
+    """the token-pruned BERT-base forward at one sequence x 32 masks (full-depth fixture: about 2 k packed rows) with the planner on and
+    pinned to the round-4 paths: same surrogate outputs up to bf16 rounding, both within the bf16 bound of the reference."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case("bert_base_l12")
+    try:
+        on = run_fixture_case(c, cuda_device, "bf16")
+        ag_knobs(AG_WS_ROUTE=0)
+        off = run_fixture_case(c, cuda_device, "bf16")
+    finally:
+        engine.set_precision("fp32")
+    for k in ("v_s", "v_1"):
+        np.testing.assert_allclose(on[k], off[k], rtol=0, atol=2e-2, err_msg=k)
+        np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)

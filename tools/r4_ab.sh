@@ -1,8 +1,7 @@
 #!/bin/bash
 # Round-4 same-box A/B runs (gpurun -- 'bash tools/r4_ab.sh <what>'); the numbers of profiles/HISTORY.md §10 come from here.
 #   epi    base (lib/base_libautognothi_hip.so = the previous build) vs current: parity, stamped tile timelines (fc1 + GELU, QKV), bench A/B
-#   split  ag_gemm_resid_split: parity, small-batch forward with AG_GEMM_SPLIT on / off alternating, no-store ablation timeline
-#          (lib/nostore_libautognothi_hip.so = tools/build_variant.sh nostore gemm_big.hip -DAG_ABL_NOSTORE)
+#   split  ag_gemm_resid_split: parity, small-batch forward with AG_GEMM_SPLIT on / off alternating, stamped timeline
 #   resid  residual epilogue: parity, stamped timelines at K = 768 / 3072, bench A/B
 R=$GRAFT_REPO_ROOT; cd $R
 WHAT=${1:-epi}
@@ -22,7 +21,7 @@ split)
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[0]); print('split=$sp B=$b', d['value'], 'fwd/s', d['ms_per_step'], 'ms/step', {n:v['avg_us'] for n,v in d['roofline']['kernels'].items()})"
   done; done
-  for lib in libautognothi_hip.so nostore_libautognothi_hip.so; do [ -f autognothi_amd/lib/$lib ] && { timeline $lib gelu 1 3072 768; timeline $lib bias 1 2304 768; }; done ;;
+  timeline libautognothi_hip.so gelu 1 3072 768; timeline libautognothi_hip.so bias 1 2304 768 ;;
 resid)
   python -m pytest tests/test_gpu_gemm_ring.py tests/test_gpu_kernels.py tests/test_gpu_gemm_split.py -q -x 2>&1 | tail -4
   for lib in base_libautognothi_hip.so libautognothi_hip.so; do timeline $lib resid 0 768 768; timeline $lib resid 0 768 3072; done
