@@ -10,6 +10,22 @@ import ctypes as C
 import os
 from typing import Optional
 
+def _hip_touched() -> bool:
+    try:
+        import torch
+        return bool(torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# Did the host program use the GPU before this package was imported?  Then the package's background stream (below) cannot have been the
+# process's first second stream, and whether it runs beside or behind the caller's is out of this package's hands — measured (round 5,
+# tests/test_gpu_scripts.py): five foreign streams + one captured graph before the first launch: two-stream epoch 372 images/s against 510 on
+# one stream, with two idle waves on the two streams running perfectly beside each other (the yes / no probe says yes: it sees the hardware
+# queues, not what the dispatcher does with 400 dependent launches beside a persistent kernel).  The two-stream epoch is therefore the
+# default only in a process where this import came first (scripts/common.train_partition); AG_TRAIN_PARTITION=<n> forces it.
+HIP_TOUCHED_BEFORE_IMPORT = _hip_touched()
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AG_HIP_LIB") or os.path.join(_HERE, "lib", "libautognothi_hip.so")   # AG_HIP_LIB: A/B another build
 

@@ -22,8 +22,8 @@ int ag_fail(int code, const char* fmt, ...) {
 
 extern "C" int ag_abi_version(void) { return AG_ABI_VERSION; }
 
-long long g_ag_launch_count = 0;
-extern "C" int64_t ag_launch_count(void) { return (int64_t)g_ag_launch_count; }
+std::atomic<long long> g_ag_launch_count{0};   // (launches come from any host thread: relaxed increments)
+extern "C" int64_t ag_launch_count(void) { return (int64_t)g_ag_launch_count.load(std::memory_order_relaxed); }
 
 // How many CUs the persistent large-M GEMM may take on a stream (ag_set_stream_cus: the two-stream training epoch, CU-masked streams).
 // Everything else launches ordinary grids and needs no hint.

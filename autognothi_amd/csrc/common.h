@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/autognothi_hip.h"
@@ -23,10 +24,10 @@ int ag_stream_cus(hipStream_t s);   // capi.cpp: CUs of a CU-masked stream regis
         if (_e != hipSuccess)                                                                      \
             return ag_fail(AG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
-extern long long g_ag_launch_count;   // capi.cpp: kernels this library has launched (ag_launch_count)
+extern std::atomic<long long> g_ag_launch_count;   // capi.cpp: kernels this library has launched (ag_launch_count)
 #define AG_LAUNCH_CHECK()                      \
     do {                                       \
-        ++g_ag_launch_count;                   \
+        g_ag_launch_count.fetch_add(1, std::memory_order_relaxed); \
         AG_HIP_CHECK(hipGetLastError());       \
     } while (0)
 #define AG_REQUIRE(cond, ...)                                                                      \

@@ -187,11 +187,14 @@ class GradBucketReducer:
     ``finish()`` (before ``optimizer.step()``) flushes the tail bucket and waits for the collectives.
 
     Exchange (``mode`` / ``AG_GRAD_EXCHANGE``):
-      * ``fp32`` (default): reduce-scatter + all-gather in place on RCCL (xGMI is a full mesh of 7 point-to-point links per GPU: every
-        link carries a shard, where a single ring is bound by one link), all-reduce on gloo; exact to the order of the sum.
+      * ``fp32`` (default): ONE all-reduce per bucket, in place on the flat buffer (RCCL picks its channels over the xGMI mesh);
+        exact to the order of the sum.
+      * ``rsag``: reduce-scatter + all-gather in place (on a full mesh of 7 point-to-point links per GPU every link carries
+        a shard, where a single ring is bound by one link) — two collectives per bucket; RCCL only (gloo: as ``fp32``).
       * ``bf16``: the bucket is packed as bf16, exchanged by all-to-all (each rank receives every rank's piece of ITS shard), summed
         in fp32 on receipt, and the fp32 shard is all-gathered: half the reduce-scatter bytes with no bf16 accumulation; the gradient
         every rank ends with is the fp32 sum of bf16-rounded contributions.
+    (None of the three has run on more than one MI355X by this builder: the default is the form with the fewest moving parts.)
     Bucket size: xGMI is point-to-point, a collective step is per-link bound, so buckets are large (default 64 MiB: the vanilla
     ViT-base explainer's 419 MB of fp32 gradients are 7 collectives, the first one in flight after the head + 2 layers).
     Every parameter must be reported at most once per step; ``finish()`` also reduces trainable parameters that were never
@@ -204,8 +207,8 @@ class GradBucketReducer:
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes, self.average = int(bucket_bytes), average
         self.mode = (mode or os.environ.get("AG_GRAD_EXCHANGE", "fp32")).lower()
-        if self.mode not in ("fp32", "bf16", "allreduce"):
-            raise ValueError(f"GradBucketReducer: unknown exchange mode {self.mode!r} (fp32 | bf16 | allreduce)")
+        if self.mode not in ("fp32", "bf16", "rsag"):
+            raise ValueError(f"GradBucketReducer: unknown exchange mode {self.mode!r} (fp32 | rsag | bf16)")
         self._pending: List[Tensor] = []
         self._pending_bytes = 0
         self._inflight: List[Tuple] = []
@@ -290,7 +293,7 @@ class GradBucketReducer:
             for t_ in (flat, send, recv):
                 t_.record_stream(side)
             self._inflight.append((work, flat, side))
-        elif self.mode == "fp32" and backend == "nccl":
+        elif self.mode == "rsag" and backend == "nccl":
             r = dist.get_rank()
             shard = flat[r * (n // w):(r + 1) * (n // w)]
             dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)

@@ -164,10 +164,16 @@ def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartitio
     integer = CUs per XCD the target forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32
     for a ViT explainer whose backbone trains, 28 for a frozen backbone or a BERT explainer.  Every rank count: with N > 1 ranks RCCL's
     kernels (the gradient exchange, on the communicator's own stream) are a third client of the CUs the target forward leaves free.  Never
-    under the hipGraph step.  None also when the second stream does not run beside the caller's (``TrainPartition.arm``)."""
+    under the hipGraph step.  None also when the host program used the GPU before it imported this package (``_lib.HIP_TOUCHED_BEFORE_IMPORT``: the one
+    state in which the schedule was measured to LOSE; "auto" only) or when the second stream shares the caller's hardware queue (``TrainPartition.arm``)."""
+    from .. import _lib as L
     from .. import training16
     mode = os.environ.get("AG_TRAIN_PARTITION", "auto")
     if mode in ("0", "") or device.type != "cuda" or training16.GRAPH_STEP:
+        return None
+    if mode == "auto" and L.HIP_TOUCHED_BEFORE_IMPORT:
+        # the host program used the GPU before importing this package: its streams / graphs took their hardware queues first, the state in which
+        # the second stream was measured to run BEHIND the step (-24 … -27 % against one stream); only an explicit AG_TRAIN_PARTITION=<n> opts in
         return None
     if mode == "auto":
         # measured (tools/train_step_bench.py and inside bench.py, 36-72 steps of 8 images x 32 masks, images/s off -> on):
@@ -226,11 +232,13 @@ def pipelined_targets(groups: Iterable, compute: Callable[[Any], Any], part: Opt
     if cur is None:
         return
     cur_t = (compute(cur), None)
-    while cur is not None:
-        nxt = next(it, None)
-        nxt_t = launch(nxt) if nxt is not None else None
-        if cur_t[1] is not None:
-            main.wait_event(cur_t[1])
-        yield cur, cur_t[0]
-        cur, cur_t = nxt, nxt_t
-    main.wait_stream(part.fwd)
+    try:
+        while cur is not None:
+            nxt = next(it, None)
+            nxt_t = launch(nxt) if nxt is not None else None
+            if cur_t[1] is not None:
+                main.wait_event(cur_t[1])
+            yield cur, cur_t[0]
+            cur, cur_t = nxt, nxt_t
+    finally:
+        main.wait_stream(part.fwd)            # (also when the consumer abandons the generator: nothing of the second stream outlives the epoch)

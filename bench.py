@@ -383,7 +383,7 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
-def grad_exchange_overlap(job, dev, tb, steps=4):
+def grad_exchange_overlap(job, dev, tb, steps=8):
     """Exposed time of the gradient exchange of one explainer training step at ONE rank: every gradient of the vanilla explainer
     (ViT-base: 104.7 M fp32 = 419 MB) goes through distributed.GradBucketReducer — 64 MiB buckets, each an asynchronous RCCL all-reduce —
     (a) from inside the backward (training.GRAD_SINK: a bucket is in flight while the layers below still run) and (b) after it,
@@ -418,7 +418,7 @@ def grad_exchange_overlap(job, dev, tb, steps=4):
         labels = torch.zeros(tb, dtype=torch.long, device=dev)
         D.world = lambda: (0, 2)         # the reducer issues its collectives (a sum over the one real rank)
 
-        reducers = {m_: D.GradBucketReducer(params, mode=m_) for m_ in ("fp32", "bf16")}    # (persistent: the bucket buffers are reused step after step)
+        reducers = {m_: D.GradBucketReducer(params, mode=m_) for m_ in ("fp32", "rsag", "bf16")}    # (persistent: the bucket buffers are reused step after step)
 
         def step(mode, exchange="fp32"):
             for q in params:
@@ -437,36 +437,41 @@ def grad_exchange_overlap(job, dev, tb, steps=4):
 
         # five rounds over the legs, interleaved (a leg timed once, after the others, measured the box's drift: round 4's line had the
         # overlapped leg slower than the serial one in one run and faster than NO exchange in the next); min and median per leg
-        legs = [("none", "fp32"), ("overlapped", "fp32"), ("after_backward", "fp32"), ("overlapped", "bf16")]
+        legs = [("none", "fp32"), ("overlapped", "fp32"), ("after_backward", "fp32"), ("overlapped", "bf16"), ("overlapped", "rsag")]
         samples = {lg: [] for lg in legs}
         n_coll = 0
         for lg in legs:
             for _ in range(2):
                 n_coll = max(n_coll, step(*lg))
-        for _ in range(5):
+        for _ in range(7):
             for lg in legs:
                 torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                for _ in range(steps):
+                evs = []
+                for _ in range(steps):      # every step between two events on the compute stream (finish() makes it wait for the collectives)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     step(*lg)
+                    e1.record()
+                    evs.append((e0, e1))
                 torch.cuda.synchronize()
-                samples[lg].append((time.perf_counter() - t_) / steps * 1e3)
+                samples[lg].extend(a_.elapsed_time(b_) for a_, b_ in evs)
         med = {lg: float(np.median(v)) for lg, v in samples.items()}
         mn = {lg: float(np.min(v)) for lg, v in samples.items()}
         gbytes = sum(q.numel() for q in params) * 4 / 1e9
         r3 = lambda x: round(x, 3)   # noqa: E731
-        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step at ONE rank, median (min) of 5 "
-                        "interleaved rounds: no exchange / bucketed exchange from inside the backward / the same buckets after the backward; "
+        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step (hipEvents around every step) at ONE rank, median (min) over 7 "
+                        "interleaved rounds of 8 steps: no exchange / bucketed exchange from inside the backward / the same buckets after the backward; "
                         "exposed = median - no-exchange median.  A bucket is packed by ONE launch into its persistent flat buffer, .grad becomes a "
-                        "view of it (no torch.cat, no copy back), reduce-scatter + all-gather in place (fp32) or bf16 all-to-all + fp32 sum on "
-                        "receipt + fp32 all-gather (bf16).  One rank: nothing crosses xGMI, the figures are packing + RCCL launches",
-                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": 5,
+                        "view of it (no torch.cat, no copy back); the collective runs in place: one all-reduce per bucket (default), reduce-scatter + "
+                        "all-gather, or bf16 all-to-all + fp32 sum on receipt + fp32 all-gather.  One rank: nothing crosses xGMI, the figures are packing + RCCL launches",
+                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": 7, "steps_per_sample": steps,
                 "ms_no_exchange": r3(med[legs[0]]), "ms_overlapped": r3(med[legs[1]]), "ms_after_backward": r3(med[legs[2]]),
-                "ms_overlapped_bf16_payload": r3(med[legs[3]]),
+                "ms_overlapped_bf16_payload": r3(med[legs[3]]), "ms_overlapped_reduce_scatter_all_gather": r3(med[legs[4]]),
                 "min_ms": {"no_exchange": r3(mn[legs[0]]), "overlapped": r3(mn[legs[1]]), "after_backward": r3(mn[legs[2]]), "overlapped_bf16": r3(mn[legs[3]])},
                 "exposed_ms_overlapped": r3(med[legs[1]] - med[legs[0]]),
                 "exposed_ms_after_backward": r3(med[legs[2]] - med[legs[0]]),
-                "exposed_ms_overlapped_bf16_payload": r3(med[legs[3]] - med[legs[0]])}
+                "exposed_ms_overlapped_bf16_payload": r3(med[legs[3]] - med[legs[0]]),
+                "exposed_ms_overlapped_reduce_scatter_all_gather": r3(med[legs[4]] - med[legs[0]])}
     finally:
         D.world = keep_world
         _tr.MIXED_BF16 = keep_mixed
@@ -669,23 +674,6 @@ def main():
     packed_rows = engine.last_packed_rows(dev)   # (BERT token pruning) visible tokens of the last timed step, read after the timed region
     secondary = {}
 
-    # ---- SURVEY C2 sweep: the reference's own operating point is 2-4 inputs x K masks per GPU (experiments/*/.hparams.json):
-    # eager launches vs one hipGraph replay per step
-    if not args.no_secondary and args.precision == "bf16" and not lean and "sweep" not in skip:
-        sweep = []
-        for b_s in (1, 4, 16, 48):
-            job.set_batch(b_s)
-            n_s = 30 if b_s <= 4 else 10
-            el_e, _ = timed(job.step, n_s, 3, dist, dev)
-            gstep = engine.GraphedStep(job.step)
-            el_g, _ = timed(gstep, n_s, 2, dist, dev)
-            del gstep
-            sweep.append({"inputs_per_gpu": b_s, "rows_per_gpu": b_s * K, "eager_fwd_per_s": round(b_s * K * world * n_s / el_e, 1),
-                          "graph_fwd_per_s": round(b_s * K * world * n_s / el_g, 1)})
-        job.set_batch(B)
-        secondary["small_batch_sweep"] = {"unit": "masked-forwards/s", "what": "same step at other per-GPU batches; graph = engine.GraphedStep "
-                                          "(one hipGraphLaunch per step: sampler + forward)", "points": sweep}
-
     # ---- fp32 parity mode (exact-fp32 MFMA): the mode the 1e-4 Shapley criterion is checked in
     if not args.no_secondary and args.precision == "bf16" and not lean and "fp32" not in skip:
         engine.set_precision("fp32")
@@ -739,24 +727,6 @@ def main():
                                                         "roofline.kernels[<class>].tflops (which include bias / GELU / residual / LayerNorm folding / "
                                                         "row statistics); fc2's class average also contains the K = hidden out-projection",
                                                 "shapes": cal}
-
-    # ---- the other BASELINE configs that fit one GPU (configs 3 and 4), compact, same step function
-    if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16" and not lean and "configs" not in skip:
-        cfgs = {}
-        cfgs["bert_base_tayp_vanilla_seq128_K32"] = compact_config_line("bert_base", dev, rank, world, 48, dist)
-        cfgs["bert_base_tayp_vanilla_seq128_K32_token_pruning_off"] = compact_config_line("bert_base", dev, rank, world, 48, dist, prune=False)
-        cfgs["vit_large_imagenette_vanilla_K64"] = compact_config_line("vit_large", dev, rank, world, 48, dist, steps=3)
-        # the per-GPU shard of BASELINE config 4 under STRONG scaling over 8 GPUs: one ViT-large input x 64 masks per GPU (64 rows)
-        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_1_input_per_gpu"] = dict(
-            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, graph=True),
-            note="what each of 8 GPUs runs when a step of 8 inputs x K = 64 is sharded by input; with ONE input per step the shard is 8 masks "
-                 "per GPU (scripts/common.shard_auto: K-within-image): see ..._8_masks_per_gpu")
-        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_8_masks_per_gpu"] = dict(
-            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, masks=8, graph=True),
-            note="config 4 at ONE input per step over 8 GPUs: every GPU embeds the input and runs 8 of its 64 masks")
-        secondary["baseline_configs"] = {"what": "BASELINE.json configs 3 and 4 at one GPU per rank: masked-forwards/s, dominant-kernel "
-                                                 "fraction of the 2.5 PF bf16 peak (in-library hipEvents), whole-step executed fraction",
-                                         "configs": cfgs}
 
     # ---- what the throughput mode costs in accuracy, from the committed reference fixtures (rank 0)
     if not args.no_secondary and args.precision == "bf16" and rank == 0 and not lean and "ledger" not in skip:
@@ -921,6 +891,44 @@ def main():
                 except Exception as exc:
                     if train_block is not None:
                         train_block["one_rank_under_torch_distributed_run"] = {"error": repr(exc)[:200]}
+    # ---- the legs that capture hipGraphs run LAST: in a process that has instantiated the graphs of the ViT-large shards the eager training
+    # epochs that follow are host-bound at 2/3 of their rate (round 5, tools/train_ab.sh: 646 / 558 images/s before, 441 / 343 after; the graph
+    # replay of the step itself is unaffected) — a caller that mixes graph capture and eager training in one process should capture last too
+    # ---- SURVEY C2 sweep: the reference's own operating point is 2-4 inputs x K masks per GPU (experiments/*/.hparams.json):
+    # eager launches vs one hipGraph replay per step
+    if not args.no_secondary and args.precision == "bf16" and not lean and "sweep" not in skip:
+        sweep = []
+        for b_s in (1, 4, 16, 48):
+            job.set_batch(b_s)
+            n_s = 30 if b_s <= 4 else 10
+            el_e, _ = timed(job.step, n_s, 3, dist, dev)
+            gstep = engine.GraphedStep(job.step)
+            el_g, _ = timed(gstep, n_s, 2, dist, dev)
+            del gstep
+            sweep.append({"inputs_per_gpu": b_s, "rows_per_gpu": b_s * K, "eager_fwd_per_s": round(b_s * K * world * n_s / el_e, 1),
+                          "graph_fwd_per_s": round(b_s * K * world * n_s / el_g, 1)})
+        job.set_batch(B)
+        secondary["small_batch_sweep"] = {"unit": "masked-forwards/s", "what": "same step at other per-GPU batches; graph = engine.GraphedStep "
+                                          "(one hipGraphLaunch per step: sampler + forward)", "points": sweep}
+
+    # ---- the other BASELINE configs that fit one GPU (configs 3 and 4), compact, same step function
+    if not args.no_secondary and args.workload == "vit_base" and args.precision == "bf16" and not lean and "configs" not in skip:
+        cfgs = {}
+        cfgs["bert_base_tayp_vanilla_seq128_K32"] = compact_config_line("bert_base", dev, rank, world, 48, dist)
+        cfgs["bert_base_tayp_vanilla_seq128_K32_token_pruning_off"] = compact_config_line("bert_base", dev, rank, world, 48, dist, prune=False)
+        cfgs["vit_large_imagenette_vanilla_K64"] = compact_config_line("vit_large", dev, rank, world, 48, dist, steps=3)
+        # the per-GPU shard of BASELINE config 4 under STRONG scaling over 8 GPUs: one ViT-large input x 64 masks per GPU (64 rows)
+        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_1_input_per_gpu"] = dict(
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, graph=True),
+            note="what each of 8 GPUs runs when a step of 8 inputs x K = 64 is sharded by input; with ONE input per step the shard is 8 masks "
+                 "per GPU (scripts/common.shard_auto: K-within-image): see ..._8_masks_per_gpu")
+        cfgs["vit_large_imagenette_vanilla_K64_strong_scaling_shard_8_masks_per_gpu"] = dict(
+            compact_config_line("vit_large", dev, rank, world, 1, dist, steps=10, masks=8, graph=True),
+            note="config 4 at ONE input per step over 8 GPUs: every GPU embeds the input and runs 8 of its 64 masks")
+        secondary["baseline_configs"] = {"what": "BASELINE.json configs 3 and 4 at one GPU per rank: masked-forwards/s, dominant-kernel "
+                                                 "fraction of the 2.5 PF bf16 peak (in-library hipEvents), whole-step executed fraction",
+                                         "configs": cfgs}
+
     if rank == 0:
         total_rows = R * world * args.steps
         value = total_rows / elapsed

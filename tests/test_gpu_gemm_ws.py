@@ -271,7 +271,10 @@ def test_ws_resid_ln_slabs_vs_float64(cuda_device, m, n, k, splits):
     act = m // 2 + 37
     nrows = torch.tensor([act], dtype=torch.int32, device=dev)
     out2, _ = ops.gemm_resid_ln_ws(A, W, B, R, r_st, G, Bt, 1e-12, rows_dev=nrows, m_expected=act, route=ops.WS_EX_SLABS, splits=splits)
-    assert torch.equal(out2[:act], out[:act])
+    if splits:                                                           # (a planned split count follows the rows expected)
+        assert torch.equal(out2[:act], out[:act])
+    else:
+        np.testing.assert_allclose(out2[:act].float().cpu().numpy(), o[:act], rtol=0, atol=2.0 ** -6 * max(np.abs(o).max(), 1.0))
     planned, _ = ops.gemm_resid_ln_ws(A, W, B, R, r_st, G, Bt, 1e-12, rows_dev=nrows, m_expected=act)
     np.testing.assert_allclose(planned[:act].float().cpu().numpy()[rows[rows < act]], ref[rows < act], **TOL)
 
