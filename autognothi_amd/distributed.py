@@ -217,6 +217,7 @@ class GradBucketReducer:
         self._weight: Optional[float] = None
         self._known = None            # ids of the parameters that received a gradient in the last regular (non-ragged) step
         self._bufs = {}               # bucket index of the step -> (flat fp32 buffer, bf16 send / receive buffers or None)
+        self._layouts = {}            # bucket index -> the bucket's cached layout (see _flush)
 
     def begin(self, weight: Optional[float] = None) -> None:
         """Start a step.  ``weight`` = this rank's share of the step's global batch (inputs of this rank / inputs of all ranks):
@@ -253,24 +254,37 @@ class GradBucketReducer:
         w = dist.get_world_size()                                # (the group's real size: shapes of the collectives)
         ps = self._pending
         pad = self.PAD
-        offs, n = [], 0
-        for q in ps:
-            offs.append(n)
-            n += -(-q.grad.numel() // pad) * pad
-        n = -(-n // (pad * w)) * (pad * w)                       # equal, aligned shards
         dev = ps[0].grad.device
-        bf16 = self.mode == "bf16" and dev.type == "cuda"
-        flat, send, recv = self._buffers(self.collectives, n, dev, bf16, w)
-        flat, send, recv = flat[:n], (send[:n] if bf16 else None), (recv[:n] if bf16 else None)
+        bf16 = self.mode == "bf16"
+        # the layout of a bucket — offsets, the views that become .grad, the destinations of the pack — is the same step after step (the
+        # backward reports the same parameters in the same order): built once per bucket, reused while the reported sequence matches
+        key = tuple(id(q) for q in ps)
+        lay = self._layouts.get(self.collectives)
+        if lay is None or lay[0] != key or lay[1] != (str(dev), bf16, w):
+            offs, n = [], 0
+            for q in ps:
+                offs.append(n)
+                n += -(-q.grad.numel() // pad) * pad
+            n = -(-n // (pad * w)) * (pad * w)                   # equal, aligned shards
+            flat, send, recv = self._buffers(self.collectives, n, dev, bf16, w)
+            flat, send, recv = flat[:n], (send[:n] if bf16 else None), (recv[:n] if bf16 else None)
+            target = send if bf16 else flat
+            views = [flat[o:o + q.grad.numel()].view_as(q.grad) for q, o in zip(ps, offs)]
+            dsts = [target[o:o + q.grad.numel()] for q, o in zip(ps, offs)]
+            lay = (key, (str(dev), bf16, w), offs, n, flat, send, recv, views, dsts)
+            self._layouts[self.collectives] = lay
+        _, _, offs, n, flat, send, recv, views, dsts = lay
         scale = 1.0 if self._weight is None else float(self._weight)
         target = send if bf16 else flat
-        views = [flat[o:o + q.grad.numel()].view_as(q.grad) for q, o in zip(ps, offs)]
         grads = [q.grad if (q.grad.dtype == torch.float32 and q.grad.is_contiguous()) else q.grad.float().contiguous() for q in ps]
         if dev.type == "cuda":
             from . import ops
-            pairs = [(g, target[o:o + g.numel()]) for g, o in zip(grads, offs) if bf16 or g.data_ptr() != flat[o:].data_ptr() or scale != 1.0]
+            pairs = [(g, d_) for g, d_, v in zip(grads, dsts, views) if bf16 or g.data_ptr() != v.data_ptr() or scale != 1.0]
             ops.pack_many(pairs, scale)                          # ONE launch (per 96 tensors) for the whole bucket
-        else:                                                    # (CPU / gloo: the sharding contract's tests)
+        elif bf16:                                               # (CPU / gloo: the sharding contract's tests)
+            for g, o in zip(grads, offs):
+                target[o:o + g.numel()].copy_((g.reshape(-1) * scale).to(torch.bfloat16))
+        else:
             for g, v in zip(grads, views):
                 if g.data_ptr() != v.data_ptr():
                     v.copy_(g)
@@ -279,7 +293,19 @@ class GradBucketReducer:
         for q, v in zip(ps, views):                              # the gradient IS the bucket's slice from here on
             q.grad = v
         backend = dist.get_backend()
-        if bf16:
+        if bf16 and dev.type != "cuda":
+            # (gloo: the same exchange, blocking — pieces, shard and gather indices as on RCCL)
+            send.view(w, n // w)             # (n is a multiple of w: equal pieces)
+            if w > 1:
+                dist.all_to_all_single(recv, send)
+            else:
+                recv.copy_(send)
+            r = dist.get_rank()
+            shard = flat[r * (n // w):(r + 1) * (n // w)]
+            shard.copy_(recv.view(w, n // w).float().sum(dim=0))
+            work = dist.all_gather_into_tensor(flat, shard.clone(), async_op=True)
+            self._inflight.append((work, flat, None))
+        elif bf16:
             # all-to-all of bf16 pieces, fp32 sum on receipt, all-gather of the fp32 shard — behind the a2a on a side stream, so that the
             # backward's stream never waits for a collective
             side = self._side_stream(dev)

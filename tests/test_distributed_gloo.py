@@ -44,6 +44,33 @@ def _check_overlapped_reducer(D, rank, world):
     assert red.finish() == 0            # state is reset between steps; nothing holds a gradient
 
 
+def _check_bf16_exchange(D, rank, world):
+    """AG_GRAD_EXCHANGE=bf16: bf16 all-to-all of the bucket's pieces, fp32 sum on receipt, fp32 all-gather — the index arithmetic of pieces,
+    shards and views (ragged tensor sizes, several buckets, weighted ranks) against sum_r w_r * bf16(g_r) taken in float64."""
+    g = torch.Generator().manual_seed(300 + rank)
+    ps = [torch.nn.Parameter(torch.zeros(s_)) for s_ in ((33, 7), (5,), (64, 16), (3,), (130,))]
+    for q in ps:
+        q.grad = torch.randn(q.shape, generator=g)
+    weight = 0.25 if rank == 0 else 0.75
+    mine = [(q.grad * weight).to(torch.bfloat16).double() for q in ps]
+    try:
+        red = D.GradBucketReducer(ps, bucket_bytes=1024, mode="bf16")
+        red.begin(weight)
+        for q in reversed(ps):
+            red.ready(q)
+        n_coll = red.finish()
+    except RuntimeError as exc:          # (a gloo build without alltoall)
+        if "alltoall" in str(exc).lower() or "not supported" in str(exc).lower():
+            return
+        raise
+    assert n_coll >= 2, n_coll
+    for q, m in zip(ps, mine):
+        both = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(both, m)
+        torch.testing.assert_close(q.grad.double(), sum(both), rtol=1e-6, atol=1e-6)
+        assert q.grad.dtype == torch.float32 and q.grad.shape == q.shape
+
+
 def _check_sharded_step_equals_unsharded(D, rank, world):
     """One explainer-style training step on a stub (plain torch on the CPU: the sharding contract, not the kernels): rows
     shard by input, every rank computes the K-mask values, loss and gradients of ITS inputs, gradients are averaged by the
@@ -126,6 +153,7 @@ def _worker(rank, world, port, out):
         assert abs(D.reduce_scalars([part], torch.device("cpu"))[0] - float((m2.double() ** 2).sum())) < 1e-9
         assert D.shard_auto(masks, n_inputs, k)[1] == "input"
         _check_overlapped_reducer(D, rank, world)
+        _check_bf16_exchange(D, rank, world)
         _check_sharded_step_equals_unsharded(D, rank, world)
         out[rank] = 1
     finally:
