@@ -12,7 +12,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard_auto, pipelined_targets, train_partition
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, on_epoch_stream, shard_auto, pipelined_targets, train_partition
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -22,6 +22,7 @@ def _cross_entropy_value(base: Tensor, labels: Tensor) -> Tensor:
     return -(s.gather(1, labels.view(-1, 1).to(torch.int64)).log()).mean()
 
 
+@on_epoch_stream
 def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                               d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                               optimizer: torch.optim.Optimizer, epoch: int,
@@ -116,6 +117,7 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
     return cls_loss / total, reg_loss / total, (cls_loss + reg_loss) / total, correct / total
 
 
+@on_epoch_stream
 def duo_explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                              d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer, epoch: int,
                              gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,

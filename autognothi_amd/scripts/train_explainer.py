@@ -18,7 +18,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, pipelined_targets, shard, shard_auto, train_partition
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, on_epoch_stream, pipelined_targets, shard, shard_auto, train_partition
 from .common import mask_source as common_mask_source
 
 
@@ -133,6 +133,7 @@ def explainer_batch_loss(recipe: ModelRecipe, m_explainer, xs: Tensor, bits: Ten
     return loss, phi, dphi, logits
 
 
+@on_epoch_stream
 def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                          d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer, epoch: int,
                          gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
@@ -165,6 +166,7 @@ def explainer_epoch_eval(env: Any, device: torch.device, n_mask_samples: int, n_
     return reg_loss / max(total, 1)
 
 
+@on_epoch_stream
 def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n_players: int, v_0: Tensor,
                           d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                           optimizer: torch.optim.Optimizer, epoch: int,

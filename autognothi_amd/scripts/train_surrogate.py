@@ -11,7 +11,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, shard
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, on_epoch_stream, shard
 
 
 def surrogate_batch_loss(recipe: ModelRecipe, m_classifier, m_surrogate, xs: Tensor, n_players: int, rng,
@@ -34,6 +34,7 @@ def surrogate_batch_loss(recipe: ModelRecipe, m_classifier, m_surrogate, xs: Ten
     return loss, dcur, orig, adapt
 
 
+@on_epoch_stream
 def surrogate_epoch_eval(env: Any, device: torch.device, n_players: int, d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe,
                          m_classifier, m_surrogate, epoch: int, gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]],
                          seed: Optional[int] = None, mask_source: Optional[MaskSource] = None) -> float:
@@ -58,6 +59,7 @@ def surrogate_epoch_eval(env: Any, device: torch.device, n_players: int, d_items
     return tot / max(n, 1)
 
 
+@on_epoch_stream
 def surrogate_epoch_train(env: Any, device: torch.device, n_players: int, d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe,
                           m_classifier, m_surrogate, optimizer: torch.optim.Optimizer, epoch: int,
                           gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
