@@ -62,7 +62,8 @@ __device__ __attribute__((aligned(16))) const uint32_t g_zero_chunk[4] = {0u, 0u
 //     rescaled a handful of times per row instead of every block; l and O always share the same reference max, so the
 //     quotient O/l is unchanged (probabilities up to 2^8 in between are exact in bf16's relative precision).
 // S^T tile of one 32-key block: four 32x32x16 MFMAs over the 64-wide head dim (K fragments by rows from the K image)
-__device__ __forceinline__ f32x16_t attn_scores(const char* smem, const int kbyte, const int (&koff)[4], const uint4 (&qf)[4]) {
+template <typename QF>   // uint4, or a 4 x 32-bit vector (attn_stream3_kernel: whole 128-bit registers, never taken apart)
+__device__ __forceinline__ f32x16_t attn_scores(const char* smem, const int kbyte, const int (&koff)[4], const QF (&qf)[4]) {
     f32x16_t s;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = 0.f;
@@ -150,9 +151,9 @@ __device__ __forceinline__ void attn_softmax_pv(f32x16_t s, const char* smem, co
     if (FENCE) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled blocks from being interleaved into a spilling schedule
 }
 
-template <int MODE, bool MASKOPS, bool FIRST>
+template <int MODE, bool MASKOPS, bool FIRST, typename QF>
 __device__ __forceinline__ void attn_block(const char* smem, const int kbyte, const int (&koff)[4], const int (&voff)[2][2],
-                                           const uint4 (&qf)[4], f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run,
+                                           const QF (&qf)[4], f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run,
                                            const uint32_t mw, const int kvalid, const int lh, const float c2) {
     const f32x16_t s = attn_scores(smem, kbyte, koff, qf);
     attn_softmax_pv<MODE, MASKOPS, FIRST>(s, smem, kbyte, voff, o0, o1, m_run, l_run, mw, kvalid, lh, c2);
@@ -322,6 +323,225 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (p.dbg & 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         ATTN_STAMP(3)
     }
+}
+
+// ---- attn_stream3_kernel: the ViT kernel above as ONE K/V request stream per CU, two wave teams, three LDS images -----------
+//
+// What the counters say about attn_bf16_kernel at the bench shape (profiles/r04_attention_sq_counters.json): per item and CU the
+// memory system needs 4.5 us (321 us per launch with the block bodies removed), the vector issue 3.9 us (four waves per SIMD), and
+// the kernel takes 6.4 us — a workgroup stages (4.0 us, nothing to issue), computes, stores and is replaced (1.8 us), and two
+// workgroups per CU overlap those phases only pairwise.  The persistent forms of rounds 1-3 kept ONE 8-wave workgroup per CU (two
+// waves per SIMD: the block body is then issue-bound) or three smaller ones; what none of them had is both at once: four waves per
+// SIMD AND a K/V request in flight at every moment.  Here: grid = CU count, 16 waves = two TEAMS of 8 (7 query blocks + one wave
+// that only stages), items j = 0, 1, 2, ... of the workgroup go to team j & 1 and LDS image j % 3 (K 200 rows + V 224 rows =
+// 53 KiB; three of them fill the 160 KiB).  An item takes two SLOTS (key blocks 0-3 | key blocks 4-6, normalisation, stores); the
+// teams run half an item apart, one workgroup barrier per slot:
+//     slot            j-1             j              j+1             j+2
+//     team j & 1      item j-2 (2nd)  item j (1st)   item j (2nd)    item j+2 (1st)
+//     other team      item j-1 (1st)  item j-1 (2nd) item j+1 (1st)  item j+1 (2nd)
+//     LDS-DMA         item j          item j+1       item j+2        item j+3         (issued by the team in its 2nd half)
+// The image of item j+2 is the one item j-1 was read from: free at the barrier that opens slot j+1, requested right behind it by the
+// team that will read it, waited for (counted: the output stores stay in flight) before the barrier that opens slot j+2.  Every
+// LDS-DMA goes through inline asm (hipcc must not see it: a tracked LDS-DMA puts a vmcnt(0) in front of every ds_read behind a
+// barrier); the Q fragments of a team's next item are requested after the last score MFMA of the current one, into the registers
+// that product has just released; the mask words two slots ahead.  Rows >= 200 of the V images are zeroed once (a padded key's
+// probability is exactly 0, its V row must only be finite); the last key block reads K rows 200-223 out of the V image (finite bits,
+// logits replaced by -inf).
+constexpr int S3_KROWS = 200, S3_VROWS = 224;
+constexpr int S3_VBASE = S3_KROWS * ROWB;                  // 25 600
+constexpr int S3_IMG = (S3_KROWS + S3_VROWS) * ROWB;       // 54 272
+constexpr int S3_LDS = 3 * S3_IMG;                         // 162 816 of 163 840
+constexpr int S3_PIECES = S3_KROWS / 8;                    // 25 pieces of 8 rows per operand
+
+typedef unsigned int s3_q4 __attribute__((ext_vector_type(4)));   // one Q fragment: a whole 128-bit register
+__device__ __forceinline__ void s3_glds(const char* gsrc, uint32_t lds_off) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ int s3_lane() {   // the lane id from an opaque value: per-lane constants are re-made per item instead of living across the loop
+    uint32_t ones = ~0u;
+    asm volatile("" : "+s"(ones));
+    return (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+}
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_stream3_kernel(AttnArgs p, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MODE = AG_MASK_VIT_MUL;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int team = wave >> 3, tw = wave & 7;
+    const int T = p.T;
+    const long rowstride = (long)3 * p.H * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int grid = (int)gridDim.x;
+    const int nj = (n_items - (int)blockIdx.x + grid - 1) / grid;       // items of this workgroup: blockIdx.x + j * grid
+    const float c2 = 0.125f * 1.4426950408889634f;
+
+    {   // V rows [200, 224) of the three images: zero, once
+        const int t = threadIdx.x;
+        if (t < 3 * 192) {
+            const int img = t / 192, o = t - img * 192;
+            *reinterpret_cast<uint4*>(smem + img * S3_IMG + S3_VBASE + S3_KROWS * ROWB + o * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    auto item_of = [&](int j) { return (int)blockIdx.x + j * grid; };
+    // mask words of item j's row by SCALAR loads (lgkmcnt: a vector load would sit in the vmcnt queue between the LDS-DMA pieces, and hipcc waits
+    // for a tracked load with a count that drains whatever was issued behind it).  A query wave's two pieces lie in ONE 32-key word
+    // (word tw >> 1), the staging wave's pieces 14-24 in words 3-6.  Waited for (lgkmcnt(0)) by the caller before stage().
+    auto mask_word_async = [&](int j, int w) -> uint32_t {
+        const int row = item_of(j) / p.heads;
+        const uint32_t* mp = p.mask + ((long)row * p.Tw + w);
+        uint32_t v;
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(mp) : "memory");
+        return v;
+    };
+    // one piece pair (K with the masked keys' chunks from the zero chunk, V) of item j -> image j % 3
+    auto stage_pair = [&](int j, int pc, uint32_t word, int ln) {
+        const int item = item_of(j), row = item / p.heads, head = item - row * p.heads;
+        const char* kb = p.qkv + (long)(row / p.share) * T * rowstride + (long)head * HD * 2 + (long)p.H * 2;
+        const char* vb = kb + (long)p.H * 2;
+        const uint32_t img = lds0 + (uint32_t)((j % 3) * S3_IMG);
+        const int r = pc * 8 + (ln >> 3), slot = ln & 7;
+        const int rc = r < T ? r : T - 1;
+        const long src = (long)rc * rowstride + ((slot ^ swz(r)) << 4);
+        const char* ksrc = kb + src;
+        if (MODE == AG_MASK_VIT_MUL && !((word >> (r & 31)) & 1u)) ksrc = reinterpret_cast<const char*>(g_zero_chunk);
+        s3_glds(ksrc, img + pc * 1024);
+        s3_glds(vb + src, img + S3_VBASE + pc * 1024);
+    };
+    auto load_q = [&](int j, s3_q4 (&qf)[4]) {                            // B operand of the score product: lane holds Q[q][16 ks + 8 lh .. + 8]
+        const int ln = s3_lane();
+        const int lr = ln & 31, lh = ln >> 5;
+        const int item = item_of(j), row = item / p.heads, head = item - row * p.heads;
+        const char* qb = p.qkv + (long)(row / p.share) * T * rowstride + (long)head * HD * 2;
+        const int q0 = tw * 32 + lr;
+        const int qc = q0 < T ? q0 : T - 1;
+        // (asynchronous loads hipcc does not see: a tracked load is waited for at its first use, at the top of the next item, with a count
+        // that also drains the previous item's output stores; these are covered by the counted wait in front of the slot barrier and tied to
+        // it by q_landed)
+        const char* qp = qb + (long)qc * rowstride + lh * 16;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                     : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]) : "v"(qp) : "memory");
+    };
+    auto q_landed = [&](s3_q4 (&qf)[4]) { asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])); };
+
+    // ---- prologue: the team's first item on its way, its Q fragments, the mask words of the item the team stages first inside the loop
+    s3_q4 qf[4] = {};
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};                                    // query wave: mw[0]; staging wave: words 3-6
+    auto request_mask = [&](int j) {
+        if (tw < 7) mw[0] = mask_word_async(j, tw >> 1);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mw[i] = mask_word_async(j, 3 + i);
+        }
+    };
+    auto mask_landed = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mw[0]), "+s"(mw[1]), "+s"(mw[2]), "+s"(mw[3]) :: "memory");
+    };
+    auto stage = [&](int j) {                                             // this wave's share of item j: query waves two piece pairs, the staging wave eleven
+        const int ln = s3_lane();
+        if (tw < 7) {
+            stage_pair(j, 2 * tw, mw[0], ln);
+            stage_pair(j, 2 * tw + 1, mw[0], ln);
+        } else {
+#pragma unroll
+            for (int pc = 14; pc < S3_PIECES; ++pc) stage_pair(j, pc, mw[(pc >> 2) - 3], ln);
+        }
+    };
+    if (team < nj) {
+        request_mask(team);
+        mask_landed();
+        stage(team);                                                      // (team t stages item t: read by nobody else before t's own barrier)
+        if (tw < 7) load_q(team, qf);
+        if (team + 2 < nj) request_mask(team + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    q_landed(qf);
+    __syncthreads();                                                      // opens slot 0 (and publishes the zeroed V rows)
+    if (team == 1) asm volatile("s_barrier" ::: "memory");               // team 1 has nothing in slot 0
+
+    if (tw < 7) {
+        for (int j = team; j < nj; j += 2) {
+            const char* img = smem + (j % 3) * S3_IMG;
+            const bool more = j + 2 < nj;
+            const int ln = s3_lane();
+            const int lr = ln & 31, lh = ln >> 5;
+            int koff[4], voff[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) koff[ks] = lr * ROWB + (((2 * ks + lh) ^ swz(lr)) << 4);
+            {
+                const int g = ln >> 4, li = ln & 15, tq = li >> 2, tp = li & 3;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int k0 = 4 * (g >> 1) + tq, k1 = k0 + 8;
+                    const int chunk = dt * 4 + 2 * (g & 1) + (tp >> 1);
+                    voff[dt][0] = S3_VBASE + k0 * ROWB + ((chunk ^ swz(k0)) << 4) + 8 * (tp & 1);
+                    voff[dt][1] = S3_VBASE + k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
+                }
+            }
+            f32x16_t o0, o1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+            float m_run = NEG_BIG, l_run = 0.f;
+            // ---- first half: key blocks 0-3
+            attn_block<MODE, false, true>(img, 0, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb)
+                attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+            asm volatile("s_barrier" ::: "memory");                      // opens slot j+1: the other team has left image (j+2) % 3
+            // ---- second half: the team's next item on its way, key blocks 4-6, normalisation, stores
+            if (more) { mask_landed(); stage(j + 2); }
+#pragma unroll
+            for (int kb = 4; kb < 6; ++kb)
+                attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+            const f32x16_t s6 = attn_scores(img, 6 * 32 * ROWB, koff, qf);
+            __builtin_amdgcn_sched_barrier(0);
+            load_q(more ? j + 2 : j, qf);                                 // (the score product above was the last reader of qf; unconditional:
+            request_mask(j + 4 < nj ? j + 4 : j);                         // a conditional load is a copy of the fragments at the loop edge, i.e. a wait)
+            __builtin_amdgcn_sched_barrier(0);
+            attn_softmax_pv<MODE, false, false>(s6, img, 6 * 32 * ROWB, voff, o0, o1, m_run, l_run, 0u, T - 192, lh, c2);
+            float l_tot;
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+                l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            const float inv = 1.0f / l_tot;
+            uint4 piece[4];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const int g = 2 * (tj & 1);
+                const f32x16_t& o = tj < 2 ? o0 : o1;
+                const uint32_t x0 = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv), x1 = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                const uint32_t y0 = pack_bf16x2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), y1 = pack_bf16x2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                piece[tj] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+            const int q = tw * 32 + lr;
+            if (q < T) {
+                const int item = item_of(j), row = item / p.heads, head = item - row * p.heads;
+                char* out = p.ctx + ((long)row * T + q) * p.H * 2 + (long)head * HD * 2;
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    *reinterpret_cast<uint4*>(out + (tj >> 1) * 64 + (tj & 1) * 32 + lh * 16) = piece[tj];
+            }
+            // everything but this item's (at most four) output stores: the pieces of item j+2 and its Q fragments have landed
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            q_landed(qf);
+            asm volatile("s_barrier" ::: "memory");                      // opens slot j+2
+        }
+    } else {                                                             // the team's staging wave
+        for (int j = team; j < nj; j += 2) {
+            const bool more = j + 2 < nj;
+            asm volatile("s_barrier" ::: "memory");
+            if (more) { mask_landed(); stage(j + 2); }
+            request_mask(j + 4 < nj ? j + 4 : j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+    }
+    if (team == (nj & 1)) asm volatile("s_barrier" ::: "memory");        // the barrier the other team's last slot pairs with
 }
 
 // ---- VALU kernel: one query per thread, 64-key K/V tiles (fp32) broadcast from LDS ----------------------
@@ -612,6 +832,30 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
         // ViT: masked keys are zeroed K rows (no per-score mask work), 7 key blocks (T = 197) unrolled;
         // BERT fixed-length rows: per-score -inf; packed rows: visible keys only
+        // ViT rows of 193-200 tokens, every token a query, enough items for every CU: one K/V stream per CU (attn_stream3_kernel)
+        static AgKnob k_s3("AG_ATTN_STREAM3");
+        if (mask_mode == AG_MASK_VIT_MUL && !a.cu && a.Tp == 224 && a.T > 192 && a.T <= S3_KROWS && a.nq == a.T && a.dbg == 0 &&
+            (int)k_s3.get(1) != 0) {
+            int n_cu = ag_device_cus();
+            const int sc = ag_stream_cus(s);
+            if (sc > 0 && sc < n_cu) n_cu = sc;
+            const long items = (long)a.R * a.heads;
+            static AgKnob k_s3min("AG_ATTN_STREAM3_MIN");      // items per CU from which the stream pays (tests: 1)
+            if (n_cu > 0 && items >= (long)k_s3min.get(6) * n_cu && items < 0x7FFFFFFFL) {
+                static bool attr_set[16] = {};
+                int dev = 0;
+                AG_HIP_CHECK(hipGetDevice(&dev));
+                if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+                    AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stream3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
+                    attr_set[dev] = true;
+                }
+                if (dev >= 0 && dev < 16) {
+                    hipLaunchKernelGGL(attn_stream3_kernel, dim3(n_cu), dim3(1024), S3_LDS, s, a, (int)items);
+                    AG_LAUNCH_CHECK();
+                    return AG_OK;
+                }
+            }
+        }
         void (*kern)(AttnArgs);
         if (mask_mode == AG_MASK_VIT_MUL && !a.cu) kern = a.Tp == 224 ? attn_bf16_kernel<AG_MASK_VIT_MUL, false, 7> : attn_bf16_kernel<AG_MASK_VIT_MUL, false, 0>;
         else if (a.cu) kern = attn_bf16_kernel<AG_MASK_BERT_ADD, false, 0>;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void dma_probe_kernel(const char* A, co
 //   shape 0: the ring GEMM's epilogue: a wave owns a 64-column strip; one store = 8 rows x 128 B (8 lanes x 16 B per row)
 //   shape 1: a wave owns 32 whole tile rows; one store = 2 rows x 512 B (32 lanes x 16 B per row)
 //   shape 2: as 0 with 4 rows x 256 B (a wave owns a 128-column strip)
+//   shape 3 / 4: straight from the accumulator layout (no LDS transposition): 16 rows x 4 x 16 B / 16 rows x 64 B per store
 //   flags bit 0: non-temporal stores
 __global__ __launch_bounds__(512) void store_probe_kernel(char* C, long ld_b, int tiles_per_wg, int tiles_n, int shape, int flags,
                                                           unsigned long long* clocks) {
@@ -197,6 +198,19 @@ __global__ __launch_bounds__(512) void store_probe_kernel(char* C, long ld_b, in
                 u32x4* dst = reinterpret_cast<u32x4*>(p0 + (long)i * 2 * ld_b);
                 if (flags & 1) __builtin_nontemporal_store(val, dst); else *dst = val;
             }
+        } else if (shape == 3 || shape == 4) {
+            // the 16x16 MFMA accumulator layout with permuted W rows, NO transposition: lane (frow = lane & 15, fq = lane >> 4) owns 32
+            // contiguous bytes of row frow (16 output features).  shape 3: two stores of 16 rows x (4 x 16 B at a 32-byte stride);
+            // shape 4: after a half swap between fq and fq ^ 2, two stores of 16 rows x 64 contiguous bytes (lanes fq = 0, 2, 1, 3)
+            const int wm = wave >> 2, wn = wave & 3, frow = lane & 15, fq = lane >> 4;
+            const int col = shape == 3 ? fq * 32 : ((fq & 1) * 32 + (fq >> 1) * 16);
+            char* p0 = base + (long)(wm * 128 + frow) * ld_b + wn * 128 + col;
+#pragma unroll 4
+            for (int i = 0; i < 8; ++i) {
+                u32x4* d0 = reinterpret_cast<u32x4*>(p0 + (long)i * 16 * ld_b);
+                u32x4* d1 = reinterpret_cast<u32x4*>(p0 + (long)i * 16 * ld_b + (shape == 3 ? 16 : 64));
+                if (flags & 1) { __builtin_nontemporal_store(val, d0); __builtin_nontemporal_store(val, d1); } else { *d0 = val; *d1 = val; }
+            }
         } else {                     // wave (wm 0..3, wn 0..1): rows wm*64 .. +64, byte columns wn*256 .. +256; 16 stores of 4 rows
             const int wm = wave >> 1, wn = wave & 1;
             char* p0 = base + (long)(wm * 64 + (lane >> 4)) * ld_b + wn * 256 + (lane & 15) * 16;
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(512) void store_probe_kernel(char* C, long ld_b, in
 
 extern "C" int ag_probe_store(int shape, int flags, void* d_C, int64_t ld_bytes, int rows, int grid, double* bytes_per_clk_per_cu,
                               double* gbytes_per_s, void* stream) {
-    AG_REQUIRE(d_C && bytes_per_clk_per_cu && gbytes_per_s && shape >= 0 && shape <= 2 && ld_bytes % 512 == 0 && rows % 256 == 0 && grid > 0,
+    AG_REQUIRE(d_C && bytes_per_clk_per_cu && gbytes_per_s && shape >= 0 && shape <= 4 && ld_bytes % 512 == 0 && rows % 256 == 0 && grid > 0,
                "ag_probe_store: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int tiles_n = (int)(ld_bytes / 512), tiles = (rows / 256) * tiles_n;
