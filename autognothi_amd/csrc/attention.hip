@@ -343,8 +343,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // The image of item j+2 is the one item j-1 was read from: free at the barrier that opens slot j+1, requested right behind it by the
 // team that will read it, waited for (counted: the output stores stay in flight) before the barrier that opens slot j+2.  Every
 // LDS-DMA goes through inline asm (hipcc must not see it: a tracked LDS-DMA puts a vmcnt(0) in front of every ds_read behind a
-// barrier); the Q fragments of a team's next item are requested after the last score MFMA of the current one, into the registers
-// that product has just released; the mask words two slots ahead.  Rows >= 200 of the V images are zeroed once (a padded key's
+// barrier); the Q fragments of a team's next item are requested at the top of the current one into a second register set (asynchronous
+// loads hipcc does not see, whole 128-bit registers that are never taken apart before their wait); the mask words by scalar loads.  Rows >= 200 of the V images are zeroed once (a padded key's
 // probability is exactly 0, its V row must only be finite); the last key block reads K rows 200-223 out of the V image (finite bits,
 // logits replaced by -inf).
 constexpr int S3_KROWS = 200, S3_VROWS = 224;
@@ -484,23 +484,29 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
             float m_run = NEG_BIG, l_run = 0.f;
+            // the team's next item's Q fragments: requested a whole item ahead into a second register set (16 of the 24 spare registers; requested
+            // after the last score product instead — into the registers it releases — the round trip sat in front of the slot barrier: 396 -> 383 us)
+            s3_q4 qn[4];
+            load_q(more ? j + 2 : j, qn);                                 // (unconditional: a conditional load is a copy of the fragments at the loop edge)
+            const bool compute = !(p.dbg & 1), staging = !(p.dbg & 2);   // (AG_ATTN_DBG ablations, wrong results: timing only)
             // ---- first half: key blocks 0-3
-            attn_block<MODE, false, true>(img, 0, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+            if (compute) {
+                attn_block<MODE, false, true>(img, 0, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
 #pragma unroll
-            for (int kb = 1; kb < 4; ++kb)
-                attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+                for (int kb = 1; kb < 4; ++kb)
+                    attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+            }
             asm volatile("s_barrier" ::: "memory");                      // opens slot j+1: the other team has left image (j+2) % 3
             // ---- second half: the team's next item on its way, key blocks 4-6, normalisation, stores
-            if (more) { mask_landed(); stage(j + 2); }
+            if (more && staging) { mask_landed(); stage(j + 2); }
+            if (compute) {
 #pragma unroll
-            for (int kb = 4; kb < 6; ++kb)
-                attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
-            const f32x16_t s6 = attn_scores(img, 6 * 32 * ROWB, koff, qf);
-            __builtin_amdgcn_sched_barrier(0);
-            load_q(more ? j + 2 : j, qf);                                 // (the score product above was the last reader of qf; unconditional:
-            request_mask(j + 4 < nj ? j + 4 : j);                         // a conditional load is a copy of the fragments at the loop edge, i.e. a wait)
-            __builtin_amdgcn_sched_barrier(0);
-            attn_softmax_pv<MODE, false, false>(s6, img, 6 * 32 * ROWB, voff, o0, o1, m_run, l_run, 0u, T - 192, lh, c2);
+                for (int kb = 4; kb < 6; ++kb)
+                    attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+                const f32x16_t s6 = attn_scores(img, 6 * 32 * ROWB, koff, qf);
+                attn_softmax_pv<MODE, false, false>(s6, img, 6 * 32 * ROWB, voff, o0, o1, m_run, l_run, 0u, T - 192, lh, c2);
+            }
+            request_mask(j + 4 < nj ? j + 4 : j);
             float l_tot;
             {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
@@ -528,14 +534,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             }
             // everything but this item's (at most four) output stores: the pieces of item j+2 and its Q fragments have landed
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            q_landed(qf);
+            q_landed(qn);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
             asm volatile("s_barrier" ::: "memory");                      // opens slot j+2
         }
     } else {                                                             // the team's staging wave
         for (int j = team; j < nj; j += 2) {
             const bool more = j + 2 < nj;
             asm volatile("s_barrier" ::: "memory");
-            if (more) { mask_landed(); stage(j + 2); }
+            if (more && !(p.dbg & 2)) { mask_landed(); stage(j + 2); }
             request_mask(j + 4 < nj ? j + 4 : j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
@@ -834,7 +842,7 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         // BERT fixed-length rows: per-score -inf; packed rows: visible keys only
         // ViT rows of 193-200 tokens, every token a query, enough items for every CU: one K/V stream per CU (attn_stream3_kernel)
         static AgKnob k_s3("AG_ATTN_STREAM3");
-        if (mask_mode == AG_MASK_VIT_MUL && !a.cu && a.Tp == 224 && a.T > 192 && a.T <= S3_KROWS && a.nq == a.T && a.dbg == 0 &&
+        if (mask_mode == AG_MASK_VIT_MUL && !a.cu && a.Tp == 224 && a.T > 192 && a.T <= S3_KROWS && a.nq == a.T && !(a.dbg & ~3) &&
             (int)k_s3.get(1) != 0) {
             int n_cu = ag_device_cus();
             const int sc = ag_stream_cus(s);

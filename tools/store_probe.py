@@ -8,7 +8,7 @@ from autognothi_amd import _lib as L
 dev = torch.device("cuda:0")
 rows, ld = 302592 // 256 * 256, 3072 * 2
 buf = torch.empty((rows, ld), dtype=torch.uint8, device=dev)
-for grid in (256,):
+for grid in [int(a) for a in sys.argv[1:]] or [256]:
     for shape in (0, 1, 2, 3, 4):
         for flags in (0, 1):
             bpc, gbs = C.c_double(), C.c_double()
