@@ -80,14 +80,12 @@ __device__ __forceinline__ bool keep_elem(uint32_t seed, uint64_t idx, float p) 
 #define AG_DEFINE_DROPOUT_SALT(setter)                                                                                \
     __device__ uint32_t g_ag_drop_salt = 0u;                                                                          \
     __device__ __forceinline__ uint32_t ag_salted(uint32_t seed) { return seed ^ (g_ag_drop_salt * 0x9E3779B1u); }    \
+    /* the salt travels BY VALUE in a kernel argument (a copy from host memory would be read when the copy executes,  \
+       not when it is issued: a host many replays ahead of the GPU would overwrite a staging slot still waiting) */     \
+    __global__ void ag_set_salt_kernel(uint32_t salt) { g_ag_drop_salt = salt; }                                      \
     int setter(uint32_t salt, hipStream_t s) {                                                                        \
-        static uint32_t* pinned = nullptr;                                                                            \
-        static int slot = 0;                                                                                          \
-        if (!pinned && hipHostMalloc((void**)&pinned, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return AG_ERR_HIP; \
-        slot = (slot + 1) & 63;                                                                                       \
-        pinned[slot] = salt;                                                                                          \
-        return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ag_drop_salt), pinned + slot, sizeof(uint32_t), 0, hipMemcpyHostToDevice, s) == hipSuccess \
-                   ? AG_OK : AG_ERR_HIP;                                                                              \
+        hipLaunchKernelGGL(ag_set_salt_kernel, dim3(1), dim3(1), 0, s, salt);                                         \
+        return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;                                                  \
     }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

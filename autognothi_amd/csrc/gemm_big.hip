@@ -16,6 +16,7 @@
 // for the 16x16x32 operand read.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -1660,6 +1661,14 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const float* __restri
 
 }  // namespace
 
+// CUs the persistent kernel may take on stream s: the device's, or the stream's own budget (ag_set_stream_cus), a multiple of the 8 XCDs
+static int stream_cus_of(hipStream_t s) {
+    int n = device_cus();
+    const int sc = ag_stream_cus(s);
+    if (sc > 0 && sc < n) n = sc >= 8 ? (sc & ~7) : sc;
+    return n;
+}
+
 bool ag_resid_split_plan(int M, int N, int K, int* m1, int* m2, int* splits) {
     SplitPlan pl;
     if (!ag_gemm_big_eligible(M, N, K, K, N, N, AG_EPI_BIAS_RESID) || !split_plan(M, N, K, device_cus(), &pl)) return false;
@@ -1670,10 +1679,15 @@ bool ag_resid_split_plan(int M, int N, int K, int* m1, int* m2, int* splits) {
 }
 int ag_device_cus() { return device_cus(); }
 
+// 0: the shape does not split on the whole device (call ag_gemm).  Otherwise the LARGEST scratch any CU budget of a stream needs (the
+// launch plans its rounds for the CUs of ITS stream — a multiple of 8 up to the device's —, which this call does not know)
 extern "C" size_t ag_gemm_resid_split_scratch_bytes(int M, int N, int K) {
     SplitPlan pl;
     if (!ag_gemm_big_eligible(M, N, K, K, N, N, AG_EPI_BIAS_RESID) || !split_plan(M, N, K, device_cus(), &pl)) return 0;
-    return (size_t)pl.splits * (size_t)pl.m2 * (size_t)N * sizeof(float);
+    size_t need = (size_t)pl.splits * (size_t)pl.m2 * (size_t)N * sizeof(float);
+    for (int n = 8; n < device_cus(); n += 8)
+        if (split_plan(M, N, K, n, &pl)) need = std::max(need, (size_t)pl.splits * (size_t)pl.m2 * (size_t)N * sizeof(float));
+    return need;
 }
 
 extern "C" int ag_gemm_resid_split(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,
@@ -1681,12 +1695,18 @@ extern "C" int ag_gemm_resid_split(const void* d_A, int64_t lda, const void* d_W
                                    size_t scratch_bytes, void* stream) {
     AG_REQUIRE(d_A && d_W && d_C && d_R && d_scratch, "ag_gemm_resid_split: null pointer");
     SplitPlan pl;
+    hipStream_t s = (hipStream_t)stream;
     AG_REQUIRE(ag_gemm_big_eligible(M, N, K, lda, ldc, ldr, AG_EPI_BIAS_RESID) && split_plan(M, N, K, device_cus(), &pl),
                "ag_gemm_resid_split: M=%d N=%d K=%d does not split (ag_gemm_resid_split_scratch_bytes == 0: call ag_gemm)", M, N, K);
-    AG_REQUIRE(scratch_bytes >= (size_t)pl.splits * pl.m2 * N * sizeof(float), "ag_gemm_resid_split: scratch too small");
     AG_REQUIRE((N % 8) == 0 && (lda % 8) == 0 && (ldc % 8) == 0 && (ldr % 8) == 0 && ((uintptr_t)d_scratch % 16) == 0, "ag_gemm_resid_split: N, lda, ldc, ldr must be multiples of 8");
-    hipStream_t s = (hipStream_t)stream;
     AgProfScope prof(AG_EPI_BIAS_RESID, 2.0 * M * (double)N * K, ((double)M * K + (double)N * K + 2.0 * (double)M * N) * 2.0, s, nullptr, (double)M);
+    // the rounds are those of THIS stream's CU budget (the target forward of the two-stream training epoch runs on 192 / 224 CUs: the
+    // whole-device plan's "full rounds" are not whole there); a budget on which the tail does not split runs the plain kernel
+    const int n_cu = stream_cus_of(s);
+    if (n_cu != device_cus() && !split_plan(M, N, K, n_cu, &pl))
+        return run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, 1, 1, M, N, K, AG_EPI_BIAS_RESID, nullptr, nullptr, 0.f, d_stats_out,
+                       nullptr, nullptr, nullptr, s);
+    AG_REQUIRE(scratch_bytes >= (size_t)pl.splits * pl.m2 * N * sizeof(float), "ag_gemm_resid_split: scratch too small");
     if (pl.m1 > 0) {
         int rc = run_big(d_A, lda, d_W, d_bias, d_C, ldc, d_R, ldr, 1, 1, pl.m1, N, K, AG_EPI_BIAS_RESID, nullptr, nullptr, 0.f, d_stats_out,
                          nullptr, nullptr, nullptr, s, /*stats_rows=*/M);

@@ -710,6 +710,9 @@ def seq_compact_plan(mask_bits: Tensor, t: int, sync: bool = True):
 _HIP_RT = None
 
 
+_CU_PARTITIONS = {}
+
+
 def cu_partition_streams(device, cus_per_xcd_first: int):
     """Two HIP streams that share the device's CUs without overlapping: the first runs on CUs [0, c) of EVERY XCD, the second on the
     rest (hipExtStreamCreateWithCUMask; on MI355X mask bit i is CU i // 8 of XCD i % 8, measured with tools/probe/cumask_probe.cpp).
@@ -717,6 +720,9 @@ def cu_partition_streams(device, cus_per_xcd_first: int):
     -> (torch stream A, torch stream B, CUs of A, CUs of B)."""
     global _HIP_RT
     dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(cus_per_xcd_first))
+    if key in _CU_PARTITIONS:        # one pair per (device, split), for the life of the process: a CU-masked stream is never destroyed here, so
+        return _CU_PARTITIONS[key]   # its handle — the key of the library's CU-budget table — is never reused for another stream
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     per_xcd = n_cu // 8
     c = int(cus_per_xcd_first)
@@ -737,7 +743,8 @@ def cu_partition_streams(device, cus_per_xcd_first: int):
                 raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
             L.check(L.lib().ag_set_stream_cus(handle, hi - lo))
             out.append(torch.cuda.ExternalStream(handle.value, device=dev))
-    return out[0], out[1], 8 * c, n_cu - 8 * c
+    _CU_PARTITIONS[key] = (out[0], out[1], 8 * c, n_cu - 8 * c)
+    return _CU_PARTITIONS[key]
 
 
 def reload_knobs() -> None:
