@@ -848,8 +848,10 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
             const int sc = ag_stream_cus(s);
             if (sc > 0 && sc < n_cu) n_cu = sc;
             const long items = (long)a.R * a.heads;
-            static AgKnob k_s3min("AG_ATTN_STREAM3_MIN");      // items per CU from which the stream pays (tests: 1)
-            if (n_cu > 0 && items >= (long)k_s3min.get(6) * n_cu && items < 0x7FFFFFFFL) {
+            // items per CU from which the stream pays (tests: 1): n items per workgroup take n + 1 slots of ~2.7 us behind a ~4 us first fill, the
+            // workgroup-per-item kernel ~6.4 us per item and CU: from three items on
+            static AgKnob k_s3min("AG_ATTN_STREAM3_MIN");
+            if (n_cu > 0 && items >= (long)k_s3min.get(3) * n_cu && items < 0x7FFFFFFFL) {
                 static bool attr_set[16] = {};
                 int dev = 0;
                 AG_HIP_CHECK(hipGetDevice(&dev));

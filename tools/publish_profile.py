@@ -19,7 +19,7 @@ for lab, var in (("gemm<bias>", "0, 1"), ("gemm<bias+gelu>", "1, 1"), ("gemm<bia
     for old in (f"gemm_stream_kernel<{var}, false>", f"gemm_stream_kernel<{var}>", f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):
         if names[lab] not in summ and old in summ:
             names[lab] = old
-attn = [k for k in summ if k.startswith("attn_bf16_kernel")]
+attn = [k for k in summ if k.startswith("attn_stream3_kernel")] or [k for k in summ if k.startswith("attn_bf16_kernel")]
 if attn:
     names["masked_attention"] = attn[0]
 sys.path.insert(0, root)
