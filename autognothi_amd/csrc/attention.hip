@@ -453,7 +453,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         request_mask(team);
         mask_landed();
         stage(team);                                                      // (team t stages item t: read by nobody else before t's own barrier)
-        if (tw < 7) load_q(team, qf);
+        if (tw < 7 && tw * 32 < p.nq) load_q(team, qf);
         if (team + 2 < nj) request_mask(team + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -461,7 +461,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     __syncthreads();                                                      // opens slot 0 (and publishes the zeroed V rows)
     if (team == 1) asm volatile("s_barrier" ::: "memory");               // team 1 has nothing in slot 0
 
-    if (tw < 7) {
+    // (a query wave whose block holds no query — the CLS-only last layer: n_query = 1 — only stages its share, like the team's staging wave: that
+    // launch is then bound by its K/V stream alone, 330 -> 165 us)
+    if (tw < 7 && tw * 32 < p.nq) {
         for (int j = team; j < nj; j += 2) {
             const char* img = smem + (j % 3) * S3_IMG;
             const bool more = j + 2 < nj;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                 piece[tj] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
             const int q = tw * 32 + lr;
-            if (q < T) {
+            if (q < p.nq) {
                 const int item = item_of(j), row = item / p.heads, head = item - row * p.heads;
                 char* out = p.ctx + ((long)row * T + q) * p.H * 2 + (long)head * HD * 2;
 #pragma unroll
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
             asm volatile("s_barrier" ::: "memory");                      // opens slot j+2
         }
-    } else {                                                             // the team's staging wave
+    } else {                                                             // the team's staging wave, query waves without a query
         for (int j = team; j < nj; j += 2) {
             const bool more = j + 2 < nj;
             asm volatile("s_barrier" ::: "memory");
@@ -840,9 +842,9 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
         if (nwaves < 4) nwaves = 4;  // waves beyond the query blocks only help staging K/V
         // ViT: masked keys are zeroed K rows (no per-score mask work), 7 key blocks (T = 197) unrolled;
         // BERT fixed-length rows: per-score -inf; packed rows: visible keys only
-        // ViT rows of 193-200 tokens, every token a query, enough items for every CU: one K/V stream per CU (attn_stream3_kernel)
+        // ViT rows of 193-200 tokens (every token a query, or the first n_query), enough items for every CU: one K/V stream per CU (attn_stream3_kernel)
         static AgKnob k_s3("AG_ATTN_STREAM3");
-        if (mask_mode == AG_MASK_VIT_MUL && !a.cu && a.Tp == 224 && a.T > 192 && a.T <= S3_KROWS && a.nq == a.T && !(a.dbg & ~3) &&
+        if (mask_mode == AG_MASK_VIT_MUL && !a.cu && a.Tp == 224 && a.T > 192 && a.T <= S3_KROWS && !(a.dbg & ~3) &&
             (int)k_s3.get(1) != 0) {
             int n_cu = ag_device_cus();
             const int sc = ag_stream_cus(s);

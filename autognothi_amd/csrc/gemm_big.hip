@@ -151,7 +151,11 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
     constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
-    constexpr int SROW = 144;  // staged row: 128 B + 16 B pad (16-B aligned reads, <=2-way write conflicts)
+    // staged row: 128 B + 16 B pad (16-B aligned reads; writes conflict-free, the whole-row reads of two consecutive rows meet in four banks).
+    // (Round 5: 128-byte rows with the main loop's chunk swizzle c ^ ((r >> 1) & 7) instead — both accesses conflict-free, SQ_LDS_BANK_CONFLICT of the
+    // QKV / fc1 launches 57 k / 85 k cycles per CU -> the residual class's 14 k — measured SLOWER, same box: QKV 811 -> 817 us, fc1 1 355 -> 1 358: four
+    // per-lane staging addresses instead of one base + literal offsets cost more than the conflicts, which are not on the epilogue's critical path.)
+    constexpr int SROW = 144;
     // this wave's 128 x (sum, sumsq) partials, behind the 32 staged rows (4.6 KB) of its LDS piece.  LAYOUT 0: 16 KiB per wave from
     // the start of the ring; LAYOUT 1 (gemm_stream_kernel: step slot 0 already holds the NEXT tile's first step image): 8 KiB per
     // wave in step slot 1 — waves 0-3 in the A half (32 KiB ..), waves 4-7 in the W half (96 KiB ..)

@@ -148,26 +148,28 @@ def test_masked_attention_many_items(cuda_device, t, heads, rows, share, n_query
     _attention_case(cuda_device, BF16, 0, t, heads, rows, share, n_query, seed=t + rows)
 
 
-@pytest.mark.parametrize("t,heads,rows,share", [(197, 12, 24, 1), (197, 12, 56, 1), (197, 12, 64, 8), (193, 12, 43, 1), (200, 16, 50, 2),
-                                                (197, 3, 260, 1)])
-def test_masked_attention_stream3(cuda_device, ag_knobs, t, heads, rows, share):
+@pytest.mark.parametrize("t,heads,rows,share,n_query", [(197, 12, 24, 1, 0), (197, 12, 56, 1, 0), (197, 12, 64, 8, 0), (193, 12, 43, 1, 0), (200, 16, 50, 2, 0),
+                                                        (197, 3, 260, 1, 0), (197, 12, 56, 1, 1), (197, 12, 43, 1, 40)])
+def test_masked_attention_stream3(cuda_device, ag_knobs, t, heads, rows, share, n_query):
     """attn_stream3_kernel (one K/V stream per CU, two wave teams, three LDS images; ViT rows of 193-200 tokens): against the oracle
     and BIT FOR BIT against the workgroup-per-item kernel (same block bodies in the same order), with one to four items per
-    workgroup (odd and even counts, workgroups with a different number of items), shared layer-0 rows, T at both ends of the range."""
+    workgroup (odd and even counts, workgroups with a different number of items), shared layer-0 rows, T at both ends of the range, the first
+    n_query tokens as queries (the CLS-only last layer: query waves without a query only stage)."""
     from autognothi_amd import ops
     ag_knobs(AG_ATTN_STREAM3=1, AG_ATTN_STREAM3_MIN=1)
-    _attention_case(cuda_device, BF16, 0, t, heads, rows, share, 0, seed=t + rows)
+    _attention_case(cuda_device, BF16, 0, t, heads, rows, share, n_query, seed=t + rows)
+    nq = n_query or t
     h = heads * 64
     g = torch.Generator(device=cuda_device); g.manual_seed(rows)
     qkv = torch.randn((rows // share, t, 3 * h), device=cuda_device, generator=g).to(torch.bfloat16)
     keep = (torch.rand((rows, t - 1), device=cuda_device, generator=g) < 0.5).to(torch.int64)
     bits = ops.pack_mask(keep)
-    new = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16)
-    again = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16)
+    new = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16, n_query=n_query)[:, :nq]
+    again = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16, n_query=n_query)[:, :nq]
     ag_knobs(AG_ATTN_STREAM3=0)
-    old = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16)
-    assert torch.equal(new.view(torch.int16), old.view(torch.int16))
-    assert torch.equal(new.view(torch.int16), again.view(torch.int16))
+    old = ops.masked_attention(qkv, bits, rows, t, h, heads, share, 0, BF16, n_query=n_query)[:, :nq]
+    assert torch.equal(new.contiguous().view(torch.int16), old.contiguous().view(torch.int16))
+    assert torch.equal(new.contiguous().view(torch.int16), again.contiguous().view(torch.int16))
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
