@@ -151,6 +151,57 @@ __device__ __forceinline__ void attn_softmax_pv(f32x16_t s, const char* smem, co
     if (FENCE) __builtin_amdgcn_sched_barrier(0);   // keep the unrolled blocks from being interleaved into a spilling schedule
 }
 
+// The LAST key block of a row whose length leaves it at most 8 valid keys (T = 197 = 6 x 32 + 5: ViT).  Register i of lane half lh holds key
+// (i & 3) + 8 (i >> 2) + 4 lh of the block: only registers 0-3 can be valid, every other score is -inf, its probability exactly 0 — so the exponent
+// arguments, exponentials, sums, conversions and the -inf selects of twelve of the sixteen scores, and the second 16-key step of the PV product (all-zero
+// probabilities), are not issued: ~25 vector instructions + 6 MFMAs instead of ~125 + 8 for the block that was the dearest of the seven.  Same values in the
+// same order as attn_softmax_pv (adding exact zeros changes nothing): bit-identical outputs.
+template <int MODE>
+__device__ __forceinline__ void attn_softmax_pv_tail8(const f32x16_t s, const char* smem, const int kbyte, const int (&voff)[2][2],
+                                                      f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run, const int kvalid, const int lh, const float c2) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (4 * lh + i) < kvalid ? s[i] : NEG_BIG;
+    float bmax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bmax), __float_as_uint(bmax), false, false);
+        bmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    {
+        const float TAU = 8.0f / c2;
+        const bool need = bmax > m_run + TAU;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            const float m_new = need ? bmax : m_run;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+    }
+    const float mc = -m_run * c2;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = __builtin_amdgcn_exp2f(fmaf(v[i], c2, mc));
+        psum += v[i];
+    }
+    l_run += psum;
+    uint4 pf;
+    pf.x = pack_bf16x2(v[0], v[1]); pf.y = pack_bf16x2(v[2], v[3]); pf.z = 0u; pf.w = 0u;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + voff[dt][0] + kbyte));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + voff[dt][1] + kbyte));
+        const bf16x8_t vf = __builtin_shufflevector(__builtin_bit_cast(b16x4, v0), __builtin_bit_cast(b16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+        if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o0, 0, 0, 0);
+        else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pf), o1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int MODE, bool MASKOPS, bool FIRST, typename QF>
 __device__ __forceinline__ void attn_block(const char* smem, const int kbyte, const int (&koff)[4], const int (&voff)[2][2],
                                            const QF (&qf)[4], f32x16_t& o0, f32x16_t& o1, float& m_run, float& l_run,
@@ -167,7 +218,7 @@ __device__ __forceinline__ void attn_block(const char* smem, const int kbyte, co
     }
 
 // NKB > 0: the key-block loop is unrolled for exactly NKB blocks (ViT's 197 tokens = 7 blocks); NKB = 0: runtime loop.
-template <int MODE, bool MASKOPS, int NKB>
+template <int MODE, bool MASKOPS, int NKB, bool TAIL8 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bf16_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,10 +324,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             attn_block<MODE, MASKOPS, true>(smem, 0, koff, voff, qf, o0, o1, m_run, l_run,
                                             MASKOPS ? __builtin_amdgcn_readlane(mwords, 0) : 0u, NKB == 1 ? T : 32, lh, c2);
 #pragma unroll
-            for (int kb = 1; kb < NKB; ++kb)
+            for (int kb = 1; kb < NKB - 1; ++kb)
                 attn_block<MODE, MASKOPS, false>(smem, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run,
-                                                 MASKOPS ? __builtin_amdgcn_readlane(mwords, kb) : 0u,
-                                                 kb == NKB - 1 ? T - kb * 32 : 32, lh, c2);
+                                                 MASKOPS ? __builtin_amdgcn_readlane(mwords, kb) : 0u, 32, lh, c2);
+            if (NKB > 1) {
+                constexpr int kb = NKB > 1 ? NKB - 1 : 1;
+                if (TAIL8) {   // the short last block (the launcher knows T - 32 (NKB - 1) <= 8): attn_softmax_pv_tail8
+                    const f32x16_t sl = attn_scores(smem, kb * 32 * ROWB, koff, qf);
+                    attn_softmax_pv_tail8<MODE>(sl, smem, kb * 32 * ROWB, voff, o0, o1, m_run, l_run, T - kb * 32, lh, c2);
+                } else {
+                    attn_block<MODE, MASKOPS, false>(smem, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run,
+                                                     MASKOPS ? __builtin_amdgcn_readlane(mwords, kb) : 0u, T - kb * 32, lh, c2);
+                }
+            }
         } else {
             int ko[4], vo[2][2];   // walked by one key block per iteration
 #pragma unroll
@@ -465,7 +525,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     // launch is then bound by its K/V stream alone, 330 -> 165 us)
     if (tw < 7 && tw * 32 < p.nq) {
         for (int j = team; j < nj; j += 2) {
-            const char* img = smem + (j % 3) * S3_IMG;
             const bool more = j + 2 < nj;
             const int ln = s3_lane();
             const int lr = ln & 31, lh = ln >> 5;
@@ -482,6 +541,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
                     voff[dt][1] = S3_VBASE + k1 * ROWB + ((chunk ^ swz(k1)) << 4) + 8 * (tp & 1);
                 }
             }
+            {   // the image's LDS offset goes INTO the per-lane offsets, once per item, and the sums are made opaque: every K / V read of the item is then
+                // one VGPR + a literal in the instruction's offset field (with the image base as a scalar hipcc re-made the address of each of the eight
+                // transposed V reads of a block with a v_add_u32: 8 of a block's ~85 vector instructions)
+                const int ib = (j % 3) * S3_IMG;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { koff[ks] += ib; asm volatile("" : "+v"(koff[ks])); }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    voff[dt][0] += ib; voff[dt][1] += ib;
+                    asm volatile("" : "+v"(voff[dt][0]), "+v"(voff[dt][1]));
+                }
+            }
             f32x16_t o0, o1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
@@ -493,10 +564,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const bool compute = !(p.dbg & 1), staging = !(p.dbg & 2);   // (AG_ATTN_DBG ablations, wrong results: timing only)
             // ---- first half: key blocks 0-3
             if (compute) {
-                attn_block<MODE, false, true>(img, 0, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+                attn_block<MODE, false, true>(smem, 0, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
 #pragma unroll
                 for (int kb = 1; kb < 4; ++kb)
-                    attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+                    attn_block<MODE, false, false>(smem, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
             }
             asm volatile("s_barrier" ::: "memory");                      // opens slot j+1: the other team has left image (j+2) % 3
             // ---- second half: the team's next item on its way, key blocks 4-6, normalisation, stores
@@ -504,9 +575,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             if (compute) {
 #pragma unroll
                 for (int kb = 4; kb < 6; ++kb)
-                    attn_block<MODE, false, false>(img, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
-                const f32x16_t s6 = attn_scores(img, 6 * 32 * ROWB, koff, qf);
-                attn_softmax_pv<MODE, false, false>(s6, img, 6 * 32 * ROWB, voff, o0, o1, m_run, l_run, 0u, T - 192, lh, c2);
+                    attn_block<MODE, false, false>(smem, kb * 32 * ROWB, koff, voff, qf, o0, o1, m_run, l_run, 0u, 32, lh, c2);
+                const f32x16_t s6 = attn_scores(smem, 6 * 32 * ROWB, koff, qf);
+                attn_softmax_pv_tail8<MODE>(s6, smem, 6 * 32 * ROWB, voff, o0, o1, m_run, l_run, T - 192, lh, c2);   // (T <= 200: at most 8 valid keys)
             }
             request_mask(j + 4 < nj ? j + 4 : j);
             float l_tot;
@@ -869,7 +940,9 @@ int run_attention(const AttnArgs& a, int dtype, int hd, int mask_mode, hipStream
             }
         }
         void (*kern)(AttnArgs);
-        if (mask_mode == AG_MASK_VIT_MUL && !a.cu) kern = a.Tp == 224 ? attn_bf16_kernel<AG_MASK_VIT_MUL, false, 7> : attn_bf16_kernel<AG_MASK_VIT_MUL, false, 0>;
+        if (mask_mode == AG_MASK_VIT_MUL && !a.cu)
+            kern = a.Tp == 224 ? (a.T - 192 <= 8 ? attn_bf16_kernel<AG_MASK_VIT_MUL, false, 7, true> : attn_bf16_kernel<AG_MASK_VIT_MUL, false, 7>)
+                               : attn_bf16_kernel<AG_MASK_VIT_MUL, false, 0>;
         else if (a.cu) kern = attn_bf16_kernel<AG_MASK_BERT_ADD, false, 0>;
         else kern = attn_bf16_kernel<AG_MASK_BERT_ADD, true, 0>;
         AG_REQUIRE(!(mask_mode == AG_MASK_VIT_MUL && a.cu), "masked attention: packed rows are a BERT-mode path");
