@@ -228,7 +228,10 @@ int ag_row_stats_bf16(const void* d_x, int64_t ldx, int rows, int H, float* d_st
  * row r reads source row r / qkv_share (layer-0 sharing of q/k/v across the masks of one input).
  * d_mask_bits [R, ceil(T/32)]; d_ctx storage dtype [R, T, H].  head_dim must be 64.
  * n_query: only queries [0, n_query) of each row are computed/written (0 = all T; the surrogate's
- * last layer only needs the CLS query). */
+ * last layer only needs the CLS query).
+ * bf16, head_dim 64: ViT-mode rows of 193-200 tokens with at least three (row, head) items per CU run as ONE K/V request stream per
+ * CU (a persistent workgroup per CU, three LDS images; AG_ATTN_STREAM3=0 turns it off), every other shape as one workgroup per item;
+ * the two give bit-identical results. */
 int ag_masked_attention(const void* d_qkv, const uint32_t* d_mask_bits, void* d_ctx, int R, int T, int H,
                         int heads, int qkv_share, int mask_mode, int n_query, int dtype, void* stream);
 
