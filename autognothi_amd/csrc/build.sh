@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 OBJS=()
 PIDS=()
-for src in gemm.hip gemm_tn.hip gemm_big.hip side_mlp.hip probe.hip attention.hip sampler.hip elementwise.hip shapley.hip train.hip train_fused.hip encoder.cpp capi.cpp; do
+for src in gemm.hip gemm_tn.hip gemm_big.hip side_mlp.hip probe.hip attention.hip cls_last.hip sampler.hip elementwise.hip shapley.hip train.hip train_fused.hip encoder.cpp capi.cpp; do
   obj="$OUT/${src%.*}.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] || [ ../../include/autognothi_hip.h -nt "$obj" ]; then
     echo "hipcc $src"

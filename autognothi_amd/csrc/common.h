@@ -223,6 +223,13 @@ bool ag_side_map_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t
 int ag_side_map(const void* d_x, int64_t ldx, const void* d_w, const float* d_b, const void* d_resid, int64_t ldr, void* d_out,
                 int64_t ldo, int M, int N, int K, int gelu, const int* d_rows, hipStream_t s);
 
+// cls_last.hip — the last layer's attention of a CLS-only ViT forward without its key / value projection
+bool ag_cls_last_supported(int T, int H, int heads, int dtype);
+size_t ag_cls_last_scratch_bytes(int R, int H, int heads);
+int ag_cls_last_attention(const void* d_h, const float* d_stats, int cols, const uint32_t* d_mask_bits, const void* d_q, const void* w_kv_ln,
+                          const float* b_kv_ln, float ln_eps, void* d_ctx, int64_t ctx_row_stride, int R, int T, int H, int heads,
+                          void* d_scratch, size_t scratch_bytes, hipStream_t s);
+
 // gemm_big.hip
 bool ag_gemm_big_eligible(int M, int N, int K, int64_t lda, int64_t ldc, int64_t ldr, int epilogue);
 int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bias, void* d_C, int64_t ldc,

@@ -161,7 +161,20 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         if (can_fold1) pq = plan_w(Min, 3 * H, H, H, 3 * H, AG_EPI_BIAS, true, cols1);
         const bool fold1 = can_fold1 && pq.valid;
         if (fold1 && last_cls && in_share == 1 && !trim_off) pq_trim = plan_w(Min, 2 * H, H, H, 3 * H, AG_EPI_BIAS, true, cols1);
-        if (fold1 && pq_trim.valid) {
+        // ... and with only the CLS query read, the keys and values need not exist either (cls_last.hip): s_k = x_k . (W_k^T q) + b_k . q and
+        // o = W_v (sum_k p_k x_k) + b_v — one pass over the layer's input rows instead of the K / V projection and its attention launch
+        static AgKnob k_kvskip("AG_LAST_KV_SKIP");  // 0: project keys and values of the last layer as every other layer does (A/B, parity tests)
+        const size_t q_bytes = align_up((size_t)R * H * es);
+        const bool kv_skip = fold1 && pq_trim.valid && (int)k_kvskip.get(1) != 0 && ag_cls_last_supported(T, H, d->heads, dt) &&
+                             (size_t)M * 3 * H * es >= q_bytes + ag_cls_last_scratch_bytes(R, H, d->heads);
+        if (kv_skip) {
+            if (!fmt1) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));
+            TRY(ag_layernorm(h_in, dt, (int64_t)T * H, R, H, w.ln1_g, w.ln1_b, d->ln_eps, ws.xs, nullptr, dt, dyn, stream));
+            // the CLS queries, compact [R, H], at the head of the (otherwise unused) qkv buffer; the scratch of the path behind them
+            TRY(ag_gemm(ws.xs, H, w.w_qkv, w.b_qkv, ws.qkv, H, nullptr, 0, 0, 0, R, H, H, AG_EPI_BIAS, dt, nullptr, nullptr, 0.f, nullptr, dyn, stream));
+            TRY(ag_cls_last_attention(h_in, ws.st1, cols1, d_mask_bits, ws.qkv, (const char*)w.w_qkv_ln + (size_t)H * H * es, w.b_qkv_ln + H, d->ln_eps,
+                                      ws.ctx, (int64_t)T * H, R, T, H, d->heads, ws.qkv + q_bytes, (size_t)M * 3 * H * es - q_bytes, hs));
+        } else if (fold1 && pq_trim.valid) {
             // the last layer's attention reads the CLS query only (cls_only_last): keys and values of every token (the [H, 3H) rows of the
             // fused projection), queries of the R CLS rows — a third of this layer's QKV product is never computed.  The CLS rows are
             // normalised by the LayerNorm kernel (strided: one row per sequence) and projected with the unfolded query rows.
@@ -189,7 +202,7 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
                     3 * H, H, AG_EPI_BIAS, nullptr, 0, nullptr, nullptr));
         }
         fmt1 = 0;
-        TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
+        if (!kv_skip) TRY(ag_masked_attention(ws.qkv, d_mask_bits, ws.ctx, R, T, H, d->heads, in_share, d->kind, last_cls ? 1 : 0, dt, stream));
 
         // -- out-projection + residual(h_in) -> hx (compact [Mo,H]) --
         // narrow layer: out-proj + residual (+ BERT's attention-output LayerNorm) fused; needs row-aligned residual rows

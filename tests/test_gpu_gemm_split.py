@@ -106,3 +106,24 @@ def test_last_layer_query_trim_on_off(cuda_device, ag_knobs):
     for k in ("v_s", "v_1", "v_0"):
         np.testing.assert_allclose(on[k], off[k], rtol=0, atol=5e-3, err_msg=k)
         np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
+
+
+@pytest.mark.parametrize("case", ["vit_base_l12", "vit_large_l24"])
+def test_last_layer_without_kv_projection_on_off(cuda_device, ag_knobs, case):
+    """cls_only_last: the last layer reads the CLS query only, so its keys and values are never projected (csrc/cls_last.hip:
+    s_k = x_k . (W_k^T q) + b_k . q, o = W_v (sum_k p_k x_k) + b_v; AG_LAST_KV_SKIP, default) — against the projected form
+    (AG_LAST_KV_SKIP=0: K / V GEMM + the CLS-only attention launch) on the reference-made full-depth fixtures: the same surrogate
+    outputs up to bf16 rounding (the new form never rounds K and V), both within the bf16 bound of the reference."""
+    from util import build_case, run_fixture_case
+    from autognothi_amd import engine
+    c = build_case(case)
+    try:
+        on = run_fixture_case(c, cuda_device, "bf16")
+        ag_knobs(AG_LAST_KV_SKIP=0)
+        off = run_fixture_case(c, cuda_device, "bf16")
+    finally:
+        engine.set_precision("fp32")
+    for k in ("v_s", "v_1", "v_0"):
+        np.testing.assert_allclose(on[k], off[k], rtol=0, atol=5e-3, err_msg=k)
+        np.testing.assert_allclose(on[k], c["g"][k], rtol=0, atol=2e-2, err_msg=k)
+    assert np.abs(on["v_s"] - off["v_s"]).max() > 0      # (the path did run)
