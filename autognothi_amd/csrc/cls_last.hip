@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void cls_attend_kernel(ClsArgs p) {
     char* const wt_l = smem;                               // [16][RS]
     char* const x_l = smem + 16 * RS;                      // [2][16][RS]
     float* const sred = reinterpret_cast<float*>(smem + 48 * RS);          // [4][16 heads][16 tokens]
-    float2* const tokst = reinterpret_cast<float2*>(sred + 4 * 256);       // [2][16] (mean, rstd)
-    float* const hs = reinterpret_cast<float*>(tokst + 32);                // [16] S_h
+    float2* const tokst = reinterpret_cast<float2*>(sred + 4 * 256);       // [256] (mean, rstd) of every token of the row
+    float* const hs = reinterpret_cast<float*>(tokst + 256);               // [16] S_h
     float* const hc = hs + 16;                                             // [16] c_h
     float* const xch = hc + 16;                                            // [4 waves][32] per-wave exchange (alpha | final scale, offset)
     uint32_t* const mwl = reinterpret_cast<uint32_t*>(xch + 128);          // [8] the row's mask words
@@ -77,22 +77,31 @@ __global__ __launch_bounds__(256) void cls_attend_kernel(ClsArgs p) {
         if (row < heads) v = *reinterpret_cast<const uint4*>(p.wt + ((long)r * heads + row) * H + ch * 8);
         *reinterpret_cast<uint4*>(wt_l + row * RS + ch * 16) = v;
     }
-    // tile loader: 16 tokens x H bf16, global -> registers (rows past T: the last token, finite data whose probability is exactly 0)
-    // (eight named registers, not an array: hipcc kept an array that lives across the tile loop in scratch memory)
-    uint4 xr0 = {}, xr1 = {}, xr2 = {}, xr3 = {}, xr4 = {}, xr5 = {}, xr6 = {}, xr7 = {};
-#define CLS_FOR8(X) X(0, xr0) X(1, xr1) X(2, xr2) X(3, xr3) X(4, xr4) X(5, xr5) X(6, xr6) X(7, xr7)
-    float2 st_next = make_float2(0.f, 1.f);
-    const int ntile = (T + 15) >> 4;
-    // (per-thread element coordinates of the NLOAD chunks: compile-time strides)
-    auto tile_row = [&](int i) { return (i * 256 + tid) / CPR; };
-    auto tile_ch = [&](int i) { return (i * 256 + tid) % CPR; };
-    if (tid < 8) mwl[tid] = tid < p.Tw ? p.mask[(long)r * p.Tw + tid] : 0u;
+    // tile loader: 16 tokens x H bf16, global -> registers one tile ahead -> LDS (two workgroups per CU take turns on the memory latency).  Rows
+    // past T: the last token, finite data whose probability is exactly 0.  (Named registers, not arrays: hipcc kept a register array that lives across
+    // the tile loop in scratch memory.  Two register sets alternating by tile parity, for two tiles in flight, were if-converted by hipcc into
+    // unconditional loads + selects, i.e. a wait for the loads just issued.)
+    uint4 xa0 = {}, xa1 = {}, xa2 = {}, xa3 = {}, xa4 = {}, xa5 = {}, xa6 = {}, xa7 = {};
+#define CLS_FOR8(X, n) X(0, n##0) X(1, n##1) X(2, n##2) X(3, n##3) X(4, n##4) X(5, n##5) X(6, n##6) X(7, n##7)
 #define CLS_LD(i, reg) if (i < NLOAD) { int t = tl0 + tile_row(i); t = t < T ? t : T - 1; reg = *reinterpret_cast<const uint4*>(p.h + ((long)r * T + t) * H + tile_ch(i) * 8); }
-#define CLS_ST(i, reg) if (i < NLOAD) *reinterpret_cast<uint4*>(x_l + (buf * 16 + tile_row(i)) * RS + tile_ch(i) * 16) = reg;
-    { const int tl0 = 0; CLS_FOR8(CLS_LD) }
-    if (tid < 16) {       // (mean, rstd) of token t0 + tid from the slab partial sums, added in slab order
-        int t = 0 + tid;
-        t = t < T ? t : T - 1;
+#define CLS_ST(i, reg) if (i < NLOAD) *reinterpret_cast<uint4*>(x_l + (bufs * 16 + tile_row(i)) * RS + tile_ch(i) * 16) = reg;
+    const int ntile = (T + 15) >> 4;
+    auto tile_row = [&](int i) { return (i * 256 + tid) / CPR; };    // (per-thread element coordinates of the NLOAD chunks: compile-time strides)
+    auto tile_ch = [&](int i) { return (i * 256 + tid) % CPR; };
+#define CLS_LOAD_TILE(n, tile_)                                                   \
+    {                                                                             \
+        const int tl0 = ((tile_) < ntile ? (tile_) : ntile - 1) * 16;             \
+        CLS_FOR8(CLS_LD, n)                                                       \
+    }
+#define CLS_STORE_TILE(n, buf_)                                                   \
+    {                                                                             \
+        const int bufs = (buf_);                                                  \
+        CLS_FOR8(CLS_ST, n)                                                       \
+    }
+    if (tid < 8) mwl[tid] = tid < p.Tw ? p.mask[(long)r * p.Tw + tid] : 0u;
+    {   // (mean, rstd) of every token of the row from the slab partial sums, added in slab order: once, here — per tile, in front of the tile's loads,
+        // hipcc waited for them with vmcnt(0): one full memory round trip per tile for the whole workgroup (171 us per launch)
+        int t = tid < T ? tid : T - 1;
         const long m = (long)r * T + t;
         float sx = 0.f, sq = 0.f;
         for (int s = 0; s < p.nslab; ++s) {
@@ -100,8 +109,9 @@ __global__ __launch_bounds__(256) void cls_attend_kernel(ClsArgs p) {
             sx += w.x; sq += w.y;
         }
         const float mean = sx * p.inv_h;
-        st_next = make_float2(mean, rsqrtf(fmaxf(sq * p.inv_h - mean * mean, 0.f) + p.eps));
+        tokst[tid] = make_float2(mean, rsqrtf(fmaxf(sq * p.inv_h - mean * mean, 0.f) + p.eps));
     }
+    CLS_LOAD_TILE(xa, 0)
     __syncthreads();
     {   // S_h = sum_i Wt[h][i] (the bf16 values the score product reads), c_h = q_h . b_k'_h: 16 lanes per head
         const int head = tid >> 4, part = tid & 15;
@@ -123,25 +133,9 @@ __global__ __launch_bounds__(256) void cls_attend_kernel(ClsArgs p) {
 
     for (int it = 0; it < ntile; ++it) {
         const int buf = it & 1, t0 = it * 16;
-        CLS_FOR8(CLS_ST)
-        if (tid < 16) tokst[buf * 16 + tid] = st_next;
-        __syncthreads();                                   // tile `it` (and, first time, S_h / c_h) visible; sred of tile it-1 fully read
-        {   // the next tile on its way (the last iteration re-reads its own: unconditional, so the registers stay registers)
-            const int tn = it + 1 < ntile ? t0 + 16 : t0;
-            { const int tl0 = tn; CLS_FOR8(CLS_LD) }
-            if (tid < 16) {       // (mean, rstd) of token t0 + tid from the slab partial sums, added in slab order
-                int t = tn + tid;
-                t = t < T ? t : T - 1;
-                const long m = (long)r * T + t;
-                float sx = 0.f, sq = 0.f;
-                for (int s = 0; s < p.nslab; ++s) {
-                    const float2 w = *reinterpret_cast<const float2*>(p.stats + s * p.stats_slab + 2 * m);
-                    sx += w.x; sq += w.y;
-                }
-                const float mean = sx * p.inv_h;
-                st_next = make_float2(mean, rsqrtf(fmaxf(sq * p.inv_h - mean * mean, 0.f) + p.eps));
-            }
-        }
+        CLS_STORE_TILE(xa, buf)
+        __syncthreads();                                   // tile `it` (and, first time, S_h / c_h / the token statistics) visible; sred of the previous tile fully read
+        CLS_LOAD_TILE(xa, it + 1)                          // (unconditional: past the end the last tile again)
         // ---- scores: this wave's H/4 slice of the contraction
         {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -176,7 +170,7 @@ __global__ __launch_bounds__(256) void cls_attend_kernel(ClsArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = t0 + 4 * tg + j;
-                const float2 st = tokst[buf * 16 + 4 * tg + j];
+                const float2 st = tokst[t < 256 ? t : 255];
                 mn[j] = st.x; rs[j] = st.y;
                 const bool vis = (mword >> (4 * tg + j)) & 1u;
                 float s = vis ? fmaf(st.y, fmaf(-st.x, S, rv[j]), c) : 0.f;     // ViT: a masked key keeps logit 0
@@ -320,11 +314,13 @@ int ag_cls_last_attention(const void* d_h, const float* d_stats, int cols, const
     a.R = R; a.T = T; a.heads = heads; a.Tw = (T + 31) / 32; a.eps = ln_eps; a.inv_h = 1.0f / (float)H;
     {
         const int RS = 2 * H + 16;
-        const int lds = 48 * RS + 4 * 256 * 4 + 32 * 8 + 32 * 4 + 4 * 32 * 4 + 32;
+        const int lds = 48 * RS + 4 * 256 * 4 + 256 * 8 + 32 * 4 + 4 * 32 * 4 + 32;
         static bool attr_set[16][2] = {};
         int dev = 0;
         AG_HIP_CHECK(hipGetDevice(&dev));
         AG_REQUIRE(dev >= 0 && dev < 16, "ag_cls_last_attention: device index %d", dev);
+        // (accounted with the attention launches it replaces: 2 x 2 T H flops per row and head, one pass over the layer's input rows)
+        AgProfScope prof(AG_PROF_ATTENTION, 4.0 * R * (double)heads * T * H, ((double)R * T * H + 2.0 * R * heads * H) * 2.0, s);
         if (H == 768) {
             if (!attr_set[dev][0]) { AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cls_attend_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_set[dev][0] = true; }
             hipLaunchKernelGGL(cls_attend_kernel<768>, dim3(R), dim3(256), lds, s, a);
