@@ -100,7 +100,7 @@ def flops_per_forward(kind, p, T):
 
 def flops_executed(kind, p, T, K, frac=1.0, bf16=True):
     """F_exec: F_ref minus work legitimately skipped per row: embed + layer-0 QKV shared across the K masks,
-    last layer's attention/out-proj/MLP (and, ViT in bf16 mode: Q-projection) on the CLS token only; BERT token pruning
+    last layer's attention/out-proj/MLP (and, ViT in bf16 mode: Q-projection; K / V projection replaced by its algebraic form) on the CLS token only; BERT token pruning
     (frac = visible tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
     H, I, Lr = p["hidden_size"], p["intermediate_size"], p["num_hidden_layers"]
     if kind in ("vanilla_bert", "duo_vanilla_bert") and frac < 1.0 and Lr >= 2:
@@ -128,6 +128,12 @@ def flops_executed(kind, p, T, K, frac=1.0, bf16=True):
         # ... and, in the LayerNorm-folded bf16 ViT encoder (csrc/encoder.cpp: AG_LAST_Q_TRIM), the query projection of the CLS rows only
         if bf16 and kind in ("vanilla_vit", "duo_vanilla_vit", "froyo_vit") and Lr >= 2 and os.environ.get("AG_LAST_Q_TRIM", "1") != "0":
             f -= 2 * T * H * H * (T - 1) / T
+            # ... and no key / value projection at all in that layer (csrc/cls_last.hip: AG_LAST_KV_SKIP; H = 768 / 1 024): one pass of a
+            # heads-"query" x H-wide attention over the layer's input rows, framed by two [heads, H] x [H, H] products per row
+            heads = p["num_attention_heads"]
+            if H in (768, 1024) and heads * 64 == H and os.environ.get("AG_LAST_KV_SKIP", "1") != "0":
+                f -= 4 * T * H * H + 4 * T * H
+                f += 4 * heads * H * H + 4 * heads * T * H
     return float(f)
 
 
