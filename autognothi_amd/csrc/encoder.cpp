@@ -163,9 +163,12 @@ static int encoder_forward_impl(const ag_encoder_desc* d, const void* d_h0, int 
         if (fold1 && last_cls && in_share == 1 && !trim_off) pq_trim = plan_w(Min, 2 * H, H, H, 3 * H, AG_EPI_BIAS, true, cols1);
         // ... and with only the CLS query read, the keys and values need not exist either (cls_last.hip): s_k = x_k . (W_k^T q) + b_k . q and
         // o = W_v (sum_k p_k x_k) + b_v — one pass over the layer's input rows instead of the K / V projection and its attention launch
-        static AgKnob k_kvskip("AG_LAST_KV_SKIP");  // 0: project keys and values of the last layer as every other layer does (A/B, parity tests)
+        // AG_LAST_KV_SKIP = the rows from which the path is taken (default 64: below, its five short launches cost more than the projection of a few
+        // thousand token rows — one input x 32 masks: 16.55 -> 16.45 k fwd/s, four inputs: 26.9 -> 27.2 k); 0: never (A/B, parity tests), 1: always
+        static AgKnob k_kvskip("AG_LAST_KV_SKIP");
+        const int kvskip_rows = (int)k_kvskip.get(64);
         const size_t q_bytes = align_up((size_t)R * H * es);
-        const bool kv_skip = fold1 && pq_trim.valid && (int)k_kvskip.get(1) != 0 && ag_cls_last_supported(T, H, d->heads, dt) &&
+        const bool kv_skip = fold1 && pq_trim.valid && kvskip_rows > 0 && R >= kvskip_rows && ag_cls_last_supported(T, H, d->heads, dt) &&
                              (size_t)M * 3 * H * es >= q_bytes + ag_cls_last_scratch_bytes(R, H, d->heads);
         if (kv_skip) {
             if (!fmt1) TRY(ag_row_stats_bf16(h_in, H, Min, H, ws.st1, stream));

@@ -98,7 +98,7 @@ def flops_per_forward(kind, p, T):
     return float(f)
 
 
-def flops_executed(kind, p, T, K, frac=1.0, bf16=True):
+def flops_executed(kind, p, T, K, frac=1.0, bf16=True, rows=None):
     """F_exec: F_ref minus work legitimately skipped per row: embed + layer-0 QKV shared across the K masks,
     last layer's attention/out-proj/MLP (and, ViT in bf16 mode: Q-projection; K / V projection replaced by its algebraic form) on the CLS token only; BERT token pruning
     (frac = visible tokens / all tokens, measured): layers 1.. run on the packed rows (GEMMs x frac, attention ~ x frac^2)."""
@@ -131,7 +131,8 @@ def flops_executed(kind, p, T, K, frac=1.0, bf16=True):
             # ... and no key / value projection at all in that layer (csrc/cls_last.hip: AG_LAST_KV_SKIP; H = 768 / 1 024): one pass of a
             # heads-"query" x H-wide attention over the layer's input rows, framed by two [heads, H] x [H, H] products per row
             heads = p["num_attention_heads"]
-            if H in (768, 1024) and heads * 64 == H and os.environ.get("AG_LAST_KV_SKIP", "1") != "0":
+            kv_rows = int(os.environ.get("AG_LAST_KV_SKIP", "64"))     # (csrc/encoder.cpp: the rows from which the path is taken; 0 = never)
+            if H in (768, 1024) and heads * 64 == H and kv_rows > 0 and (rows is None or rows >= kv_rows):
                 f -= 4 * T * H * H + 4 * T * H
                 f += 4 * heads * H * H + 4 * heads * T * H
     return float(f)
@@ -377,7 +378,7 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
         pr = engine.last_packed_rows(dev)
         frac = pr / float(tb * job.K * job.T) if pr else 1.0
     f_targets = tb * job.K * flops_executed(job.kind if job.kind in ("vanilla_vit", "vanilla_bert") else
-                                            ("vanilla_vit" if job.vit else "vanilla_bert"), job.params, job.T, job.K, frac)
+                                            ("vanilla_vit" if job.vit else "vanilla_bert"), job.params, job.T, job.K, frac, rows=tb * job.K)
     f_grand = tb * flops_executed("vanilla_vit" if job.vit else "vanilla_bert", job.params, job.T, 1, 1.0)
     # backward = 2x forward for every trained GEMM; a frozen backbone is forwarded only (no dX below the head either)
     f_train = tb * (f_exp + 2.0 * (f_exp - (f_bb if frozen_backbone else 0.0)))
@@ -542,7 +543,7 @@ def compact_config_line(workload, dev, rank, world, batch, dist, steps=5, prune=
     el = el_e if el_g is None else min(el_e, el_g)
     value = job.R * world * steps / el
     frac_vis = packed / float(job.R * job.T) if (job.kind in ("vanilla_bert", "duo_vanilla_bert") and packed and engine_prunes(prune)) else 1.0
-    f_exec = flops_executed(job.kind, job.params, job.T, job.K, frac_vis)
+    f_exec = flops_executed(job.kind, job.params, job.T, job.K, frac_vis, rows=job.R)
     dom = max(st, key=lambda c: st[c][0])
     ms, fl, _, n = st[dom]
     return {"workload": WORKLOAD_LABEL[workload], "masks_per_input": job.K, "inputs_per_gpu_per_step": batch,
@@ -939,7 +940,7 @@ def main():
         total_rows = R * world * args.steps
         value = total_rows / elapsed
         frac = packed_rows / float(R * T) if (kind in ("vanilla_bert", "duo_vanilla_bert", "ltt_bert") and packed_rows) else 1.0
-        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac, bf16=args.precision == "bf16")
+        f_ref, f_exec = flops_per_forward(kind, params, T), flops_executed(kind, params, T, K, frac, bf16=args.precision == "bf16", rows=R)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
         roofline = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s"}
         if not args.graph:
