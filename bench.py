@@ -567,7 +567,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     # 48 inputs x 32 masks x 197 tokens = 1182 M-tiles of 256 rows: 3546 / 10638 / 14184 tiles for the N = 768 / 2304 / 3072
     # GEMMs = 13.85 / 41.6 / 55.4 rounds of 256 CUs (<= 1.1 % idle in the last round; B=16 loses 7.7 % on the N = 768 ones)
-    ap.add_argument("--batch", type=int, default=None, help="images (or sequences) per GPU per step (default: 96 for vit_base — 3 072 masked rows: the step's fixed costs, the 185 us mask sampler first, are amortised over twice the rows of rounds 1-4's 48: +0.9 % same box —, 48 otherwise)")
+    ap.add_argument("--batch", type=int, default=48, help="images (or sequences) per GPU per step (96 amortises the step's fixed costs over twice the rows: +0.5 % same box, secondary.small_batch_sweep)")
     ap.add_argument("--workload", default="vit_base", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", type=int, default=0, help="K masks per input (default: the BASELINE config's K)")
@@ -644,8 +644,6 @@ def main():
     if args.no_secondary:
         args.attr_batch = args.train_batch = 0
 
-    if args.batch is None:
-        args.batch = 96 if args.workload == "vit_base" else 48
     engine.set_precision(args.precision)
     job = Job(args.workload, dev, rank, world, args.batch, args.masks, args.precision)
     kind, params, K, B, P, T, R = job.kind, job.params, job.K, job.B, job.P, job.T, job.R
@@ -907,7 +905,7 @@ def main():
     # eager launches vs one hipGraph replay per step
     if not args.no_secondary and args.precision == "bf16" and not lean and "sweep" not in skip:
         sweep = []
-        for b_s in sorted({1, 4, 16, 48, args.batch}):
+        for b_s in (sorted({1, 4, 16, 48, 96, args.batch}) if args.workload == "vit_base" else sorted({1, 4, 16, 48, args.batch})):
             job.set_batch(b_s)
             n_s = 30 if b_s <= 4 else 10
             el_e, _ = timed(job.step, n_s, 3, dist, dev)
