@@ -37,6 +37,19 @@ def barrier() -> None:
         dist.barrier()
 
 
+def all_agree(flag: bool, device: Optional[torch.device] = None) -> bool:
+    """True on every rank iff ``flag`` is true on EVERY rank (MIN all-reduce; one rank: the flag).  For per-rank decisions that change the
+    ORDER in which a rank issues collectives — the two-stream training epoch issues the next group's target forward (which may contain an
+    all-gather for a batch with fewer inputs than ranks) before this group's gradient exchange: all ranks take that schedule or none does."""
+    _, w = world()
+    if w == 1:
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 class MainOnly:
     """Rank-0-only view of the reference's ExpEnv for the pipeline entry points (scripts/train_*.py): ``log`` / ``metrics`` /
     ``flush_cfg`` act on rank 0 and are no-ops elsewhere; everything else (``config``, ``model_path``, ``d_loader`` ...) reads
@@ -209,6 +222,10 @@ class GradBucketReducer:
         self.mode = (mode or os.environ.get("AG_GRAD_EXCHANGE", "fp32")).lower()
         if self.mode not in ("fp32", "bf16", "rsag"):
             raise ValueError(f"GradBucketReducer: unknown exchange mode {self.mode!r} (fp32 | rsag | bf16)")
+        # rsag / bf16 have run on gloo (world 2) and on RCCL at world size 1 only: on RCCL with more than one rank they need
+        # AG_GRAD_EXCHANGE_UNPROVEN=1 beside the mode until tests/test_gpu_rccl.py has covered them on two GPUs (no such box was available
+        # to the builder); without it the reducer falls back to the one in-place all-reduce per bucket
+        self._unproven_ok = os.environ.get("AG_GRAD_EXCHANGE_UNPROVEN", "0") == "1"
         self._pending: List[Tensor] = []
         self._pending_bytes = 0
         self._inflight: List[Tuple] = []
@@ -241,9 +258,10 @@ class GradBucketReducer:
     def _buffers(self, index: int, n: int, device, bf16: bool, w: int):
         have = self._bufs.get(index)
         if have is None or have[0].numel() < n or have[0].device != device or (bf16 and have[1] is None):
-            flat = torch.empty(n, dtype=torch.float32, device=device)
-            send = torch.empty(n, dtype=torch.bfloat16, device=device) if bf16 else None
-            recv = torch.empty(n, dtype=torch.bfloat16, device=device) if bf16 else None
+            # (zeroed once: the padding between segments and behind the last one takes part in every sum)
+            flat = torch.zeros(n, dtype=torch.float32, device=device)
+            send = torch.zeros(n, dtype=torch.bfloat16, device=device) if bf16 else None
+            recv = torch.zeros(n, dtype=torch.bfloat16, device=device) if bf16 else None
             have = (flat, send, recv)
             self._bufs[index] = have
         return have
@@ -255,10 +273,13 @@ class GradBucketReducer:
         ps = self._pending
         pad = self.PAD
         dev = ps[0].grad.device
-        bf16 = self.mode == "bf16"
+        mode = self.mode
+        if mode != "fp32" and w > 1 and dist.get_backend() == "nccl" and not self._unproven_ok:
+            mode = "fp32"
+        bf16 = mode == "bf16"
         # the layout of a bucket — offsets, the views that become .grad, the destinations of the pack — is the same step after step (the
         # backward reports the same parameters in the same order): built once per bucket, reused while the reported sequence matches
-        key = tuple(id(q) for q in ps)
+        key = tuple((id(q), tuple(q.grad.shape), str(q.grad.device)) for q in ps)
         lay = self._layouts.get(self.collectives)
         if lay is None or lay[0] != key or lay[1] != (str(dev), bf16, w):
             offs, n = [], 0
@@ -319,7 +340,7 @@ class GradBucketReducer:
             for t_ in (flat, send, recv):
                 t_.record_stream(side)
             self._inflight.append((work, flat, side))
-        elif self.mode == "rsag" and backend == "nccl":
+        elif mode == "rsag" and backend == "nccl":
             r = dist.get_rank()
             shard = flat[r * (n // w):(r + 1) * (n // w)]
             dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)

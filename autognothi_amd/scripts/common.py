@@ -123,13 +123,18 @@ def on_epoch_stream(fn):
     runs on whatever stream is current).  AG_EPOCH_STREAM=0: the caller's stream as it is."""
     import functools
 
+    import inspect
+    sig = inspect.signature(fn)
+
     @functools.wraps(fn)
-    def wrapper(env, device, *args, **kwargs):
+    def wrapper(*args, **kwargs):
+        # (the reference calls its epoch bodies by keyword as well: _explainer_epoch_train(env=..., device=...))
+        device = sig.bind(*args, **kwargs).arguments.get("device")
         if getattr(device, "type", None) != "cuda" or os.environ.get("AG_EPOCH_STREAM", "1") == "0":
-            return fn(env, device, *args, **kwargs)
+            return fn(*args, **kwargs)
         cur = torch.cuda.current_stream(device)
         if cur != torch.cuda.default_stream(device) or torch.cuda.is_current_stream_capturing():
-            return fn(env, device, *args, **kwargs)
+            return fn(*args, **kwargs)
         key = str(device)
         st = _EPOCH_STREAMS.get(key)
         if st is None:
@@ -137,7 +142,7 @@ def on_epoch_stream(fn):
         st.wait_stream(cur)
         try:
             with torch.cuda.stream(st):
-                return fn(env, device, *args, **kwargs)
+                return fn(*args, **kwargs)
         finally:
             cur.wait_stream(st)
     return wrapper
@@ -223,6 +228,19 @@ def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartitio
     if key not in _PARTITIONS:
         _PARTITIONS[key] = TrainPartition(device, c)
     return _PARTITIONS[key].arm()
+
+
+def train_partition_all_ranks(device: torch.device, m_explainer) -> Optional[TrainPartition]:
+    """``train_partition`` as ONE decision of all ranks.  Each rank's verdict depends on its own process history (import order) and on a
+    wall-clock probe of its own streams, and the two-stream epoch changes the ORDER of a rank's collectives — ``pipelined_targets`` issues the
+    targets of group g + 1, which for a batch with fewer inputs than ranks contain an all-gather (``gather_masks_within_inputs``), before the
+    gradient exchange of group g.  A rank on the two-stream schedule beside a rank on one stream would mismatch collectives on the one
+    communicator: every rank takes the schedule only if every rank can (MIN all-reduce of the local verdict; one rank: the local verdict)."""
+    from .. import distributed
+    part = train_partition(device, m_explainer)
+    if distributed.world()[1] > 1 and not distributed.all_agree(part is not None, device):
+        return None
+    return part
 
 
 def _cuda_tensors(obj):

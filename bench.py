@@ -390,7 +390,7 @@ def _train_step_rate(job, dist, n_train, tb, precision, graph=False):
     return tb * job.world * n_train / el, f_targets + f_grand + f_train, frozen_backbone
 
 
-def grad_exchange_overlap(job, dev, tb, steps=8):
+def grad_exchange_overlap(job, dev, tb, steps=40, rounds=3):
     """Exposed time of the gradient exchange of one explainer training step at ONE rank: every gradient of the vanilla explainer
     (ViT-base: 104.7 M fp32 = 419 MB) goes through distributed.GradBucketReducer — 64 MiB buckets, each an asynchronous RCCL all-reduce —
     (a) from inside the backward (training.GRAD_SINK: a bucket is in flight while the layers below still run) and (b) after it,
@@ -442,19 +442,30 @@ def grad_exchange_overlap(job, dev, tb, steps=8):
                 red.begin(0.5)
             return red.finish() if mode != "none" else 0
 
-        # five rounds over the legs, interleaved (a leg timed once, after the others, measured the box's drift: round 4's line had the
-        # overlapped leg slower than the serial one in one run and faster than NO exchange in the next); min and median per leg
+        # interleaved rounds over the legs, `steps` consecutive steps per sample, every step between two hipEvents on the compute stream
+        # (finish() makes it wait for the collectives); before the first sample the clocks are warmed for >= 1.5 s (a leg timed once, after
+        # the others, measured the box's drift: round 4's line had the overlapped leg slower than the serial one in one run and faster than NO
+        # exchange in the next; round 5's 8-step samples still ordered no-exchange above after-backward).  min and median per leg, and a
+        # verdict of its own: the legs must come out in the order their work implies or the line says "unstable"
         legs = [("none", "fp32"), ("overlapped", "fp32"), ("after_backward", "fp32"), ("overlapped", "bf16"), ("overlapped", "rsag")]
         samples = {lg: [] for lg in legs}
         n_coll = 0
         for lg in legs:
             for _ in range(2):
                 n_coll = max(n_coll, step(*lg))
-        for _ in range(7):
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 1.5:
+            for lg in legs[:3]:
+                step(*lg)
+            torch.cuda.synchronize()
+        for _ in range(rounds):
             for lg in legs:
+                for _ in range(3):
+                    step(*lg)
                 torch.cuda.synchronize()
                 evs = []
-                for _ in range(steps):      # every step between two events on the compute stream (finish() makes it wait for the collectives)
+                for _ in range(steps):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     step(*lg)
@@ -466,19 +477,24 @@ def grad_exchange_overlap(job, dev, tb, steps=8):
         mn = {lg: float(np.min(v)) for lg, v in samples.items()}
         gbytes = sum(q.numel() for q in params) * 4 / 1e9
         r3 = lambda x: round(x, 3)   # noqa: E731
-        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step (hipEvents around every step) at ONE rank, median (min) over 7 "
-                        "interleaved rounds of 8 steps: no exchange / bucketed exchange from inside the backward / the same buckets after the backward; "
-                        "exposed = median - no-exchange median.  A bucket is packed by ONE launch into its persistent flat buffer, .grad becomes a "
-                        "view of it (no torch.cat, no copy back); the collective runs in place: one all-reduce per bucket (default), reduce-scatter + "
-                        "all-gather, or bf16 all-to-all + fp32 sum on receipt + fp32 all-gather.  One rank: nothing crosses xGMI, the figures are packing + RCCL launches",
-                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": 7, "steps_per_sample": steps,
-                "ms_no_exchange": r3(med[legs[0]]), "ms_overlapped": r3(med[legs[1]]), "ms_after_backward": r3(med[legs[2]]),
-                "ms_overlapped_bf16_payload": r3(med[legs[3]]), "ms_overlapped_reduce_scatter_all_gather": r3(med[legs[4]]),
-                "min_ms": {"no_exchange": r3(mn[legs[0]]), "overlapped": r3(mn[legs[1]]), "after_backward": r3(mn[legs[2]]), "overlapped_bf16": r3(mn[legs[3]])},
-                "exposed_ms_overlapped": r3(med[legs[1]] - med[legs[0]]),
-                "exposed_ms_after_backward": r3(med[legs[2]] - med[legs[0]]),
-                "exposed_ms_overlapped_bf16_payload": r3(med[legs[3]] - med[legs[0]]),
-                "exposed_ms_overlapped_reduce_scatter_all_gather": r3(med[legs[4]] - med[legs[0]])}
+        eps = 0.03 * med[legs[0]]
+        # expected order: no exchange <= exchange from inside the backward <= the same exchange after the backward (each within eps = 3 %)
+        stable = (med[legs[0]] <= med[legs[1]] + eps) and (med[legs[0]] <= med[legs[2]] + eps) and (med[legs[1]] <= med[legs[2]] + eps)
+        return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step (hipEvents around every step) at ONE rank, "
+                        f"median and min over {rounds} interleaved rounds of {steps} steps after a 1.5 s warm-up: no exchange / bucketed exchange from inside the "
+                        "backward / the same buckets after the backward.  A bucket is packed by ONE launch into its persistent flat buffer, .grad becomes a "
+                        "view of it; the collective runs in place: one all-reduce per bucket (default), reduce-scatter + all-gather, or bf16 all-to-all + "
+                        "fp32 sum on receipt + fp32 all-gather.  One rank: nothing crosses xGMI, the figures are packing + RCCL launches.  unstable = the "
+                        "medians do not come out as no_exchange <= overlapped <= after_backward within 3 %: no exposed-time claim is made from such a line",
+                "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": rounds, "steps_per_sample": steps,
+                "unstable": not stable,
+                "no_exchange_ms": r3(med[legs[0]]), "overlapped_ms": r3(med[legs[1]]), "after_backward_ms": r3(med[legs[2]]),
+                "overlapped_bf16_payload_ms": r3(med[legs[3]]), "overlapped_reduce_scatter_all_gather_ms": r3(med[legs[4]]),
+                "min_ms": {"no_exchange": r3(mn[legs[0]]), "overlapped": r3(mn[legs[1]]), "after_backward": r3(mn[legs[2]]), "overlapped_bf16": r3(mn[legs[3]]),
+                           "overlapped_rsag": r3(mn[legs[4]])},
+                "exposed_ms_overlapped": None if not stable else r3(med[legs[1]] - med[legs[0]]),
+                "exposed_ms_after_backward": None if not stable else r3(med[legs[2]] - med[legs[0]]),
+                "exposed_ms_by_min": {"overlapped": r3(mn[legs[1]] - mn[legs[0]]), "after_backward": r3(mn[legs[2]] - mn[legs[0]])}}
     finally:
         D.world = keep_world
         _tr.MIXED_BF16 = keep_mixed
@@ -1003,6 +1019,24 @@ def main():
                                   "ref_equiv_tflops": round(value / world * f_ref / 1e12, 1),
                                   "exec_tflops": round(value / world * f_exec / 1e12, 1),
                                   "exec_frac_of_peak": round(value / world * f_exec / 1e12 / peak, 4)}
+        # flat scalars (the driver's parsed record keeps only scalar members of `roofline`): the whole-step figure the >= 50 % target is judged
+        # on, the three GEMM classes, attention, and the counter traffic of the other two classes
+        roofline["whole_step_exec_frac"] = roofline["whole_step"]["exec_frac_of_peak"]
+        roofline["whole_step_exec_tflops"] = roofline["whole_step"]["exec_tflops"]
+        roofline["f_exec_gflop_per_fwd"] = roofline["whole_step"]["f_exec_gflop_per_fwd"]
+        roofline["f_ref_gflop_per_fwd"] = roofline["whole_step"]["f_ref_gflop_per_fwd"]
+        if not args.graph:
+            pk = roofline.get("kernels", {})
+            for flat, lab_ in (("qkv_tflops", "gemm<bias>"), ("fc1_gelu_tflops", "gemm<bias+gelu>"), ("resid_tflops", "gemm<bias+residual>")):
+                if lab_ in pk:
+                    roofline[flat] = pk[lab_]["tflops"]
+                    roofline[flat.replace("_tflops", "_avg_us")] = pk[lab_]["avg_us"]
+            if "masked_attention" in pk:
+                roofline["attention_avg_us"] = pk["masked_attention"]["avg_us"]
+            for flat, lab_ in (("qkv_traffic_over_algorithmic", "gemm<bias>"), ("fc1_gelu_traffic_over_algorithmic", "gemm<bias+gelu>")):
+                v_ = roofline.get("traffic_over_algorithmic_by_class", {}).get(lab_)
+                if v_ is not None:
+                    roofline[flat] = v_
         if args.precision == "bf16" and not args.graph:
             # what the matrix cores of this board sustain on random operands with nothing else running (power cap):
             # context for `frac`, which stays priced against the 2.4 GHz datasheet peak
@@ -1043,6 +1077,53 @@ def main():
                                     "sample": f"torch-CPU fp32 port of the reference path, {cpu_rows} rows (1 input x K={K}) of the same workload; "
                                               f"thread counts {tried} tried (warm-up + best of 2 each, then best of 5 at the fastest), {cpu_threads} of the host's "
                                               f"{os.cpu_count()} logical CPUs were fastest"}
+        # ---- numbers only, LAST in the line (the driver keeps the line's tail): metric 2 and BASELINE configs 3-5 next to the headline
+        summ = {"masked_fwd_per_s": round(value, 1), "whole_step_exec_frac": roofline["whole_step_exec_frac"],
+                "dominant_frac": roofline.get("frac")}
+        for k_ in ("qkv_tflops", "fc1_gelu_tflops", "resid_tflops", "attention_avg_us"):
+            if k_ in roofline:
+                summ[k_] = roofline[k_]
+        vc = secondary.get("vendor_gemm_calibration", {}).get("shapes", {})
+        for k_ in ("qkv", "fc1", "fc2"):
+            if k_ in vc:
+                summ[f"vendor_{k_}_tflops"] = vc[k_]["vendor_tflops"]
+        if attrs_per_s is not None:
+            summ["shapley_attrs_per_s_per_image"] = round(attrs_per_s, 1)
+        for pt in secondary.get("small_batch_sweep", {}).get("points", []):
+            if pt["inputs_per_gpu"] in (1, 4, 16):
+                summ[f"B{pt['inputs_per_gpu']}_fwd_per_s"] = max(pt["eager_fwd_per_s"], pt["graph_fwd_per_s"])
+        bc = secondary.get("baseline_configs", {}).get("configs", {})
+        for short, key in (("bert_base", "bert_base_tayp_vanilla_seq128_K32"), ("bert_base_unpruned", "bert_base_tayp_vanilla_seq128_K32_token_pruning_off"),
+                           ("vit_large", "vit_large_imagenette_vanilla_K64"),
+                           ("vit_large_shard_1_input", "vit_large_imagenette_vanilla_K64_strong_scaling_shard_1_input_per_gpu"),
+                           ("vit_large_shard_8_masks", "vit_large_imagenette_vanilla_K64_strong_scaling_shard_8_masks_per_gpu")):
+            if key in bc:
+                summ[f"{short}_fwd_per_s"] = bc[key]["value"]
+                summ[f"{short}_exec_frac"] = bc[key]["exec_frac_of_peak"]
+                if short in ("bert_base", "vit_large"):
+                    summ[f"{short}_dominant_frac"] = bc[key]["frac"]
+        if train_block is not None:
+            summ["train_vit_base_images_per_s"] = train_block["value"]
+            summ["train_vit_base_frac"] = train_block["roofline"]["frac"]
+            summ["train_vit_base_launches_per_step"] = train_block["library_launches_per_step"]
+            if train_block.get("one_stream_value") is not None:
+                summ["train_vit_base_one_stream_images_per_s"] = train_block["one_stream_value"]
+        for wl, short in (("duo_bert_base", "train_duo_bert"), ("froyo_vit_base", "train_froyo_vit")):
+            if wl in c5:
+                summ[f"{short}_images_per_s"] = c5[wl]["value"]
+                summ[f"{short}_frac"] = c5[wl]["roofline"]["frac"]
+                summ[f"{short}_launches_per_step"] = c5[wl]["library_launches_per_step"]
+            for tb_ in (2, 4):
+                sh_ = c5.get("strong_scaling_shards", {}).get(f"{wl}_{tb_}_images_per_gpu")
+                if sh_:
+                    summ[f"{short}_{tb_}img_frac"] = max(sh_["frac"], sh_.get("graph_replay_frac") or 0.0)
+        gx = c5.get("gradient_exchange_overlap", {})
+        for k_ in ("no_exchange_ms", "after_backward_ms", "overlapped_ms", "unstable"):
+            if k_ in gx:
+                summ[f"exchange_{k_}"] = gx[k_]
+        if "cpu_baseline" in line:
+            summ["cpu_fwd_per_s"] = line["cpu_baseline"]["value"]
+        line["summary"] = summ
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -115,6 +115,45 @@ def _check_sharded_step_equals_unsharded(D, rank, world):
     assert abs(tot / n - float(full)) < 1e-5
 
 
+def _check_partition_verdict_is_collective(D, rank, world):
+    """the two-stream epoch changes the order of a rank's collectives (the next group's target forward — with an
+    all-gather for a batch of fewer inputs than ranks — before this group's gradient exchange), and each rank's local verdict comes from
+    its own process history and a wall-clock probe.  train_partition_all_ranks must hand every rank the SAME answer: the partition
+    forced on for rank 0 only -> None on both ranks; on for both -> both keep theirs."""
+    from autognothi_amd.scripts import common
+    assert D.all_agree(True) is True
+    assert D.all_agree(rank == 0) is False
+    assert D.all_agree(False) is False
+    keep = common.train_partition
+    sentinel = object()
+    try:
+        common.train_partition = lambda device, m: (sentinel if rank == 0 else None)
+        assert common.train_partition_all_ranks(torch.device("cpu"), None) is None
+        common.train_partition = lambda device, m: sentinel
+        assert common.train_partition_all_ranks(torch.device("cpu"), None) is sentinel
+        common.train_partition = lambda device, m: None
+        assert common.train_partition_all_ranks(torch.device("cpu"), None) is None
+    finally:
+        common.train_partition = keep
+    # ... and the epoch body's order of collectives with a ragged tail (3 inputs, then 1 input = fewer inputs than ranks: the targets of
+    # that batch all-gather): with the verdict None on both ranks pipelined_targets issues compute(g) and the steps of g strictly in turn
+    order = []
+
+    def compute(g):
+        order.append(("targets", g))
+        if g == "tail":
+            got = D.gather_masks_within_inputs(torch.full((1, 2), float(rank)), 1, 2)
+            assert got.shape[0] == 2
+        return g
+
+    for g, t in common.pipelined_targets(["full", "tail"], compute, common.train_partition_all_ranks(torch.device("cpu"), None)):
+        a = torch.nn.Parameter(torch.zeros(4)); a.grad = torch.full((4,), float(rank + 1))
+        D.allreduce_grads([a], average=True)
+        assert torch.allclose(a.grad, torch.full((4,), 1.5))
+        order.append(("step", g))
+    assert order == [("targets", "full"), ("step", "full"), ("targets", "tail"), ("step", "tail")], order
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -155,6 +194,7 @@ def _worker(rank, world, port, out):
         _check_overlapped_reducer(D, rank, world)
         _check_bf16_exchange(D, rank, world)
         _check_sharded_step_equals_unsharded(D, rank, world)
+        _check_partition_verdict_is_collective(D, rank, world)
         out[rank] = 1
     finally:
         dist.destroy_process_group()
