@@ -72,12 +72,14 @@ SIGNATURES = {
     "ag_gemm": (i32, [vp, i64, vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp]),
     "ag_gemm_ex": (i32, [vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp, i64, vp, i64, i32, vp, vp]),
     "ag_gemm_ex_splits": (i32, [i32, i32, i32]),
+    "ag_gemm_ex_group": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ag_rows_finish": (i32, [vp, i32, i64, vp, f32, u32, vp, vp, vp, vp, f32, vp, vp, i32, i32, vp]),
     "ag_rows_ln_bwd_scratch_floats": (sz, [i32, i32]),
     "ag_rows_ln_bwd": (i32, [vp, i32, i64, vp, vp, vp, f32, vp, vp, vp, f32, u32, vp, vp, vp, i32, vp, i32, i32, vp]),
     "ag_slab_reduce": (i32, [vp, i32, i64, i64, vp, i32, vp]),
     "ag_colsum_bf16_scratch_floats": (sz, [i32, i32]),
     "ag_colsum_bf16": (i32, [vp, i32, i32, i64, vp, i32, vp, vp]),
+    "ag_colsum_bf16_group": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "ag_cast_f32_many": (i32, [vp, vp, vp, vp, i32, vp]),
     "ag_pack_f32_many": (i32, [vp, vp, vp, vp, i32, f32, vp]),
     "ag_set_dropout_salt": (i32, [u32, vp]),
@@ -98,6 +100,9 @@ SIGNATURES = {
     "ag_side_linear_supported": (i32, [i32, i32, i32, i32]),
     "ag_side_linear": (i32, [vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, f32, vp, i64, vp, vp]),
     "ag_row_stats_bf16": (i32, [vp, i64, i32, i32, vp, vp]),
+    "ag_cls_last_is_supported": (i32, [i32, i32, i32, i32]),
+    "ag_cls_last_workspace_bytes": (C.c_size_t, [i32, i32, i32]),
+    "ag_cls_last_attention_rows": (i32, [vp, vp, i32, vp, vp, vp, vp, C.c_float, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "ag_masked_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ag_vit_im2col": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "ag_vit_assemble": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -341,3 +341,13 @@ int ag_cls_last_attention(const void* d_h, const float* d_stats, int cols, const
     }
     return AG_OK;
 }
+
+// C ABI (include/autognothi_hip.h): the kernel-level entry of the path, for the parity tests
+extern "C" int ag_cls_last_is_supported(int T, int H, int heads, int dtype) { return ag_cls_last_supported(T, H, heads, dtype) ? 1 : 0; }
+extern "C" size_t ag_cls_last_workspace_bytes(int R, int H, int heads) { return ag_cls_last_scratch_bytes(R, H, heads); }
+extern "C" int ag_cls_last_attention_rows(const void* d_h, const float* d_stats, int cols, const uint32_t* d_mask_bits, const void* d_q,
+                                          const void* w_kv_ln, const float* b_kv_ln, float ln_eps, void* d_ctx, int64_t ctx_row_stride, int R,
+                                          int T, int H, int heads, void* d_scratch, size_t scratch_bytes, void* stream) {
+    return ag_cls_last_attention(d_h, d_stats, cols, d_mask_bits, d_q, w_kv_ln, b_kv_ln, ln_eps, d_ctx, ctx_row_stride, R, T, H, heads, d_scratch,
+                                 scratch_bytes, (hipStream_t)stream);
+}

@@ -621,6 +621,18 @@ __device__ __forceinline__ void glds_x4b(const char* base0, const char* base1, u
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base0), "s"(base1), "s"(lds0) : "memory", "scc");
 }
+#ifdef AG_EXP_NT_A      // experiment (round 6): the A stream's pieces with the non-temporal hint
+__device__ __forceinline__ void glds_x4b_nt(const char* base0, const char* base1, uint32_t o0, uint32_t o1, uint32_t lds0) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "s_add_u32 m0, %5, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
+                 "s_add_u32 m0, %5, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4 nt\n\t"
+                 "s_add_u32 m0, %5, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base0), "s"(base1), "s"(lds0) : "memory", "scc");
+}
+#endif
 // one piece (the wave-uniform operands are forced into SGPRs: behind a group-dependent branch the compiler no longer proves them uniform)
 __device__ __forceinline__ void glds_x1(const char* base_, uint32_t o, uint32_t lds_) {
     const uint64_t bv = (uint64_t)(uintptr_t)base_;
@@ -1007,6 +1019,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         const uint32_t lds = ldsX_w + slot * LOP_BYTES + h * 4096;
         if (!t.edge) {
             const char* b0 = t.x + (long)step * LROWB + (long)(2 * h) * d16;
+#ifdef AG_EXP_NT_A
+            if (stA) glds_x4b_nt(b0, b0 + d16, vb[0], vb[1], lds); else
+#endif
             glds_x4b(b0, b0 + d16, vb[0], vb[1], lds);
         } else {
             uint32_t d = d16, om = t.off_max;

@@ -164,8 +164,9 @@ enum { E_STORE_BF16 = 0, E_STORE_F32 = 1, E_GELU_DUAL = 2, E_GELU_BWD = 3, E_SLA
        E_FWD = 5, E_FWD_GELU = 6, E_FWD_RESID = 7 };
 constexpr int STAT_LDS_BYTES = 1024;   // (mean, rstd) of the tile's 128 rows, behind the ring (E_FWD / E_FWD_GELU with ln_stats)
 
+// one unit (128 x 128 tile x contraction range) of the product `pin`; `block_id`: the unit's index in the product's own grid
 template <bool AC, bool BC, int EPI, int NST>
-__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_kernel(ExArgs pin) {
+__device__ __forceinline__ void gemm_ex_body(const ExArgs& pin, const int block_id) {
     constexpr int LPS = 8;   // LDS-DMA instructions per wave and step (4 per operand)
     constexpr bool FWD = EPI == E_FWD || EPI == E_FWD_GELU || EPI == E_FWD_RESID;
     ExArgs p = pin;
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_kernel(ExA
 
     const int tiles_n = (p.N + BT - 1) / BT, tiles_m = (p.M + BT - 1) / BT;
     const int nunits = tiles_m * tiles_n * p.splits;
-    if ((FWD || EPI == E_SLABS) && (int)blockIdx.x >= nunits) return;
+    if ((FWD || EPI == E_SLABS) && block_id >= nunits) return;
     // bijective XCD remap: units b, b + 8, ... share an XCD under round-robin dispatch and get consecutive work
-    const int b = blockIdx.x, xcd = b & 7, q_ = nunits >> 3, r_ = nunits & 7;
+    const int b = block_id, xcd = b & 7, q_ = nunits >> 3, r_ = nunits & 7;
     const int unit = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + (b >> 3);
     const int tile = unit / p.splits, sp = unit - tile * p.splits;
     const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
@@ -411,6 +412,27 @@ __global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_kernel(ExA
 }
 
 template <bool AC, bool BC, int EPI, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_kernel(ExArgs pin) {
+    gemm_ex_body<AC, BC, EPI, NST>(pin, (int)blockIdx.x);
+}
+
+// Several products of one operand order and epilogue in ONE launch (round 6: the dW products of the training step's backward, which
+// were one under-filled launch + a slab reduction each): product i owns blocks [first[i], first[i + 1]).  The bijective XCD remap of
+// a product's units then works on its own index range (a product's first block need not be a multiple of 8: consecutive units still
+// alternate over the XCDs).
+constexpr int EX_GROUP_MAX = 8;
+struct ExGroupArgs { ExArgs p[EX_GROUP_MAX]; int first[EX_GROUP_MAX + 1]; int count; };
+template <bool AC, bool BC, int EPI, int NST>
+__global__ __launch_bounds__(NTHREADS, NST == 2 ? 2 : 1) void gemm_ex_group_kernel(ExGroupArgs g) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < EX_GROUP_MAX; ++j) i += (j < g.count && b >= g.first[j]) ? 1 : 0;
+    i = __builtin_amdgcn_readfirstlane(i);
+    gemm_ex_body<AC, BC, EPI, NST>(g.p[i], b - g.first[i]);
+}
+
+template <bool AC, bool BC, int EPI, int NST>
 int launch_nst(const ExArgs& a, hipStream_t s) {
     constexpr int LDS = NST * 2 * TILE_BYTES + ((EPI == E_FWD || EPI == E_FWD_GELU) ? STAT_LDS_BYTES : 0);
     static bool attr_set[16] = {};
@@ -516,6 +538,81 @@ extern "C" int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d
     if (!a_col && !b_col) return dispatch_epi<false, false>(epi, a, s);
     if (!a_col && b_col) return dispatch_epi<false, true>(epi, a, s);
     return dispatch_epi<true, true>(epi, a, s);
+}
+
+namespace {
+template <bool AC, bool BC, int EPI>
+int launch_group(const ExGroupArgs& g, hipStream_t s) {
+    constexpr int NST = 2;
+    constexpr int LDS = NST * 2 * TILE_BYTES;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    AG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        AG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ex_group_kernel<AC, BC, EPI, NST>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_ex_group_kernel<AC, BC, EPI, NST>), dim3(g.first[g.count]), dim3(NTHREADS), LDS, s, g);
+    AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+}  // namespace
+
+// `count` products C_i = A_i . B_i of ONE operand order with the plain store epilogue (no bias), C_i fp32 or bf16, in as few launches as
+// the kernel's product table allows (EX_GROUP_MAX per launch): the same 128 x 128 units as ag_gemm_ex with splits = 1 — a group of
+// under-filled products covers the chip where each alone would not, so none of them needs contraction ranges and a slab reduction.
+extern "C" int ag_gemm_ex_group(int count, const void* const* d_A, const int64_t* lda, const void* const* d_B, const int64_t* ldb,
+                                const int* M, const int* N, const int* Kc, void* const* d_C, const int64_t* ldc, int a_col, int b_col,
+                                int c_dtype, void* stream) {
+    AG_REQUIRE(count >= 0 && (count == 0 || (d_A && lda && d_B && ldb && M && N && Kc && d_C && ldc)), "ag_gemm_ex_group: bad arguments");
+    AG_REQUIRE((a_col == 0 || a_col == 1) && (b_col == 0 || b_col == 1) && !(a_col && !b_col),
+               "ag_gemm_ex_group: operand orders (a_col, b_col) in {(0,0), (0,1), (1,1)}");
+    AG_REQUIRE(c_dtype == AG_BF16 || c_dtype == AG_F32, "ag_gemm_ex_group: bad c_dtype %d", c_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    static AgKnob epi_knob("AG_GEMM_EX_EPI");
+    for (int base = 0; base < count; base += EX_GROUP_MAX) {
+        ExGroupArgs g{};
+        int n = 0, blocks = 0;
+        double flops = 0.0, bytes = 0.0;
+        for (int i = base; i < count && i < base + EX_GROUP_MAX; ++i) {
+            if (M[i] == 0 || N[i] == 0) continue;
+            AG_REQUIRE(d_A[i] && d_B[i] && d_C[i], "ag_gemm_ex_group: null pointer in product %d", i);
+            AG_REQUIRE(M[i] > 0 && N[i] > 0 && Kc[i] > 0, "ag_gemm_ex_group: bad shape of product %d: M=%d N=%d Kc=%d", i, M[i], N[i], Kc[i]);
+            AG_REQUIRE(N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0 && ldc[i] % 4 == 0,
+                       "ag_gemm_ex_group: product %d: N and the operand row strides must be multiples of 8, ldc of 4", i);
+            AG_REQUIRE((a_col && b_col) || Kc[i] % 8 == 0, "ag_gemm_ex_group: product %d: Kc=%d must be a multiple of 8 unless both operands are stored [Kc, .]", i, Kc[i]);
+            AG_REQUIRE(!a_col || M[i] % 8 == 0, "ag_gemm_ex_group: product %d: a transposed A needs M %% 8 == 0 (M=%d)", i, M[i]);
+            AG_REQUIRE(((uintptr_t)d_A[i] % 16) == 0 && ((uintptr_t)d_B[i] % 16) == 0 && ((uintptr_t)d_C[i] % 16) == 0,
+                       "ag_gemm_ex_group: product %d: operands and C must be 16-byte aligned", i);
+            ExArgs& a = g.p[n];
+            a.A = (const char*)d_A[i]; a.lda_b = (long)lda[i] * 2;
+            a.B = (const char*)d_B[i]; a.ldb_b = (long)ldb[i] * 2;
+            a.M = M[i]; a.N = N[i]; a.Kc = Kc[i];
+            a.C = (char*)d_C[i]; a.ldc = ldc[i];
+            a.splits = 1;
+            a.lds_epilogue = epi_knob.get(1) != 0 && ldc[i] % 8 == 0;
+            g.first[n] = blocks;
+            blocks += ceil_div(M[i], BT) * ceil_div(N[i], BT);
+            flops += 2.0 * M[i] * (double)N[i] * Kc[i];
+            bytes += 2.0 * ((double)M[i] * Kc[i] + (double)N[i] * Kc[i]) + (c_dtype == AG_F32 ? 4.0 : 2.0) * (double)M[i] * N[i];
+            ++n;
+        }
+        if (n == 0) continue;
+        g.first[n] = blocks;
+        g.count = n;
+        AgProfScope prof(AG_PROF_GEMM_EX, flops, bytes, s);
+        int rc;
+        if (c_dtype == AG_F32) {
+            rc = (!a_col && !b_col) ? launch_group<false, false, E_STORE_F32>(g, s)
+               : (!a_col && b_col)  ? launch_group<false, true, E_STORE_F32>(g, s) : launch_group<true, true, E_STORE_F32>(g, s);
+        } else {
+            rc = (!a_col && !b_col) ? launch_group<false, false, E_STORE_BF16>(g, s)
+               : (!a_col && b_col)  ? launch_group<false, true, E_STORE_BF16>(g, s) : launch_group<true, true, E_STORE_BF16>(g, s);
+        }
+        if (rc != AG_OK) return rc;
+    }
+    return AG_OK;
 }
 
 // =====================================================================================================================

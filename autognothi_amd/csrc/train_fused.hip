@@ -355,6 +355,60 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     }
 }
 
+// the same column sums for several matrices in one launch (round 6: the bias gradients of the Linears whose dW products go out as one
+// grouped launch): matrix i owns blocks [first[i], first[i + 1]) of 32 columns each
+constexpr int COLSUM_GROUP_MAX = 16;
+struct ColsumGroup {
+    const bf16_t* x[COLSUM_GROUP_MAX]; float* out[COLSUM_GROUP_MAX]; long ldx[COLSUM_GROUP_MAX];
+    int M[COLSUM_GROUP_MAX], N[COLSUM_GROUP_MAX], first[COLSUM_GROUP_MAX + 1]; int count;
+};
+__global__ __launch_bounds__(256) void colsum_bf16_group_kernel(const ColsumGroup g) {
+    __shared__ float sacc[64][4][8];
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < COLSUM_GROUP_MAX; ++j) i += (j < g.count && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
+    const bf16_t* __restrict__ x = g.x[i];
+    float* __restrict__ out = g.out[i];
+    const int M = g.M[i], N = g.N[i], blk = (int)blockIdx.x - g.first[i];
+    const long ldx = g.ldx[i];
+    const int cg = threadIdx.x & 3, rg = threadIdx.x >> 2;
+    const int c = blk * 32 + cg * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < N) {          // (the row walk and the summation tree of colsum_bf16_kernel: the same bits)
+        int m = rg;
+        for (; m + 192 < M; m += 256) {
+            uint4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const uint4*>(x + (long)(m + 64 * j) * ldx + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[0] += __uint_as_float(u[j].x << 16); a[1] += __uint_as_float(u[j].x & 0xFFFF0000u);
+                a[2] += __uint_as_float(u[j].y << 16); a[3] += __uint_as_float(u[j].y & 0xFFFF0000u);
+                a[4] += __uint_as_float(u[j].z << 16); a[5] += __uint_as_float(u[j].z & 0xFFFF0000u);
+                a[6] += __uint_as_float(u[j].w << 16); a[7] += __uint_as_float(u[j].w & 0xFFFF0000u);
+            }
+        }
+        for (; m < M; m += 64) {
+            const uint4 u = *reinterpret_cast<const uint4*>(x + (long)m * ldx + c);
+            a[0] += __uint_as_float(u.x << 16); a[1] += __uint_as_float(u.x & 0xFFFF0000u);
+            a[2] += __uint_as_float(u.y << 16); a[3] += __uint_as_float(u.y & 0xFFFF0000u);
+            a[4] += __uint_as_float(u.z << 16); a[5] += __uint_as_float(u.z & 0xFFFF0000u);
+            a[6] += __uint_as_float(u.w << 16); a[7] += __uint_as_float(u.w & 0xFFFF0000u);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sacc[rg][cg][j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int col = blk * 32 + threadIdx.x;
+        if (col < N) {
+            float t = 0.f;
+            for (int gr = 0; gr < 64; ++gr) t += sacc[gr][threadIdx.x >> 3][threadIdx.x & 7];
+            out[col] = t;
+        }
+    }
+}
+
 constexpr int CAST_MAX = 96;
 struct CastTable {
     const float* src[CAST_MAX];
@@ -517,6 +571,28 @@ extern "C" int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float*
     AG_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)d_x % 16) == 0, "ag_colsum_bf16: N and ldx must be multiples of 8, x 16-byte aligned");
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_x, M, N, (long)ldx, d_out, accumulate);
     AG_LAUNCH_CHECK();
+    return AG_OK;
+}
+
+extern "C" int ag_colsum_bf16_group(int count, const void* const* d_x, const int* M, const int* N, const int64_t* ldx, float* const* d_out, void* stream) {
+    AG_REQUIRE(count >= 0 && (count == 0 || (d_x && M && N && ldx && d_out)), "ag_colsum_bf16_group: bad arguments");
+    for (int base = 0; base < count; base += COLSUM_GROUP_MAX) {
+        ColsumGroup g{};
+        int n = 0, blocks = 0;
+        for (int i = base; i < count && i < base + COLSUM_GROUP_MAX; ++i) {
+            AG_REQUIRE(d_x[i] && d_out[i] && M[i] >= 0 && N[i] > 0, "ag_colsum_bf16_group: bad matrix %d", i);
+            AG_REQUIRE(N[i] % 8 == 0 && ldx[i] % 8 == 0 && ((uintptr_t)d_x[i] % 16) == 0, "ag_colsum_bf16_group: matrix %d: N and ldx must be multiples of 8, x 16-byte aligned", i);
+            g.x[n] = (const bf16_t*)d_x[i]; g.out[n] = d_out[i]; g.ldx[n] = (long)ldx[i]; g.M[n] = M[i]; g.N[n] = N[i];
+            g.first[n] = blocks;
+            blocks += ceil_div(N[i], 32);
+            ++n;
+        }
+        if (n == 0) continue;
+        g.first[n] = blocks;
+        g.count = n;
+        hipLaunchKernelGGL(colsum_bf16_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+        AG_LAUNCH_CHECK();
+    }
     return AG_OK;
 }
 

@@ -402,6 +402,56 @@ def colsum_bf16(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = Fals
     return out
 
 
+def gemm_ex_group(pairs, order: Tuple[int, int] = TN, out_dtype: int = F32):
+    """[(a, b)] bf16 operand pairs of ONE operand order -> [C_i] (fresh fp32 / bf16 tensors) by ag_gemm_ex_group: one launch per 8
+    products, plain store, no bias.  order TN: a [Kc, M], b [Kc, N] -> C [M, N] (the dW products dY^T X of a backward)."""
+    import ctypes as C
+    if not pairs:
+        return []
+    a_col, b_col = order
+    n = len(pairs)
+    L.require_gpu(*[t_ for pr in pairs for t_ in pr])
+    ms, ns, ks = [], [], []
+    for a, b in pairs:
+        if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+            raise TypeError("gemm_ex_group: operands must be bf16")
+        (kc, m) = a.shape if a_col else a.shape[::-1]
+        (kc2, nn_) = b.shape if b_col else b.shape[::-1]
+        if kc != kc2:
+            raise ValueError(f"gemm_ex_group: contraction lengths differ ({kc} vs {kc2})")
+        ms.append(m); ns.append(nn_); ks.append(kc)
+    dev = pairs[0][0].device
+    outs = [torch.empty((m, nn_), dtype=storage_dtype(out_dtype), device=dev) for m, nn_ in zip(ms, ns)]
+    pa = (C.c_void_p * n)(*[a.data_ptr() for a, _ in pairs])
+    pb = (C.c_void_p * n)(*[b.data_ptr() for _, b in pairs])
+    pc = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    lda = (C.c_int64 * n)(*[a.stride(0) for a, _ in pairs])
+    ldb = (C.c_int64 * n)(*[b.stride(0) for _, b in pairs])
+    ldc = (C.c_int64 * n)(*[o.stride(0) for o in outs])
+    am, an, ak = (C.c_int * n)(*ms), (C.c_int * n)(*ns), (C.c_int * n)(*ks)
+    with L.on(dev):
+        L.check(L.lib().ag_gemm_ex_group(n, pa, lda, pb, ldb, am, an, ak, pc, ldc, a_col, b_col, out_dtype, L.stream()))
+    return outs
+
+
+def colsum_bf16_group(xs) -> list:
+    """column sums of several bf16 [M_i, N_i] matrices -> [fp32 [N_i]] in one launch per 16 (ag_colsum_bf16_group; the bits of colsum_bf16)."""
+    import ctypes as C
+    if not xs:
+        return []
+    L.require_gpu(*xs)
+    n = len(xs)
+    dev = xs[0].device
+    outs = [torch.empty(x.shape[1], dtype=torch.float32, device=dev) for x in xs]
+    px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    po = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    am, an = (C.c_int * n)(*[x.shape[0] for x in xs]), (C.c_int * n)(*[x.shape[1] for x in xs])
+    ld = (C.c_int64 * n)(*[x.stride(0) for x in xs])
+    with L.on(dev):
+        L.check(L.lib().ag_colsum_bf16_group(n, px, am, an, ld, po, L.stream()))
+    return outs
+
+
 def cast_many(pairs) -> None:
     """[(src fp32 tensor, dst bf16 or fp32 tensor of the same numel)] -> one ag_cast_f32_many launch (per 96 segments)."""
     import ctypes as C

@@ -41,6 +41,9 @@ SIDE_MIN_ROWS = int(os.environ.get("AG_TRAIN_SIDE_MIN_ROWS", "1024"))   # token 
 # 2-4 images per step, where the ~420 launches are host-bound).  Never used while a gradient sink is installed (N > 1 ranks: the
 # bucket reducer must be told, kernel by kernel, which gradients are final).
 GRAPH_STEP = os.environ.get("AG_TRAIN_GRAPH", "0") == "1"
+# dW products per grouped launch (round 6; _Side.defer_dw): 8 = the Linears of two layers; 0 / 1: every Linear's dW as its own
+# ag_gemm_ex launch (+ slab reduction), the round-4 form (A/B)
+DW_GROUP = int(os.environ.get("AG_TRAIN_DW_GROUP", "8"))
 
 
 def supported(module: nn.Module) -> bool:
@@ -64,6 +67,7 @@ class _Side:
         self.streams = [torch.cuda.Stream(device) for _ in range(N_SIDE)] if SIDE_STREAM else []
         self.turn = 0
         self.keep: List[Tensor] = []
+        self.pending: List[Tuple] = []     # deferred dW products (defer_dw)
         self.finals: List[Tensor] = []     # parameters whose gradient was produced on the MAIN stream since the last fork
         self.dirty = False
         # this backward runs its dW products in line (set per step by the trainers): under hipGraph capture — a one-branch graph replays at
@@ -95,6 +99,37 @@ class _Side:
         self.keep.extend(keep)
         self.dirty = True
 
+    def defer_dw(self, lw, dyb: Tensor, xb: Tensor, db: Optional[Tensor]) -> None:
+        """(round 6) the dW product of one Linear joins the pending group; DW_GROUP of them (two layers' Linears) leave as ONE
+        ag_gemm_ex_group launch + ONE grouped column-sum launch on the side stream.  Alone, a dW product of 36-144 tiles needed 3-6
+        contraction ranges to cover the chip and a slab reduction behind it (two or three launches of ~15 us per Linear, ten per layer);
+        eight of them are ~860 tiles: no contraction ranges, no reduction, two launches per two layers — and 64 MiB of gradients, one
+        exchange bucket (distributed.GradBucketReducer), become final together."""
+        self.pending.append((lw, dyb, xb, db))
+        if len(self.pending) >= DW_GROUP:
+            self.flush_dw()
+
+    def flush_dw(self) -> None:
+        if not self.pending:
+            return
+        group, self.pending = self.pending, []
+
+        def work():
+            gs = ops.gemm_ex_group([(dyb, xb) for _, dyb, xb, _ in group], ops.TN, F32)
+            sums = iter(ops.colsum_bf16_group([dyb for _, dyb, _, db in group if db is None]))
+            for (lw, dyb, xb, db), g in zip(group, gs):
+                bias_g = db if db is not None else next(sums)
+                off = 0
+                for mod in lw.mods:
+                    rows = mod.weight.shape[0]
+                    if mod.weight.requires_grad:
+                        T._acc_grad(mod.weight, g[off:off + rows], fresh=True)
+                    if mod.bias.requires_grad:
+                        T._acc_grad(mod.bias, bias_g[off:off + rows], fresh=True)
+                    off += rows
+        keep = [t_ for _, dyb, xb, db in group for t_ in (dyb, xb, db) if t_ is not None]
+        self.run(work, *keep)
+
     def final_on_main(self, *params: Tensor) -> None:
         """a gradient that a main-stream kernel wrote: reported to training.GRAD_SINK at a later fork (or at the join), on a
         stream that is ordered behind it."""
@@ -106,6 +141,7 @@ class _Side:
             T._final(*fin)
 
     def join(self) -> None:
+        self.flush_dw()
         if self.dirty:
             cur = torch.cuda.current_stream()
             for st in self.streams:
@@ -247,6 +283,9 @@ class Lin16:
         if not self.trainable:
             return
         lw = self.lw
+        if DW_GROUP > 1:
+            side.defer_dw(lw, dyb, xb, db)
+            return
 
         def work():
             n, k = dyb.shape[1], xb.shape[1]

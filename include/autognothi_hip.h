@@ -26,9 +26,11 @@
 extern "C" {
 #endif
 
-#define AG_ABI_VERSION 4   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
+#define AG_ABI_VERSION 5   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
                             * 3: ag_gemm_ex + the fused training kernels + ag_gemm_resid_split (additions only);
-                            * 4: ag_gemm_ws (additions only) */
+                            * 4: ag_gemm_ws (additions only);
+                            * 5: ag_cls_last_attention_rows (the kernel-level entry of the K / V-free last layer), ag_gemm_ex_group,
+                            *    ag_colsum_bf16_group (additions only) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
@@ -430,6 +432,13 @@ int ag_gemm_ex(const void* d_A, int64_t lda, int a_col, const void* d_B, int64_t
                int epilogue, const float* d_bias, void* d_C, int64_t ldc, int c_dtype, const void* d_aux, int64_t ld_aux,
                void* d_out2, int64_t ld_out2, int splits, float* d_slabs, void* stream);
 int ag_gemm_ex_splits(int M, int N, int Kc);
+/* `count` products C_i = A_i . B_i of ONE operand order (a_col, b_col as in ag_gemm_ex) with the plain store epilogue and no bias, C_i
+ * [M_i, N_i] in c_dtype (AG_F32 / AG_BF16), as ONE launch per 8 products: the backward of the bf16 training step hands the dW products
+ * of two layers (8 Linears: torch.autograd's grad_weight of every nn.Linear in scripts/train_explainer.py:197, train_duo_explainer.py:197)
+ * to one launch whose 128 x 128 units cover the chip, where each product alone needed contraction ranges + a slab reduction.  The arrays
+ * are HOST arrays of `count` entries.  Requirements per product as ag_gemm_ex. */
+int ag_gemm_ex_group(int count, const void* const* d_A, const int64_t* lda, const void* const* d_B, const int64_t* ldb, const int* M,
+                     const int* N, const int* Kc, void* const* d_C, const int64_t* ldc, int a_col, int b_col, int c_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels of the bf16 training step (round 4, csrc/train_fused.hip): the consumers of ag_gemm_ex's split-K slabs.  Each adds
@@ -459,6 +468,9 @@ int ag_slab_reduce(const float* d_slabs, int splits, int64_t slab_stride, int64_
  * ag_colsum_bf16_scratch_floats returns 0). */
 size_t ag_colsum_bf16_scratch_floats(int M, int N);
 int ag_colsum_bf16(const void* d_x, int M, int N, int64_t ldx, float* d_out, int accumulate, float* d_scratch, void* stream);
+/* the same column sums (same row walk and summation tree: the same bits) for `count` matrices in one launch per 16 (HOST arrays):
+ * the bias gradients of the Linears whose dW products ag_gemm_ex_group computes */
+int ag_colsum_bf16_group(int count, const void* const* d_x, const int* M, const int* N, const int64_t* ldx, float* const* d_out, void* stream);
 /* `count` fp32 -> bf16 conversions (h_dst_dtype[i] = AG_BF16) or fp32 copies (AG_F32) in ONE launch per 96 segments: every
  * weight of a model after the optimiser step, q | k | v landing side by side in their fused buffer.  HOST arrays of DEVICE pointers
  * (passed to the kernel by value: no table copy, graph-capturable); segments 16-byte aligned. */
@@ -536,6 +548,20 @@ int ag_reload_knobs(void);
  * 24-28 of every XCD's 32 CUs while the explainer's own, under-filled step runs on the caller's stream (the reference runs the two back
  * to back: scripts/train_explainer.py:153-198).  Also what a stream created with hipExtStreamCreateWithCUMask has to be registered with. */
 int ag_set_stream_cus(void* stream, int n_cu);
+
+/* The last layer's attention of a CLS-only ViT forward WITHOUT its key / value projection (csrc/cls_last.hip; the encoder takes this
+ * path from AG_LAST_KV_SKIP rows up).  Restates reference models/vanilla_vit.py:436-465 (Q / K / V Linear, scores / 8, scores * mask,
+ * soft-max, P V) for the ONE query per row and head that the heads read (models/vanilla_vit.py:51-56: hidden[:, 0]), with the layer's
+ * LayerNorm (models/vanilla_vit.py:369) folded:  d_h [R*T, H] bf16 = the residual stream entering the layer, d_stats its row statistics
+ * ((sum, sumsq) per slab of `cols` = 256 or 128 columns, slab-major: ag_row_stats_bf16), d_mask_bits [R, ceil(T/32)] key bits,
+ * d_q [R, H] bf16 = the CLS queries (already projected, bias included), w_kv_ln [2H, H] bf16 = the gamma-folded key | value rows of the
+ * fused projection and b_kv_ln [2H] their folded biases (b + W beta) -> d_ctx + r * ctx_row_stride (elements): the merged-heads
+ * attention output [H] of row r's CLS token.  ag_cls_last_supported: bf16, H = 768 / 1024, heads * 64 == H, 2 <= T <= 256. */
+int ag_cls_last_is_supported(int T, int H, int heads, int dtype);
+size_t ag_cls_last_workspace_bytes(int R, int H, int heads);
+int ag_cls_last_attention_rows(const void* d_h, const float* d_stats, int cols, const uint32_t* d_mask_bits, const void* d_q,
+                               const void* w_kv_ln, const float* b_kv_ln, float ln_eps, void* d_ctx, int64_t ctx_row_stride, int R, int T,
+                               int H, int heads, void* d_scratch, size_t scratch_bytes, void* stream);
 
 /* Measurement aid (bench.py): what this board's matrix cores sustain when a kernel issues nothing but
  * v_mfma_f32_16x16x32_bf16 from registers on every SIMD (two waves each) for `iters` x 16 instructions per

@@ -383,6 +383,14 @@ def gen_full_depth():
     gen_model_fixture("froyo_vit_base_l12", r_fvit.froyo_vit_recipe, fvit, "vit", B=1, K=32, mask_seed=3407, froyo=True)
 
 
+def gen_full_depth_b2():
+    """Round 6: ViT-base at full depth on TWO inputs x K = 32 = 64 masked rows — the row count from which the
+    encoder runs its last layer without the K / V projection (csrc/cls_last.hip, AG_LAST_KV_SKIP default 64), so that the default
+    threshold meets the reference's numbers (vit_base_l12 has 32 rows and stays on the projected form)."""
+    base = hparams("vit_base_imagenette_vanilla")
+    gen_model_fixture("vit_base_l12_b2", r_vvit.vanilla_vit_recipe, base, "vit", B=2, K=32, mask_seed=3407)
+
+
 def gen_full_depth_aux():
     """What the full-depth tolerances are derived from: the reference run in float64 (same synthetic weights and inputs cast
     up) next to its fp32 self — |ref32 - ref64| is the reference's OWN rounding noise at 12 / 24 layers, the yardstick for
@@ -745,6 +753,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mc_shapley":
         gen_mc_shapley()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full_depth_b2":   # round 6
+        gen_full_depth_b2()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bert_phi":   # round 4
         gen_bert_phi()

@@ -149,3 +149,37 @@ def test_gemm_ex_staged_epilogue_equals_direct_stores(cuda_device, ag_knobs, ord
         direct = run_all(da, db, dbias, du, m, n, kc)
         for x, y in zip(staged, direct):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("order", [NT, NN, TN], ids=["NT", "NN", "TN"])
+def test_gemm_ex_group_equals_the_single_launches(cuda_device, order):
+    """ag_gemm_ex_group (round 6: the dW products of two layers in one launch): every product of a group of 11 (two launches: 8 + 3;
+    ragged shapes, a one-tile product, products whose first block is not a multiple of 8) against float64 and BIT FOR BIT against the
+    same product as its own ag_gemm_ex launch with one contraction range."""
+    from autognothi_amd import ops
+    shapes = SHAPES[order] + [(768, 768, 1024), (136, 264, 512), (2304, 768, 1024), (768, 3072, 1024), (128, 128, 64), (392, 1000, 200)]
+    if order == TN:
+        shapes = [(m - m % 8, n, kc) for m, n, kc in shapes]
+    else:
+        shapes = [(m, n, kc - kc % 8) for m, n, kc in shapes]
+    ops_ = [_operands(order, m, n, kc, 300 + i, cuda_device) for i, (m, n, kc) in enumerate(shapes)]
+    for out_dtype in (ops.F32, ops.BF16):
+        outs = ops.gemm_ex_group([(o[1], o[2]) for o in ops_], order, out_dtype)
+        assert len(outs) == len(shapes)
+        for (m, n, kc), o, got in zip(shapes, ops_, outs):
+            single = ops.gemm_ex(o[1], o[2], order, EX_STORE, out_dtype=out_dtype)
+            assert got.shape == (m, n) and torch.equal(got, single), (order, m, n, kc)
+            ref = o[3] @ o[4].T
+            tol = dict(rtol=2e-4, atol=2e-4) if out_dtype == ops.F32 else dict(rtol=1e-2, atol=2e-2)
+            np.testing.assert_allclose(got.float().cpu().numpy(), ref, **tol, err_msg=f"{order} {m}x{n}x{kc}")
+
+
+def test_colsum_bf16_group_equals_colsum_bf16(cuda_device):
+    from autognothi_amd import ops
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn((m, n), generator=g).to(torch.bfloat16).to(cuda_device) for m, n in
+          [(1024, 768), (1576, 3072), (1576, 2304), (7, 8), (1024, 3072), (300, 40), (64, 768)] * 3]
+    outs = ops.colsum_bf16_group(xs)
+    for x, o in zip(xs, outs):
+        assert torch.equal(o, ops.colsum_bf16(x))
+        np.testing.assert_allclose(o.cpu().numpy(), x.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
