@@ -756,7 +756,10 @@ AgWsPlan ag_ws_plan(int M_bound, int N, int K, int64_t lda, int64_t ldc, int64_t
                                            resid_share, f->route, f->splits, m_expected);
         if (forced.valid) return forced;
     }
-    const bool big = dtype == AG_BF16 && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M_bound, N, K, lda, ldc, ldr, epilogue);
+    // (ag_gemm's own dispatch: AG_GEMM_SMALL sends every shape to the mid-size kernel, which folds no LayerNorm and writes no statistics —
+    // a planned route 0 must not promise them then)
+    static const bool force_small = getenv("AG_GEMM_SMALL") != nullptr;
+    const bool big = dtype == AG_BF16 && !force_small && epilogue != AG_EPI_BIAS_GELU_ADD && ag_gemm_big_eligible(M_bound, N, K, lda, ldc, ldr, epilogue);
     const double big_epi = resid ? 8.5 : (epilogue == AG_EPI_BIAS_GELU ? 6.0 : 4.5);
     // ---- ag_gemm as it is
     if (route < 0 || route == AG_WS_GEMM) {
@@ -971,11 +974,19 @@ extern "C" int ag_gemm_resid_ln_ws(const void* d_A, int64_t lda, const void* d_W
 extern "C" size_t ag_gemm_ws_scratch_bytes(int M, int N, int K, int epilogue) {
     if (epilogue != AG_EPI_BIAS_RESID || M <= 0 || N <= 0 || K <= 0) return 0;
     size_t need = ag_gemm_resid_split_scratch_bytes(M, N, K);
-    // (the slab route at its widest split the planner may pick: bounded at 256 MiB)
-    for (int s = 8; s >= 1; --s) {
-        const size_t b = (size_t)s * M * N * sizeof(float);
-        if (b <= ((size_t)256 << 20)) { need = b > need ? b : need; break; }
-    }
+    // what the planner would take for this shape in either statistics setting and slab width (the routes it may pick at a call: the plan is
+    // recomputed there with the call's own flags) — not the widest split that fits a fixed cap: four inputs x 32 masks of ViT-base reserved
+    // 230 MB per encoder workspace for a slab route the cost model never chooses at that size
+    for (int dyn = 0; dyn < 2; ++dyn)                       // (a device-side row count: priced for 0.55 of the bound, as the pruned BERT section plans)
+        for (int stats = 0; stats < 2; ++stats)
+            for (int cols_ok = 1; cols_ok <= 3; ++cols_ok)
+                for (int share = 1; share <= 2; ++share) {
+                    const AgWsPlan pl = ag_ws_plan(M, N, K, K, N, N, AG_EPI_BIAS_RESID, AG_BF16, dyn != 0, false, 0, stats != 0, cols_ok, share, -1, 0,
+                                                   dyn ? (int)(0.55 * M) : 0);
+                    if (pl.valid && pl.scratch_bytes > need) need = pl.scratch_bytes;
+                }
+    // (a forced route / split count — AG_WS_FORCE, the parity tests' explicit route argument — may ask for more: ag_gemm_ws checks the
+    // scratch it is given against the plan it runs and fails loudly)
     return need;
 }
 

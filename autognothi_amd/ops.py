@@ -558,6 +558,8 @@ def gemm_resid_ln_ws(a: Tensor, w: Tensor, bias: Optional[Tensor], r_pre: Tensor
         stats_out = new_row_stats(m, n, a.device)
     with L.on(a.device):
         need = int(L.lib().ag_gemm_ws_scratch_bytes(m, n, k, L.AG_EPI_BIAS_RESID))
+        if route >= 0:
+            need = max(need, max(1, splits if splits > 0 else 8) * m * n * 4)
         scratch = _scratch(a.device, (need + 3) // 4) if need else None
         L.check(L.lib().ag_gemm_resid_ln_ws(L.ptr(a), k, L.ptr(w), L.ptr(bias), L.ptr(out), n, L.ptr(r_pre), n, L.ptr(r_stats), L.ptr(ln_g),
                                             L.ptr(ln_b), float(ln_eps), m, n, k, L.ptr(stats_out), L.ptr(rows_dev), int(m_expected), route, splits,
@@ -608,6 +610,8 @@ def gemm_ws(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, m: Opti
     cols = C.c_int(0)
     with L.on(a.device):
         need = int(L.lib().ag_gemm_ws_scratch_bytes(m, n, k, epilogue))
+        if route >= 0:        # (a pinned route / split count — the parity tests — may ask for more slabs than the planner would)
+            need = max(need, max(1, splits if splits > 0 else 8) * m * n * 4)
         scratch = _scratch(a.device, (need + 3) // 4) if need else None
         L.check(L.lib().ag_gemm_ws(L.ptr(a), lda, L.ptr(w), L.ptr(bias), L.ptr(out), ldc, L.ptr(resid), ldr, rows_per_seq, resid_share,
                                    m, n, k, epilogue, L.AG_BF16, L.ptr(ln_stats), stats_in_cols, L.ptr(ln_colsum), float(ln_eps),

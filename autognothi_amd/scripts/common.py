@@ -243,6 +243,17 @@ def train_partition_all_ranks(device: torch.device, m_explainer) -> Optional[Tra
     return part
 
 
+def log_schedule(env, part: Optional[TrainPartition]) -> None:
+    """which schedule this epoch takes (the default depends on import order): always to the ``autognothi_amd.schedule``
+    logger (INFO), and into the epoch log when ``env.log_schedule`` is set (the reference's log has no such line: off by default)."""
+    import logging
+    msg = ("  > schedule: " + (f"two streams (target forward on {part.n_fwd // 8} CUs per XCD of the background stream)" if part is not None
+                               else "one stream"))
+    logging.getLogger("autognothi_amd.schedule").info(msg)
+    if env is not None and getattr(env, "log_schedule", False):
+        env.log(msg)
+
+
 def _cuda_tensors(obj):
     if isinstance(obj, torch.Tensor):
         if obj.is_cuda:

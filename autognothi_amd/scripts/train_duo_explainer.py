@@ -12,7 +12,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, on_epoch_stream, shard_auto, pipelined_targets, train_partition_all_ranks
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, mask_source as common_mask_source, on_epoch_stream, shard_auto, pipelined_targets, train_partition_all_ranks, log_schedule
 from .train_explainer import explainer_batch_loss, surrogate_null, surrogate_targets, surrogate_targets_lookahead
 
 
@@ -63,6 +63,7 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
 
     # (one rank: the targets of the NEXT group on a second stream beside this group's steps, scripts/common.TrainPartition)
     part = train_partition_all_ranks(device, m_explainer)
+    log_schedule(env, part)
 
     def compute(group):
         return surrogate_targets_lookahead(m_recipe, m_surrogate, [g_[1] for g_ in group], n_mask_samples, n_players, src,

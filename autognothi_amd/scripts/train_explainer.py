@@ -18,7 +18,7 @@ from torch import Tensor
 
 from .. import distributed, engine, ops
 from ..recipes.types import ModelRecipe
-from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, on_epoch_stream, pipelined_targets, shard, shard_auto, train_partition_all_ranks
+from .common import DROPOUT_RANK_STRIDE, Log, MaskSource, Span, device_rng, on_epoch_stream, pipelined_targets, shard, shard_auto, train_partition_all_ranks, log_schedule
 from .common import mask_source as common_mask_source
 
 
@@ -220,6 +220,7 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
     # group's steps run on the caller's (common.TrainPartition / pipelined_targets) — with N > 1 ranks beside the gradient exchange too;
     # otherwise (AG_TRAIN_PARTITION=0, no second hardware queue) the two alternate
     part = train_partition_all_ranks(device, m_explainer)
+    log_schedule(env, part)
 
     def batches():
         def compute(group):
