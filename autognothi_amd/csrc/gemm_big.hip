@@ -621,18 +621,6 @@ __device__ __forceinline__ void glds_x4b(const char* base0, const char* base1, u
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base0), "s"(base1), "s"(lds0) : "memory", "scc");
 }
-#ifdef AG_EXP_NT_A      // experiment (round 6): the A stream's pieces with the non-temporal hint
-__device__ __forceinline__ void glds_x4b_nt(const char* base0, const char* base1, uint32_t o0, uint32_t o1, uint32_t lds0) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\t"
-                 "s_add_u32 m0, %5, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\t"
-                 "s_add_u32 m0, %5, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4 nt\n\t"
-                 "s_add_u32 m0, %5, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4 nt\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(o0), "v"(o1), "s"(base0), "s"(base1), "s"(lds0) : "memory", "scc");
-}
-#endif
 // one piece (the wave-uniform operands are forced into SGPRs: behind a group-dependent branch the compiler no longer proves them uniform)
 __device__ __forceinline__ void glds_x1(const char* base_, uint32_t o, uint32_t lds_) {
     const uint64_t bv = (uint64_t)(uintptr_t)base_;
@@ -913,7 +901,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_line_kernel(BigArgs pin) {
 // to); after the epilogue: one barrier, tile constants, step 1's requests, and step 0 computes at once.
 // LDS behind the ring: two tails and two raw-partials areas (tiles alternate: the next tile's constants arrive while this tile's epilogue
 // reads its own), then the sink of the L2 touches
-constexpr int AG_GEMM_PIPE_DEFAULT = 0;
+// Round 6: the UPPER K half's twelve fragments are read from between the lower half's MFMAs into a second fragment set, so the upper
+// half's request phase holds requests only (1) — same request schedule, same waits, bit-identical results; -0.3 ... -1.2 % per launch on
+// the four encoder GEMMs, same box (profiles/HISTORY.md §12).  0 = every half's fragments in its own request phase (rounds 3-5; A/B via
+// tools/build_variant.sh -DAG_STREAM_HOIST_HI=0).  The MFMAs of both halves go through asm with the accumulator TIED (vdst = src2): left
+// to itself hipcc picks the untied form for the software-pipelined half, every accumulator moving to another register quad at each MFMA —
+// sixteen registers more in flight and spills inside the loop (§12); tied, both fragment sets fit in 211-229 registers.
+#ifndef AG_STREAM_HOIST_HI
+#define AG_STREAM_HOIST_HI 1
+#endif
 constexpr int STREAM_TAIL = NSLOT * SLOT_BYTES;                  // + par * TAIL_BYTES
 constexpr int STREAM_RAW = STREAM_TAIL + 2 * TAIL_BYTES;         // + par * 8192: 8 waves x 4 slabs x (32 sums | 32 sums of squares)
 constexpr int STREAM_SINK = STREAM_RAW + 2 * 8192;
@@ -927,7 +923,7 @@ constexpr int STREAM_LDS_BYTES = STREAM_SINK + 256;
 // (ds_read_b64 in the accumulator layout, chunk-swizzled image), read back as whole 128-byte rows and stored; the next tile's step 0
 // goes into the slot-0 area as soon as the first half has left it.  Everything is private to the wave.  (L2 touches of the residual lines
 // a step ahead of the pieces, from behind the waves' last wait: +6 % on the out-projection — one line per lane is the dearest request shape.)
-template <int EPI, int VAR = 0, bool RLDS = false, bool PIPE = false>
+template <int EPI, int VAR = 0, bool RLDS = false>
 __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     BigArgs p = pin;
     p.M = __builtin_amdgcn_readfirstlane(ag_dyn_clamp(p.M, p.dyn));   // (a scalar: everything derived from it — tile counts, edges, has_next — stays in SGPRs)
@@ -955,19 +951,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         const int ch = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
         vb[par] = (uint32_t)(row * ldx + ch * 16);
     }
-    // pipelined loop: group 0 stages A rows [32 gw, +32) (vbn) and pieces 4-7 of W rows [64 gw, +64) (vbo); group 1 pieces 0-3 of W rows
-    // [64 gw, +64) (vb) and A rows 128 + [32 gw, +32) (vbo)
-    const int ldo = stA ? (int)p.ldw_b : (int)p.lda_b;
-    const uint32_t d16o = (uint32_t)(16 * ldo);
-    uint32_t vbn[2] = {0u, 0u}, vbo[2] = {0u, 0u};
-    if (PIPE) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int ch = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
-            vbn[par] = (uint32_t)((gw * 32 + par * 8 + (lane >> 3)) * ldx + ch * 16);
-            vbo[par] = (uint32_t)(((stA ? gw * 64 : gw * 32) + par * 8 + (lane >> 3)) * ldo + ch * 16);
-        }
-    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t ldsX_w = lds0 + (stA ? 0 : LW_BASE) + gw * 8192;         // + slot * LOP_BYTES
     const int fr = lane & 15, fc = lane >> 4;
@@ -976,8 +959,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     asm volatile("" : "+v"(vA), "+v"(vW));
 
     // a tile of the stream: scalars only
-    // (xo / off_max_o / edge_o: the OTHER operand's rows of the tile — the pipelined loop's groups each stage half of both operands)
-    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; long cz; const char* xo; uint32_t off_max_o; int edge_o; };     // (whole words only: never copied through memory)
+    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; long cz; };     // (whole words only: never copied through memory)
     auto tile_of = [&](int b) {
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
@@ -1005,23 +987,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         }
         t.off_max = (uint32_t)((vrows - 1) * ldx + 112);
         t.edge = vrows < BT ? 1 : 0;
-        t.xo = t.x; t.off_max_o = 0u; t.edge_o = 0;
-        if (PIPE) {
-            const int vro = stA ? min(BT, p.N - t.n0) : min(BT, p.M - t.m0);
-            t.xo = stA ? p.W + (long)t.n0 * p.ldw_b : p.A + (long)t.m0 * p.lda_b;
-            if (BATCH) t.xo += (long)bz * p.bk_b;
-            t.off_max_o = (uint32_t)((vro - 1) * ldo + 112);
-            t.edge_o = vro < BT ? 1 : 0;
-        }
         return t;
     };
     auto refill4 = [&](const Tile& t, int step, int slot, int h) {
         const uint32_t lds = ldsX_w + slot * LOP_BYTES + h * 4096;
         if (!t.edge) {
             const char* b0 = t.x + (long)step * LROWB + (long)(2 * h) * d16;
-#ifdef AG_EXP_NT_A
-            if (stA) glds_x4b_nt(b0, b0 + d16, vb[0], vb[1], lds); else
-#endif
             glds_x4b(b0, b0 + d16, vb[0], vb[1], lds);
         } else {
             uint32_t d = d16, om = t.off_max;
@@ -1142,171 +1113,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         // tile's coordinates are worked out under their latency.  (Steps 0 and 1 were touched into L2 by the previous tile's last two
         // steps, step 2 is touched by step 0 as usual.)
         const Tile nxt = tile_of(has_next ? bn : bt);                 // (no next tile: the prefetch slots re-touch this one)
-        if constexpr (PIPE) {
-        // ---- the phased main loop with the fragment reads INSIDE the MFMA phases (round 6) ----
-        // Same two wave groups half a phase apart, same barriers.  What moved: a wave reads the twelve fragments of its NEXT MFMA phase from
-        // between the MFMAs of the current one (two fragment sets in registers; the accumulators are tied through asm MFMAs so that both fit),
-        // so the phase between two MFMA phases holds nothing but the barrier pair and the wave's four piece requests.  That moves every read one
-        // interval earlier, and with it the deadline of the pieces:
-        //   intervals of step s (barriers B1..B4): I1 group 0 requests | group 1 MFMA hi(s-1), reading lo(s)
-        //                                          I2 group 0 MFMA lo(s), reading hi(s) | group 1 requests
-        //                                          I3 group 0 requests | group 1 MFMA lo(s), reading hi(s)
-        //                                          I4 group 0 MFMA hi(s), reading lo(s+1) | group 1 requests
-        //   image of step s+1 (other slot): W rows (read by both groups; free after B4(s-1), needed at B4(s)): group 1, pieces 0-3 in I4(s-1) and
-        //   4-7 in I2(s); A rows [0, 128) (group 0's; free after B3(s-1), needed at B4(s)): group 0 in I1(s); A rows [128, 256) (group 1's; free
-        //   after B4(s-1), needed at B1(s+1)): group 0 in I3(s) — sixteen pieces in every interval, four per requesting wave.
-        // Waits: group 0 vmcnt(5) before B4 (its I1 pieces; the touch and the I3 pieces stay in flight) and vmcnt(0) behind its hi MFMAs; group 1
-        // vmcnt(0) behind its lo MFMAs.  Every MFMA phase ends with lgkmcnt(0): its reads have completed before the barrier that frees their rows.
-        typedef __attribute__((address_space(3))) const char* lds_cptr;
-        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) const u32x4v* lds_u4ptr;
-        u32x4v fw[2][4], fx[2][8];                                    // fragment sets: [0] = K half 0 of a step, [1] = half 1
-        auto rdX = [&](const int slot, const int kh, const int i) __attribute__((always_inline)) {
-            fx[kh][i] = *(lds_u4ptr)((lds_cptr)(uintptr_t)(vA ^ (kh ? 64u : 0u)) + slot * LOP_BYTES + i * (16 * LROWB));
-        };
-        auto rdW = [&](const int slot, const int kh, const int i) __attribute__((always_inline)) {
-            fw[kh][i] = *(lds_u4ptr)((lds_cptr)(uintptr_t)(vW ^ (kh ? 64u : 0u)) + slot * LOP_BYTES + i * (16 * LROWB));
-        };
-        // four pieces of 8 rows: `base` = first row's address of the step's columns, per-lane offsets o0 / o1 (+ 16 rows for pieces 2, 3)
-        auto req4 = [&](const char* base, const uint32_t d, const uint32_t o0, const uint32_t o1, const bool edge, const uint32_t off_max, const uint32_t row_off,
-                        const uint32_t lds) __attribute__((always_inline)) {
-            if (!edge) {
-                const char* b0 = base + (long)row_off * (d >> 4);
-                glds_x4b(b0, b0 + d, o0, o1, lds);
-            } else {
-                uint32_t dd = d, om = off_max, ro = row_off * (d >> 4);
-                asm volatile("" : "+s"(dd), "+s"(om), "+s"(ro));
-                glds_x4(base, min(o0 + ro, om), min(o1 + ro, om), min(o0 + ro + dd, om), min(o1 + ro + dd, om), lds);
-            }
-        };
-        // group 0: A rows [32 gw, +32) of the step image (the rows group 0's own waves multiply)
-        auto reqAtop = [&](const Tile& t, int step, int slot) __attribute__((always_inline)) {
-            req4(t.x + (long)step * LROWB, d16, vbn[0], vbn[1], t.edge, t.off_max, 0u, lds0 + slot * LOP_BYTES + gw * 4096);
-        };
-        // group 0: pieces 4-7 (rows 32..63) of W rows [64 gw, +64)
-        auto reqWhi = [&](const Tile& t, int step, int slot) __attribute__((always_inline)) {
-            req4(t.xo + (long)step * LROWB, d16o, vbo[0], vbo[1], t.edge_o, t.off_max_o, 32u, lds0 + LW_BASE + slot * LOP_BYTES + gw * 8192 + 4096);
-        };
-        // group 1: A rows 128 + [32 gw, +32) (the rows group 1's own waves multiply)
-        auto reqAbot = [&](const Tile& t, int step, int slot) __attribute__((always_inline)) {
-            req4(t.xo + (long)step * LROWB, d16o, vbo[0], vbo[1], t.edge_o, t.off_max_o, 128u, lds0 + slot * LOP_BYTES + 16384 + gw * 4096);
-        };
-        // top of a tile: its step 0 is in slot 0 (first tile, RLDS: on its way — this wave's part is waited for here); slot 1 has just been the
-        // epilogue's staging area: group 1 requests pieces 0-3 of step 1's W rows (its own staging piece: no other wave's business), which I4 of
-        // "step -1" would have carried; group 0's A rows of step 1 (other waves' staging pieces) go out behind the barrier
-        if (!stA) { refill4(cur, 1, 1, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        finish_constants(cur, par);
-        asm volatile("s_barrier" ::: "memory");                       // step 0's image and the tile's constants are visible
-        if (stA) reqAtop(cur, 1, 1);
-        if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 4] = t_; }
-#ifndef AG_PIPE_RD_IN_D
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { rdW(0, 0, i); rdX(0, 0, i); }    // the tile's first fragments (exposed)
-#pragma unroll
-        for (int i = 4; i < 8; ++i) rdX(0, 0, i);
-#endif
-        if (grp == 1) asm volatile("s_barrier" ::: "memory");
-        // one K = 32 half of step s (slot = s & 1).  rd: read the next half's fragments (not in a tile's last half); `last`: the tile's last step
-        auto halfq = [&](const int s, const int slot, const int kh, const bool zero, const bool rd, const bool last) __attribute__((always_inline)) {
-            asm volatile("s_barrier" ::: "memory");                        // "a"
-            // ---- request phase ---- ("step ns" = the next tile's step 0, or — RLDS — the first half of this tile's residual: rows [0, 64) of
-            // each wave's sub-tile into its own piece area of slot 0, group 0 in I1 / I3 and group 1 in I4 / I2 of the last steps)
-            {
-                const bool own1 = s + 1 < ns, own2 = s + 2 < ns;
-                if (grp == 0) {
-                    if (kh == 0) {                                         // I1: pieces 4-7 of step s+1's W rows
-                        if (own1) reqWhi(cur, s + 1, slot ^ 1);
-                        else if (RLDS) res4(cur, 0, 0);
-                        else if (has_next) reqWhi(nxt, 0, slot ^ 1);
-                    } else {                                               // I3: step s+2's A rows [0, 128) (own slot: last read in I2)
-                        const bool ownp = s + 2 < ns;
-                        prefetch(ownp ? cur : nxt, ownp ? s + 2 : s + 2 - ns);
-                        bool four = true;
-                        if (own2) reqAtop(cur, s + 2, slot);
-                        else if (RLDS) { if (last) res4(cur, 0, 1); else four = false; }
-                        else if (has_next && !last) reqAtop(nxt, 0, slot);
-                        else four = false;
-                        // step s+1's image: its A rows (requested an I3 ago, or at the top of the tile) and this step's I1 pieces
-                        if (!last) { if (four) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
-                    }
-                } else if (kh == 0) {                                      // I2: step s+1's A rows [128, 256)
-                    if (own1) reqAbot(cur, s + 1, slot ^ 1);
-                    else if (RLDS) res4(cur, 0, 1);
-                    else if (has_next) reqAbot(nxt, 0, slot ^ 1);
-                } else if (!last) {                                        // I4: pieces 0-3 of step s+2's W rows (own slot: last read in I3)
-                    bool four = true;
-                    if (own2) refill4(cur, s + 2, slot, 0);
-                    else if (RLDS) res4(cur, 0, 0);
-                    else if (has_next) refill4(nxt, 0, slot, 0);
-                    else four = false;
-                    if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's I2 pieces
-                }
-            }
-#ifdef AG_PIPE_RD_IN_D
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { rdW(slot, kh, i); rdX(slot, kh, i); }
-#pragma unroll
-            for (int i = 4; i < 8; ++i) rdX(slot, kh, i);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            asm volatile("s_barrier" ::: "memory");                        // "b"
-            // ---- MFMA phase: 8 groups of 4 (A fragment g against the four W fragments); behind groups 0-5 two reads of the next half's set ----
-            const int nb = kh ^ 1, rslot = kh ? slot ^ 1 : slot;
-            __builtin_amdgcn_s_setprio(1);
-#ifdef AG_PIPE_SN_MAJOR
-#pragma unroll
-            for (int sn = 0; sn < 4; ++sn) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    if (zero) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[sn][g]) : "v"(fw[kh][sn]), "v"(fx[kh][g]));
-                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[sn][g]) : "v"(fw[kh][sn]), "v"(fx[kh][g]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef AG_PIPE_RD_IN_D
-                if (rd) { rdW(rslot, nb, sn); rdX(rslot, nb, 2 * sn); rdX(rslot, nb, 2 * sn + 1); }
-#endif
-            }
-#else
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sn = 0; sn < 4; ++sn) {
-                    // (through asm: the accumulators stay where they are.  hipcc's own choice for this loop was the untied MFMA form, every
-                    // accumulator moving to another register quad at each MFMA: sixteen registers more in flight and spills inside the loop)
-                    if (zero) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[sn][g]) : "v"(fw[kh][sn]), "v"(fx[kh][g]));
-                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[sn][g]) : "v"(fw[kh][sn]), "v"(fx[kh][g]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef AG_PIPE_RD_IN_D
-                if (rd) {
-                    if (g < 4) { rdW(rslot, nb, g); rdX(rslot, nb, g); }
-                    else if (g < 6) { rdX(rslot, nb, 2 * g - 4); rdX(rslot, nb, 2 * g - 3); }
-                }
-#endif
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(0);
-            // the phase's reads have completed (they went out at least two groups ago); the pieces the NEXT barrier publishes have landed
-            if (!last && grp == 1 && kh == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // pieces 0-3 of step s+1's W rows (an I4 ago / the top of the tile)
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        halfq(0, 0, 0, true, true, false);
-        halfq(0, 0, 1, false, true, false);
-        int s = 1;
-        for (; s + 1 < ns; s += 2) {
-            halfq(s, 1, 0, false, true, false); halfq(s, 1, 1, false, true, false);
-            halfq(s + 1, 0, 0, false, true, false); halfq(s + 1, 0, 1, false, true, false);
-        }
-        halfq(s, 1, 0, false, true, true);
-        halfq(s, 1, 1, false, false, true);
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (the asm MFMAs' results are read by vector instructions next: hipcc does not know to wait)
-        if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 5] = t_; }
-        if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
-        } else {
         refill4(cur, 1, 1, 0); refill4(cur, 1, 1, 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // all but step 1's pieces (after the first tile: nothing but store acknowledgements)
         finish_constants(cur, par);
@@ -1315,6 +1121,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         // one K = 32 half of step `s` from ring slot SLOT (phases, request placement and waits: gemm_line_kernel).  `rt` / `rstep`:
         // the step image this step requests (its own tile's step s+1, or the next tile's step 0), `pt` / `pstep`: the one it touches.
         // (`last` && RLDS: the step's requests are the first half of the residual tile; nothing is waited for in it — the epilogue counts)
+#if AG_STREAM_HOIST_HI
+        // (AG_STREAM_HOIST_HI) the upper half's fragments, read during the lower half's MFMA phase
+        typedef unsigned int u32x4h __attribute__((ext_vector_type(4)));
+        u32x4h fwh[4], fxh[8];
+#endif
         auto half = [&](const int slot, const int kh, const bool refill, const Tile& rt, const int rstep, const Tile& pt, const int pstep, const bool zero,
                         const bool last) {
             asm volatile("s_barrier" ::: "memory");                        // "a"
@@ -1336,26 +1147,57 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const lds_cptr pa = (lds_cptr)(uintptr_t)(vA ^ x64) + slot * LOP_BYTES;
             const lds_cptr pw = (lds_cptr)(uintptr_t)(vW ^ x64) + slot * LOP_BYTES;
             u32x4v fw[4], fx[8];
+#if AG_STREAM_HOIST_HI
+            if (kh == 0) {
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) fw[i] = *(lds_u4ptr)(pw + i * (16 * LROWB));
 #pragma unroll
             for (int i = 0; i < 8; ++i) fx[i] = *(lds_u4ptr)(pa + i * (16 * LROWB));
+#if AG_STREAM_HOIST_HI
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fw[i] = fwh[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fx[i] = fxh[i];
+            }
+#endif
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0)
             asm volatile("" ::: "memory");
             if (grp == 1 && kh == 1 && !(RLDS && last)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");                        // "b"
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+#if AG_STREAM_HOIST_HI
+            if (kh == 0) {
+                const lds_cptr pa1 = (lds_cptr)(uintptr_t)(vA ^ 64u) + slot * LOP_BYTES;
+                const lds_cptr pw1 = (lds_cptr)(uintptr_t)(vW ^ 64u) + slot * LOP_BYTES;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int sn = 0; sn < 4; ++sn) {
+                        if (zero) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[sn][g]) : "v"(fw[sn]), "v"(fx[g]));
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[sn][g]) : "v"(fw[sn]), "v"(fx[g]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < 4) { fwh[g] = *(lds_u4ptr)(pw1 + g * (16 * LROWB)); fxh[g] = *(lds_u4ptr)(pa1 + g * (16 * LROWB)); }
+                    else if (g < 6) { fxh[2 * g - 4] = *(lds_u4ptr)(pa1 + (2 * g - 4) * (16 * LROWB)); fxh[2 * g - 3] = *(lds_u4ptr)(pa1 + (2 * g - 3) * (16 * LROWB)); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+#pragma unroll
+                    for (int sn = 0; sn < 4; ++sn)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[sn][g]) : "v"(fw[sn]), "v"(fx[g]));
+            }
+#else
 #pragma unroll
             for (int sn = 0; sn < 4; ++sn)
 #pragma unroll
                 for (int sm = 0; sm < 8; ++sm)
-#ifdef AG_OLD_ASM_MFMA
-                {
-                    if (zero) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[sn][sm]) : "v"(fw[sn]), "v"(fx[sm]));
-                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[sn][sm]) : "v"(fw[sn]), "v"(fx[sm]));
-                }
-#else
                     acc[sn][sm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[sn]), __builtin_bit_cast(bf16x8_t, fx[sm]),
                                                                           zero ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[sn][sm], 0, 0, 0);
 #endif
@@ -1380,9 +1222,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             step(s + 1, 0, true, false, false);
         }
         step(s, 1, has_next, false, true);                                              // s == ns - 1: requests the NEXT tile's step 0 into slot 0
+#if AG_STREAM_HOIST_HI
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (the asm MFMAs' results are read by vector instructions next: hipcc's hazard recogniser does not see them)
+#endif
         if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 5] = t_; }
         if (grp == 0) asm volatile("s_barrier" ::: "memory");              // pairs group 1's extra first barrier
-        }   // !PIPE
 
         // (the next tile's step 0 has landed in slot 0: the last step's waits; the epilogue stages through slot 1.)  The next tile's constants
         // are requested now, into the other tail: they land under the epilogue
@@ -1532,17 +1376,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     }
 }
 
-template <int EPI, int VAR, bool RLDS = false, bool PIPE = false>
+template <int EPI, int VAR, bool RLDS = false>
 int launch_stream_var(const BigArgs& a, hipStream_t s) {
-    if constexpr (!RLDS && !PIPE && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2 || VAR == 3)) {
+    if constexpr (!RLDS && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2 || VAR == 3)) {
         // residual through LDS: identity residual row map (share == 1: every layer but the first) and 32-bit byte offsets into R
         static AgKnob k_rlds("AG_GEMM_RLDS");
         if (a.R && a.share == 1 && (unsigned long long)a.M * (unsigned long long)a.ldr < 0x7FFFFFF0ull && (int)k_rlds.get(1) != 0)
             return launch_stream_var<EPI, VAR, true>(a, s);
-    }
-    if constexpr (!PIPE) {
-        static AgKnob k_pipe("AG_GEMM_PIPE");      // 1: the software-pipelined main loop (round 6), 0: the two-group phased one
-        if ((int)k_pipe.get(AG_GEMM_PIPE_DEFAULT) != 0) return launch_stream_var<EPI, VAR, RLDS, true>(a, s);
     }
     // per device (a process may drive several: the attribute belongs to the device's copy of the code object, and partitions
     // differ in their CU count)
@@ -1553,7 +1393,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess) return ag_fail(AG_ERR_HIP, "gemm_stream: hipGetDevice");
     if (dev < 0 || dev >= MAX_DEV) return ag_fail(AG_ERR_UNSUPPORTED, "gemm_stream: device index %d", dev);
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS, PIPE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream): %s", hipGetErrorString(e));
         hipDeviceProp_t prop;
@@ -1582,7 +1422,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
             if (grid > n_cu) grid = n_cu;
         }
     }
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS, PIPE>), dim3(grid), dim3(NT), STREAM_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(grid), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
     return AG_OK;
 }
