@@ -189,7 +189,8 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         ncl[sn] = n < p.N ? n : p.N - 4;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!OUT_F32) asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring (the staging buffers reuse it)
+    // every wave is done reading the ring (the staging buffers reuse it)
+    if (!OUT_F32) asm volatile("s_barrier" ::: "memory");
     // residual row of output row m: ((m / T) / share) * T + (m % T); walked incrementally (m advances by 16)
     int r_t = 0, r_seq_rem = 0;
     long r_base = 0;  // (seq / share) * T

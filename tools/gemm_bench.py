@@ -17,6 +17,9 @@ for name, n, k, epi in shapes:
     w = ((torch.rand((n, k), device=dev, generator=g) * 2 - 1) / k ** 0.5).to(torch.bfloat16)
     b = torch.rand(n, device=dev, generator=g)
     r = torch.rand((M, n), device=dev, generator=g).to(torch.bfloat16) if epi == L.AG_EPI_BIAS_RESID else None
+    if os.environ.get("GB_ZERO") == "1":      # all-zero operands: the same instruction stream and cycles, less switching power (the clock the chip holds)
+        a.zero_(); w.zero_()
+        if r is not None: r.zero_()
     out = ops.gemm(a, w, b, epi, L.AG_BF16, resid=r)
     ref = a[:4096].float() @ w.float().T + b
     if epi == L.AG_EPI_BIAS_RESID: ref = ref + r[:4096].float()

@@ -23,7 +23,7 @@ for part in spec.split(";"):
     name, _, kv = part.partition(":")
     env = dict(x.split("=", 1) for x in kv.split(",") if x)
     variants.append((name, env))
-all_keys = sorted({k for _, e in variants for k in e if k != "LIB"})
+all_keys = sorted({k for _, e in variants for k in e if k not in ("LIB", "DATA")})
 LIBDIR = os.path.dirname(L.LIB_PATH)
 
 
@@ -46,10 +46,15 @@ for name, n, k, epi in shapes:
     b = torch.rand(n, device=dev, generator=g)
     r = torch.rand((M, n), device=dev, generator=g).to(torch.bfloat16) if epi == L.AG_EPI_BIAS_RESID else None
     outs, times = {}, {v[0]: [] for v in variants}
+    # DATA=zero: the same launches on all-zero operands (same instruction stream and cycles; what differs is switching power, i.e. the clock
+    # the chip holds: MI355X_MICROARCH.md 'DVFS give-back' item 1)
+    az, wz = torch.zeros_like(a), torch.zeros_like(w)
+    pick = lambda env: (az, wz) if env.get("DATA") == "zero" else (a, w)   # noqa: E731
     for vn, env in variants:      # warm-up + outputs
         apply(env)
-        o = ops.gemm(a, w, b, epi, L.AG_BF16, resid=r)
-        for _ in range(3): ops.gemm(a, w, b, epi, L.AG_BF16, resid=r, out=o)
+        a_, w_ = pick(env)
+        o = ops.gemm(a_, w_, b, epi, L.AG_BF16, resid=r)
+        for _ in range(3): ops.gemm(a_, w_, b, epi, L.AG_BF16, resid=r, out=o)
         torch.cuda.synchronize()
         outs[vn] = o.clone()
     ref = a[:2048].float() @ w.float().T + b
@@ -61,10 +66,11 @@ for name, n, k, epi in shapes:
         order = variants[rd % len(variants):] + variants[:rd % len(variants)]
         for vn, env in order:
             apply(env)
-            ops.gemm(a, w, b, epi, L.AG_BF16, resid=r, out=o)
+            a_, w_ = pick(env)
+            ops.gemm(a_, w_, b, epi, L.AG_BF16, resid=r, out=o)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(REPS): ops.gemm(a, w, b, epi, L.AG_BF16, resid=r, out=o)
+            for _ in range(REPS): ops.gemm(a_, w_, b, epi, L.AG_BF16, resid=r, out=o)
             e1.record(); torch.cuda.synchronize()
             times[vn].append(e0.elapsed_time(e1) / REPS * 1e3)
     for vn, _ in variants:
