@@ -3,7 +3,7 @@
 For one input and its K fixture masks — row 0 replaced by the all-visible mask, row 1 by the least-visible mask of the set —
 prints, per encoder depth, the relative L2 error of the bf16 hidden state against the fp32 one for the all-visible row, the
 least-visible row and the rest, then the error of the head outputs.  Run once per knob setting (AG_LN_FOLD, AG_BERT_LN_FOLD,
-AG_BERT_PRUNE are read at import): tools/bf16_ledger.sh.
+AG_BERT_PRUNE are read at import: e.g. `AG_LN_FOLD=0 python tools/bf16_ledger.py vit_base_l12`).
 
 usage: python tools/bf16_ledger.py vit_base_l12|bert_base_l12 [--json out.json]
 """
