@@ -215,3 +215,43 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "4")
     bench.maybe_spawn(argparse.Namespace(gpus=4))                 # already a rank of a launched job
     assert len(calls) == 1
+
+
+def test_epoch_wrapper_binds_arguments_by_name():
+    """the reference calls its epoch bodies by keyword too (_explainer_epoch_train(env=..., device=...)); the
+    epoch-stream wrapper must find `device` wherever it is passed, and on a CPU device it is the plain call."""
+    import torch
+    from autognothi_amd.scripts import common
+    seen = []
+
+    @common.on_epoch_stream
+    def body(env, device, n, flag=False):
+        seen.append((env, device, n, flag))
+        return n + 1
+
+    cpu = torch.device("cpu")
+    assert body("e", cpu, 1) == 2
+    assert body(env="e", device=cpu, n=2, flag=True) == 3
+    assert body("e", n=3, device=cpu) == 4
+    assert seen == [("e", cpu, 1, False), ("e", cpu, 2, True), ("e", cpu, 3, False)]
+
+
+def test_schedule_is_named_on_request(caplog):
+    """the epoch names the schedule it took: always on the autognothi_amd.schedule logger, in the epoch log only when env.log_schedule is
+    set (the reference's log has no such line)."""
+    import logging
+    from autognothi_amd.scripts import common
+
+    class Env:
+        def __init__(self, on):
+            self.lines, self.log_schedule = [], on
+
+        def log(self, msg):
+            self.lines.append(msg)
+
+    quiet, loud = Env(False), Env(True)
+    with caplog.at_level(logging.INFO, logger="autognothi_amd.schedule"):
+        common.log_schedule(quiet, None)
+        common.log_schedule(loud, None)
+    assert quiet.lines == [] and loud.lines == ["  > schedule: one stream"]
+    assert sum("one stream" in r.getMessage() for r in caplog.records) == 2
