@@ -478,14 +478,16 @@ def grad_exchange_overlap(job, dev, tb, steps=40, rounds=3):
         gbytes = sum(q.numel() for q in params) * 4 / 1e9
         r3 = lambda x: round(x, 3)   # noqa: E731
         eps = 0.03 * med[legs[0]]
-        # expected order: no exchange <= exchange from inside the backward <= the same exchange after the backward (each within eps = 3 %)
-        stable = (med[legs[0]] <= med[legs[1]] + eps) and (med[legs[0]] <= med[legs[2]] + eps) and (med[legs[1]] <= med[legs[2]] + eps)
+        # what must hold whatever the machine does: an exchange cannot make the step faster — no exchange <= either exchanging leg (medians
+        # AND minima, within eps = 3 %).  Which of the two exchanging legs is cheaper is the measurement, not a condition: at ONE rank there is
+        # no transfer to hide, and the in-backward form gives up the round-robin over the side streams (all gradients come from one stream)
+        stable = all(med[legs[0]] <= med[lg] + eps and mn[legs[0]] <= mn[lg] + eps for lg in legs[1:3])
         return {"what": "explainer forward + backward of the vanilla explainer (bf16 step, no optimiser), ms per step (hipEvents around every step) at ONE rank, "
                         f"median and min over {rounds} interleaved rounds of {steps} steps after a 1.5 s warm-up: no exchange / bucketed exchange from inside the "
                         "backward / the same buckets after the backward.  A bucket is packed by ONE launch into its persistent flat buffer, .grad becomes a "
                         "view of it; the collective runs in place: one all-reduce per bucket (default), reduce-scatter + all-gather, or bf16 all-to-all + "
-                        "fp32 sum on receipt + fp32 all-gather.  One rank: nothing crosses xGMI, the figures are packing + RCCL launches.  unstable = the "
-                        "medians do not come out as no_exchange <= overlapped <= after_backward within 3 %: no exposed-time claim is made from such a line",
+                        "fp32 sum on receipt + fp32 all-gather.  One rank: nothing crosses xGMI, the figures are packing + RCCL launches.  unstable = a leg "
+                        "WITH the exchange came out faster than the leg without (median or min, beyond 3 %): no exposed-time claim is made from such a line",
                 "images_per_step": tb, "gradient_gbytes": round(gbytes, 3), "bucket_mib": 64, "collectives_per_step": n_coll, "repeats": rounds, "steps_per_sample": steps,
                 "unstable": not stable,
                 "no_exchange_ms": r3(med[legs[0]]), "overlapped_ms": r3(med[legs[1]]), "after_backward_ms": r3(med[legs[2]]),
