@@ -201,7 +201,7 @@ _PARTITIONS = {}
 def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartition]:
     """The epoch's second stream, or None.  ``AG_TRAIN_PARTITION``: "0" = off (targets and steps back to back on the caller's stream); an
     integer = CUs per XCD the target forward's persistent GEMM may take (a multiple of the 4 shader engines); "auto" (default): 24 of 32
-    for a ViT explainer whose backbone trains, 28 for a frozen backbone or a BERT explainer.  Every rank count: with N > 1 ranks RCCL's
+    for a ViT explainer whose backbone trains, 16 for a BERT explainer whose backbone trains, 28 for a frozen backbone.  Every rank count: with N > 1 ranks RCCL's
     kernels (the gradient exchange, on the communicator's own stream) are a third client of the CUs the target forward leaves free.  Never
     under the hipGraph step.  None also when the host program used the GPU before it imported this package (``_lib.HIP_TOUCHED_BEFORE_IMPORT``: the one
     state in which the schedule was measured to LOSE; "auto" only) or when the second stream shares the caller's hardware queue (``TrainPartition.arm``)."""
@@ -217,8 +217,15 @@ def train_partition(device: torch.device, m_explainer) -> Optional[TrainPartitio
     if mode == "auto":
         # measured (tools/train_step_bench.py and inside bench.py, 36-72 steps of 8 images x 32 masks, images/s off -> on):
         # vanilla ViT-base 553 -> 638 at 24 (601 at 28, 608 at 20); froyo ViT-base 726 -> 790 at 28 (748 at 24, 688 at 20); duo BERT-base 920 -> 950-1 015 at 28
-        vit = getattr(m_explainer, "vit", None)
-        c = 24 if (vit is not None and any(q.requires_grad for q in vit.parameters())) else 28
+        # round 6 (the dW products grouped: the step's launches are larger and want more CUs; tools/r6_part_sweep.sh, 36 steps): duo BERT-base 1 051 at 28,
+        # 1 090 at 24, 1 146 at 20, **1 172 at 16**, 1 070 at 12; vanilla ViT-base 667 at 24 (630 at 20 / 28); froyo 810 at 28 (764 at 24)
+        vit, bert = getattr(m_explainer, "vit", None), getattr(m_explainer, "bert", None)
+        if vit is not None and any(q.requires_grad for q in vit.parameters()):
+            c = 24
+        elif bert is not None and any(q.requires_grad for q in bert.parameters()):
+            c = 16
+        else:
+            c = 28
     else:
         c = int(mode)
     props = torch.cuda.get_device_properties(device)

@@ -834,7 +834,7 @@ def main():
                                  "issues the step)",
                        "one_stream_value": None if rate_one is None else round(rate_one, 1),
                        "schedule": "one rank: the K-mask target forward of the NEXT group of batches on the device's background stream, its persistent GEMM "
-                                   "confined to 24 (frozen backbone / BERT: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition; "
+                                   "confined to 24 (BERT backbone trained: 16; frozen backbone: 28) of every XCD's 32 CUs, beside this group's steps (scripts/common.TrainPartition; "
                                    "same masks, steps and parameters bit for bit: tests/test_gpu_scripts.py); one_stream_value = AG_TRAIN_PARTITION=0: the two "
                                    "back to back on one stream; N > 1 ranks run the two-stream schedule too (one_rank_under_torch_distributed_run)",
                        "graph_replay_value": None if rate_graph is None else round(rate_graph, 1),
