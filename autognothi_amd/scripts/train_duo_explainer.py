@@ -27,7 +27,7 @@ def duo_explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: in
                               d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                               optimizer: torch.optim.Optimizer, epoch: int,
                               gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
-                              target_rows: int = 1536, mask_source: Optional[MaskSource] = None) -> Tuple[float, float, float, float]:
+                              target_rows: int = int(__import__('os').environ.get('AG_TARGET_ROWS', '1536')), mask_source: Optional[MaskSource] = None) -> Tuple[float, float, float, float]:
     """reference _duo_explainer_epoch_train (:121-213) -> (train_cls_loss, train_reg_loss, train_loss, train_cls_acc), the
     three losses as the reference accumulates them (sum of the per-batch values / samples).  The losses and the hit count stay
     on the device during the epoch and are read once at its end.  N > 1 ranks: sharded exactly as

@@ -171,7 +171,7 @@ def explainer_epoch_train(env: Any, device: torch.device, n_mask_samples: int, n
                           d_items: Iterable[Tuple[Any, Any]], m_recipe: ModelRecipe, m_surrogate, m_explainer,
                           optimizer: torch.optim.Optimizer, epoch: int,
                           gen_input: Callable[[Any, Any], Tuple[Tensor, Tensor]], seed: Optional[int] = None,
-                          target_rows: int = 1536, mask_source: Optional[MaskSource] = None) -> float:
+                          target_rows: int = int(__import__('os').environ.get('AG_TARGET_ROWS', '1536')), mask_source: Optional[MaskSource] = None) -> float:
     """reference _explainer_epoch_train (:128-207) / _duo_explainer_epoch_train: per batch — K-mask surrogate
     targets (no grad, HIP inference path), explainer forward + Shapley loss + backward (HIP training kernels,
     autognothi_amd/training.py), then the reference's own optimiser step.  -> train_reg_loss (mean).
