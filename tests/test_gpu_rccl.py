@@ -123,6 +123,71 @@ def test_sharded_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
         torch.testing.assert_close(q0 - q.detach(), 0.5 * 0.5 * w, rtol=1e-4, atol=1e-6 * gscale)
 
 
+def test_three_steps_of_gradient_views_through_fused_adamw_on_rccl(cuda_device, rccl_group, monkeypatch):
+    """the reducer makes every ``.grad`` a VIEW of a persistent flat bucket buffer that the next step overwrites, and the
+    layouts are cached step after step — here three consecutive steps of the epoch body (rank 0 of a pretended 2, collectives on RCCL) with
+    torch's fused AdamW reading those views, against the same three steps taken by hand: plain backward, gradients halved (rank 0's share of
+    the batch, summed over the one real rank), the same optimiser.  Masks: the epoch's one generator continues from step to step; the
+    dropout streams are keyed on (seed, trainer.step)."""
+    import copy
+    from autognothi_amd import distributed as D, engine, ops, training as T
+    from autognothi_amd.scripts import train_explainer as te
+    c = build_case("vit_tiny_c1")
+    dev, recipe = cuda_device, c["recipe"]
+    engine.set_precision("fp32")
+    srg = c["surrogate"].to(dev).eval()
+    exp = c["explainer"].to(dev)
+    k, p = c["K"], c["P"]
+    xs4 = torch.cat([torch.from_numpy(c["xs"]), torch.from_numpy(c["xs"]).flip(0) * 0.5], 0).to(dev)
+    zs4 = torch.zeros(4, dtype=torch.long, device=dev)
+    v_0 = torch.full((1, c["g"]["v_0"].shape[1]), 1.0 / c["g"]["v_0"].shape[1], device=dev)
+    seed, epoch, n_steps = 77, 1, 3
+    trainer = T.make_explainer_trainer(recipe, exp)
+    exp.__dict__["_ag_trainer"] = trainer
+    params = [q for q in exp.parameters() if q.requires_grad]
+    state0 = copy.deepcopy(exp.state_dict())
+    step0 = trainer.step
+    exp.train()
+    # ---- by hand
+    opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-4, fused=True)      # (eps well above the fp32 noise of two runs of the backward: no sign flips of ~0 gradients)
+    engine.watch_optimizer(opt)
+    rng = ops.DeviceMT19937(dev, seed)
+    for _ in range(n_steps):
+        bits = ops.mask_shapley_new(rng, 4 * k, p, want_i64=False, want_bits=True)[1][:2 * k].contiguous()
+        with torch.no_grad():
+            v_s, _ = recipe.fw_surrogate(srg, xs4[:2], bits)
+            v_1, _ = recipe.fw_surrogate(srg, xs4[:2], torch.ones((2, p), dtype=torch.int64, device=dev))
+        for q in params:
+            q.grad = None
+        trainer.loss_and_grads(xs4[:2], bits, v_0, v_s, v_1, k, labels=zs4[:2], train=True, seed=seed + epoch)
+        for q in params:
+            q.grad.mul_(0.5)
+        gmax = [float(q.grad.abs().max()) for q in params]
+        opt.step()
+    want = [q.detach().clone() for q in params]
+    # ---- the epoch body as rank 0 of 2, from the same start
+    exp.load_state_dict(state0)
+    trainer.step = step0
+    monkeypatch.setattr(D, "world", lambda: (0, 2))
+    opt2 = torch.optim.AdamW(params, lr=1e-3, eps=1e-4, fused=True)
+    te.explainer_epoch_train(None, dev, k, p, v_0, [(None, None)] * n_steps, recipe, srg, exp, opt2, epoch, lambda a, b_: (xs4, zs4), seed=seed)
+    torch.cuda.synchronize()
+    moved = max(float((q.detach() - w0.to(dev)).abs().max()) for q, w0 in zip(params, [state0[n_] for n_, q_ in exp.named_parameters() if q_.requires_grad]))
+    assert moved > 1e-4                                  # (three AdamW steps did move the parameters)
+    # (a parameter whose gradient is analytically zero — the key biases: a soft-max ignores a constant added to every logit of a row; the last
+    # bias of the explainer head: the Shapley normalisation removes any constant — receives rounding noise, which AdamW turns into steps of either sign: compared are the parameters with a gradient above the noise)
+    live = [g >= 1e-4 * max(gmax) for g in gmax]
+    assert sum(live) >= 0.9 * len(params)
+    for q, w, on in zip(params, want, live):
+        if on:
+            torch.testing.assert_close(q.detach(), w, rtol=2e-4, atol=2e-5)    # (atol = 0.7 % of one AdamW step of lr 1e-3: two runs of the backward agree to fp32 rounding only)
+    # every gradient is (still) a view of one of the reducer's flat buffers
+    red = exp.__dict__.get("_ag_reducer")
+    if red is not None:
+        bases = {flat.untyped_storage().data_ptr() for flat, _, _ in red._bufs.values()}
+        assert all(q.grad is None or q.grad.untyped_storage().data_ptr() in bases for q in params)
+
+
 def test_mask_mode_epoch_body_on_rccl(cuda_device, rccl_group, monkeypatch):
     """A global batch with FEWER inputs than ranks (one input, pretending rank 0 of 2): explainer_epoch_train shards the K masks
     inside the input (common.shard_auto) — this rank draws the WHOLE global mask call, runs masks [0, K/2) through the surrogate,
