@@ -652,7 +652,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
     dist = None
-    dev = torch.device(f"cuda:{local_rank}")
+    # development only (a one-GPU box cannot hold two RCCL ranks): AG_BENCH_DEVICE pins every rank to one device and AG_BENCH_BACKEND=gloo
+    # carries the collectives, so that the N > 1 code path of this file — lean mode, sharded epochs, the gradient exchange — runs with a real
+    # world size of 2 on one MI355X (tests/test_gpu_scripts.py).  Never a measurement: the line then says collective_backend "gloo (dev)"
+    dev_backend = os.environ.get("AG_BENCH_BACKEND", "nccl")
+    dev = torch.device(f"cuda:{int(os.environ.get('AG_BENCH_DEVICE', local_rank))}")
     torch.cuda.set_device(dev)
     if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):   # under a launcher: also a 1-rank job runs the
         import torch.distributed as dist                                       # RCCL barriers / reductions (1-GPU boxes test them)
@@ -663,7 +667,10 @@ def main():
         keep_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+            if dev_backend == "nccl":
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(backend=dev_backend, rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -1077,7 +1084,7 @@ def main():
             "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD_LABEL[args.workload],
                        "masks_per_input": K, "inputs_per_gpu_per_step": B, "rows_per_gpu_per_step": R, "rows_per_step": R * world,
-                       "tokens": T, "ranks": world, "collective_backend": "rccl (torch.distributed nccl)" if world > 1 else "none (1 rank)",
+                       "tokens": T, "ranks": world, "collective_backend": ("rccl (torch.distributed nccl)" if dev_backend == "nccl" else f"{dev_backend} (dev)") if world > 1 else "none (1 rank)",
                        "sharding": "rows by input, no data-path collective; one mask stream, each rank takes its rows of the global call",
                        "weights": "seeded random init", "launch": "hipGraph replay" if args.graph else "eager",
                        "visible_token_fraction_after_layer0": round(frac, 4)},

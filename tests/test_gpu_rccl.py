@@ -246,3 +246,25 @@ def test_bench_under_launcher_runs_rccl_barriers():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["secondary"]["train_explainer_step"]["value"] > 0
+
+
+def test_bench_with_a_real_world_size_of_two_over_gloo():
+    """bench.py's N > 1 code path with TWO real ranks on the box's one GPU: a second RCCL rank cannot share a device, so the collectives go over
+    gloo (AG_BENCH_BACKEND=gloo, AG_BENCH_DEVICE=0: development switches, never a measurement).  What is checked: the launch line of the driver
+    (`python bench.py --gpus 2` spawns torch.distributed.run) runs to the end — lean mode, the sharded training epochs with their two-rank
+    gradient exchange and the one-decision-of-all-ranks schedule, the attribution leg, the max-over-ranks timing — and rank 0 prints ONE line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AG_BENCH_BACKEND="gloo", AG_BENCH_DEVICE="0")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k_, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--train-batch", "2",
+           "--attr-batch", "4"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["rows_per_step"] == 2 * line["config"]["rows_per_gpu_per_step"] and line["config"]["collective_backend"] == "gloo (dev)"
+    assert line["secondary"]["train_explainer_step"]["value"] > 0
+    assert line["secondary"]["config5_train_explainer_step"]["duo_bert_base"]["value"] > 0
+    assert line["secondary"]["value"] > 0        # Shapley attributions / s over both ranks
