@@ -28,7 +28,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, which="explainer"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -43,9 +43,10 @@ def _run(rank, world, port, out_dir):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        meta = golden_json("model_vit_tiny_c1.json")
+        duo = which == "duo"
+        meta = golden_json("model_duo_vit_tiny_l3.json" if duo else "model_vit_tiny_c1.json")
         prm = dict(meta["params"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-        recipe = get_recipe("vanilla_vit")
+        recipe = get_recipe("duo_vanilla_vit" if duo else "vanilla_vit")
         cfg = recipe.t_config(**prm)
         srg, exp = recipe.t_surrogate(cfg), recipe.t_explainer(cfg)
         synth.load_synth_weights(srg, seed=0)
@@ -57,21 +58,37 @@ def _run(rank, world, port, out_dir):
         batches = [(base[:b] * (1.0 - 0.1 * i) + 0.05 * i, torch.zeros(b, dtype=torch.long, device=dev)) for i, b in enumerate(BATCHES)]
         with torch.no_grad():
             v_0, _ = recipe.fw_surrogate(srg, torch.zeros_like(base[:1]), torch.ones((1, p), dtype=torch.long, device=dev))
-        params = [q for q in exp.parameters() if q.requires_grad]
-        before = [q.detach().clone() for q in params]
-        opt = torch.optim.SGD(params, lr=2e-3)
         lines = []
 
         class Env:
             def log(self, msg):
                 lines.append(msg)
 
-        got = te.explainer_epoch_train(Env(), dev, k, p, v_0, [(i, None) for i in range(len(BATCHES))], recipe, srg, exp, opt, EPOCH,
-                                       lambda a, b_: batches[a], seed=SEED)
+        items = [(i, None) for i in range(len(BATCHES))]
+        if which == "surrogate":       # the surrogate is the trained model, a classifier of the same architecture gives the targets
+            from autognothi_amd.scripts import train_surrogate as ts
+            cls = recipe.t_classifier(cfg)
+            synth.load_synth_weights(cls, seed=2)
+            cls = cls.to(dev).eval()
+            srg.train()
+            params = [q for q in srg.parameters() if q.requires_grad]
+            before = [q.detach().clone() for q in params]
+            opt = torch.optim.SGD(params, lr=2e-3)
+            got = ts.surrogate_epoch_train(Env(), dev, p, items, recipe, cls, srg, opt, EPOCH, lambda a, b_: batches[a], seed=SEED)
+        else:
+            params = [q for q in exp.parameters() if q.requires_grad]
+            before = [q.detach().clone() for q in params]
+            opt = torch.optim.SGD(params, lr=2e-3)
+            if duo:
+                from autognothi_amd.scripts import train_duo_explainer as td
+                got = td.duo_explainer_epoch_train(Env(), dev, k, p, v_0, items, recipe, srg, exp, opt, EPOCH, lambda a, b_: batches[a], seed=SEED)
+                got = float(got[2])        # (cls loss, reg loss, total loss, accuracy)
+            else:
+                got = te.explainer_epoch_train(Env(), dev, k, p, v_0, items, recipe, srg, exp, opt, EPOCH, lambda a, b_: batches[a], seed=SEED)
         torch.cuda.synchronize()
         if rank == 0:
             moved = max(float((q.detach() - q0).abs().max()) for q, q0 in zip(params, before))
-            np.savez(os.path.join(out_dir, f"world{world}.npz"), loss=np.asarray([got]), n_lines=np.asarray([len(lines)]), moved=np.asarray([moved]),
+            np.savez(os.path.join(out_dir, f"{which}_world{world}.npz"), loss=np.asarray([got]), n_lines=np.asarray([len(lines)]), moved=np.asarray([moved]),
                      **{f"p{i}": q.detach().cpu().numpy() for i, q in enumerate(params)})
         else:
             assert lines == []              # (rank-0-only logging)
@@ -80,22 +97,26 @@ def _run(rank, world, port, out_dir):
             dist.destroy_process_group()
 
 
-def test_sharded_explainer_epoch_on_two_ranks_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("which", ["explainer", "duo", "surrogate"])
+def test_sharded_epoch_on_two_ranks_equals_one_rank(tmp_path, which):
+    """explainer: scripts/train_explainer.explainer_epoch_train; duo: train_duo_explainer.duo_explainer_epoch_train (the cross-entropy head rides
+    along); surrogate: train_surrogate.surrogate_epoch_train (ONE uniform mask per input: the one-input batch leaves a rank without rows — an
+    empty shard that still enters every collective)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     for world in (1, 2):
         port = _free_port()
-        procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path))) for r in range(world)]
+        procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), which)) for r in range(world)]
         for pr in procs:
             pr.start()
         for pr in procs:
             pr.join(600)
             assert pr.exitcode == 0, f"world {world}: a rank failed (exit code {pr.exitcode})"
-    one, two = np.load(tmp_path / "world1.npz"), np.load(tmp_path / "world2.npz")
+    one, two = np.load(tmp_path / f"{which}_world1.npz"), np.load(tmp_path / f"{which}_world2.npz")
     assert abs(float(one["loss"][0]) - float(two["loss"][0])) <= 1e-5 * abs(float(one["loss"][0])) + 1e-9
     assert int(one["n_lines"][0]) == int(two["n_lines"][0]) > 0
     keys = [k_ for k_ in one.files if k_[0] == "p" and k_[1:].isdigit()]
     for k_ in keys:
         scale = float(np.abs(one[k_]).max()) + 1e-12
         np.testing.assert_allclose(two[k_], one[k_], rtol=1e-4, atol=1e-5 * scale, err_msg=k_)
-    assert len(keys) > 100 and float(one["moved"][0]) > 1e-6          # (four SGD steps did move the parameters)
+    assert len(keys) > 50 and float(one["moved"][0]) > 1e-6          # (four SGD steps did move the parameters)
