@@ -65,6 +65,19 @@ def _run(rank, world, port, out_dir, which="explainer"):
                 lines.append(msg)
 
         items = [(i, None) for i in range(len(BATCHES))]
+        if which == "faithfulness":    # three single-image samples on two ranks: one full group (by image) + a tail sharded inside the image
+            import json
+            from autognothi_amd.scripts import measure_faithfulness as mf
+            fin = recipe.t_final(cfg)
+            synth.load_synth_weights(fin, seed=2)
+            fin = fin.to(dev).eval()
+            samples = [(base[i:i + 1] * (1.0 + 0.1 * i), torch.tensor([i % 3], device=dev)) for i in range(3)]
+            rep = mf.measure_faithfulness_loaded(Env(), dev, recipe, srg, fin, samples, lambda a, b_: (a, b_), 8)
+            torch.cuda.synchronize()
+            if rank == 0:
+                with open(os.path.join(out_dir, f"{which}_world{world}.json"), "w") as f:
+                    json.dump({"report": rep, "lines": lines}, f)
+            return
         if which == "surrogate":       # the surrogate is the trained model, a classifier of the same architecture gives the targets
             from autognothi_amd.scripts import train_surrogate as ts
             cls = recipe.t_classifier(cfg)
@@ -120,3 +133,28 @@ def test_sharded_epoch_on_two_ranks_equals_one_rank(tmp_path, which):
         scale = float(np.abs(one[k_]).max()) + 1e-12
         np.testing.assert_allclose(two[k_], one[k_], rtol=1e-4, atol=1e-5 * scale, err_msg=k_)
     assert len(keys) > 50 and float(one["moved"][0]) > 1e-6          # (four SGD steps did move the parameters)
+
+
+def test_faithfulness_loop_on_two_ranks_equals_one_rank(tmp_path):
+    """scripts/measure_faithfulness.measure_faithfulness_loaded (reference :195-218) with the real fw_final / fw_surrogate: samples by rank, the
+    short last group by perturbation row inside the image (rows all-gathered), curves gathered and re-ordered: the single-process report."""
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for world in (1, 2):
+        port = _free_port()
+        procs = [ctx.Process(target=_run, args=(r, world, port, str(tmp_path), "faithfulness")) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        for pr in procs:
+            pr.join(600)
+            assert pr.exitcode == 0, f"world {world}: a rank failed (exit code {pr.exitcode})"
+    one, two = (json.load(open(tmp_path / f"faithfulness_world{w}.json")) for w in (1, 2))
+    assert one["report"]["data_cls"] == two["report"]["data_cls"] and len(one["report"]["data_cls"]) == 3
+    assert one["lines"] == two["lines"] and len(one["lines"]) == 3
+    for key in ("insertion", "deletion", "insertion_non_ok", "deletion_non_ok"):
+        assert abs(one["report"][key]["auc"] - two["report"][key]["auc"]) <= 1e-6, key
+    for a, b in zip(one["report"]["data_ins"] + one["report"]["data_del"], two["report"]["data_ins"] + two["report"]["data_del"]):
+        assert a.keys() == b.keys()
+        for cl in a:
+            np.testing.assert_allclose(list(b[cl].values()), list(a[cl].values()), rtol=1e-5, atol=1e-7)
