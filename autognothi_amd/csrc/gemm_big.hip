@@ -1549,7 +1549,7 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
         if (f) { fprintf(f, "%p\n", (void*)dbuf); fclose(f); }
     }
     // group width: one group (the plain N-fastest order) unless the weight matrix overflows an XCD's 4 MiB L2 while the
-    // A panels are cheap to fetch again (short K): then groups of <= 2.5 MiB of weight rows (fc1 768->3072: 2 groups of 6
+    // A panels are cheap to fetch again (short K): then groups of <= 3.2 MiB of weight rows (fc1 768->3072: 2 groups of 6
     // tiles, measured -1.7 %; splitting fc2's 3 tiles (K = 3072) costs +16 %: its A panels are 1.5 MB each)
     static AgKnob k_ngrp("AG_GEMM_NGRP"), k_wfit("AG_GEMM_WFIT_MB"), k_nt("AG_GEMM_NT");   // (the parity tests toggle them)
     const int ngrp_env = (int)k_ngrp.get(0);
@@ -1557,7 +1557,9 @@ static int run_big(const void* d_A, int64_t lda, const void* d_W, const float* d
         const int tiles_n = ceil_div(N, BT);
         const double wbytes = (double)N * K * 2.0;
         const double wfit_mb = k_wfit.get(4.0);   // (experiment knob)
-        int groups = (wbytes > wfit_mb * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (2.5 * 1024 * 1024) + 0.999) : 1;
+        // (round 6, tools/r6_gemm_ab.py at M = 605 184: ViT-large's QKV, 3 072 x 1 024 = 6.3 MB of W, 12 N-tiles, as 2 / 3 / 4 / 6 / 12 tiles
+        // per group: 3 240 / 3 119 / 3 209 / **3 075** / 3 127 us — groups of <= 3.2 MB, not 2.5: two groups of 6, where the old rule made three of 4)
+        int groups = (wbytes > wfit_mb * 1024 * 1024 && K <= 1024) ? (int)(wbytes / (3.2 * 1024 * 1024) + 0.999) : 1;
         int g = ngrp_env > 0 ? ngrp_env : ceil_div(tiles_n, groups);
         // wide outputs (16 or more N-tiles: none in the encoder): the 32 tiles an XCD runs at a time would be ONE row of
         // tiles (1 A slice + 32 W slices per half-step); groups of 4 columns make them an 8 x 4 block (8 + 4 slices) that

@@ -130,6 +130,20 @@ class _Side:
         keep = [t_ for _, dyb, xb, db in group for t_ in (dyb, xb, db) if t_ is not None]
         self.run(work, *keep)
 
+    def begin(self, inline: bool) -> None:
+        """start of a backward.  A backward that raised half way (an allocation failure, a bad shape) leaves deferred products, kept
+        tensors and unreported gradients of THAT step behind: they must not leave with this step's first group."""
+        self.pending.clear()
+        self.finals.clear()
+        if self.dirty:                     # (forked work of the aborted step may still read what ``keep`` holds)
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)
+            self.dirty = False
+        self.keep.clear()
+        self.turn = 0
+        self.inline = inline
+
     def final_on_main(self, *params: Tensor) -> None:
         """a gradient that a main-stream kernel wrote: reported to training.GRAD_SINK at a later fork (or at the join), on a
         stream that is ordered behind it."""
@@ -755,7 +769,7 @@ class ExplainerTrainer16:
         b, t, h, c, ph, s_exp, duo_saved, o_last = self.saved
         self.saved = None
         side = self.side
-        side.inline = self.use_graph or b * t < SIDE_MIN_ROWS
+        side.begin(self.use_graph or b * t < SIDE_MIN_ROWS)
         dev = dphi.device
         dz_extra = None
         if self.duo and dbase is not None:
@@ -897,6 +911,7 @@ class SurrogateTrainer16:
     def backward_probs(self, dprobs: Tensor) -> None:
         b, t, h, probs, pooled, ph, s_pool = self.saved
         self.saved = None
+        self.side.begin(b * t < SIDE_MIN_ROWS)
         dlogits = ops.softmax_rows_bwd(probs, dprobs.contiguous().float())
         with _fp32_lin():
             if self.is_vit:
@@ -906,7 +921,6 @@ class SurrogateTrainer16:
                 dzc = self.pool.backward(ops.tanh_bwd(pooled, dp))
         dz = torch.zeros((b, t, h), dtype=torch.float32, device=dprobs.device)
         dz[:, 0, :].copy_(dzc)
-        self.side.inline = b * t < SIDE_MIN_ROWS
         if not self.backbone.frozen:
             self.backbone.backward(self.side, dz.view(b * t, h))
         self.side.join()

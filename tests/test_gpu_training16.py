@@ -141,6 +141,41 @@ def test_bf16_step_is_bit_reproducible_and_stream_independent(cuda_device, mixed
         assert torch.equal(g0[n], g2[n]), f"{n}: differs with the side stream off"
 
 
+def test_an_aborted_backward_leaves_nothing_for_the_next_step(cuda_device, mixed):
+    """training16._Side.begin: a backward that raised half way leaves deferred dW products (and kept tensors, unreported gradients)
+    behind; the next step must not send them off with its first group — its gradients equal a clean step's bit for bit."""
+    from autognothi_amd import training16
+    dev = cuda_device
+    c, prm, exp, xs, masks, bits, v0, vs, v1, labels = _explainer_case("bert_base_l2", dev)
+    tr = mixed.ExplainerTrainer(c["recipe"], exp)
+
+    def grads():
+        for p in exp.parameters():
+            p.grad = None
+        loss, _ = tr.loss_and_grads(xs, bits, v0.to(dev), vs.to(dev), v1.to(dev), c["K"], labels=labels.to(dev), train=True, seed=3)
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.clone() for n, p in exp.named_parameters() if p.grad is not None}
+
+    l0, g0 = grads()
+    side = training16._Side.of(dev)
+    assert side.pending == [] and side.keep == [] and side.finals == []
+    if training16.DW_GROUP > 1:
+        # what an exception inside the backward leaves: some Linear's (dY, X) pair waiting for its group, a gradient not yet reported
+        lin = next(m for m in exp.modules() if isinstance(m, torch.nn.Linear) and m.weight.requires_grad)
+        lw = training16.LinW([lin], 1, dev)
+        n, k = lin.weight.shape
+        side.pending.append((lw, torch.ones((256, n), dtype=torch.bfloat16, device=dev), torch.ones((256, k), dtype=torch.bfloat16, device=dev), None))
+    side.finals.append(next(p for p in exp.parameters() if p.requires_grad))
+    side.keep.append(torch.ones(8, device=dev))
+    l1, g1 = grads()
+    assert l0 == l1 and set(g0) == set(g1)
+    for n_ in g0:
+        if n_.endswith("word_embeddings.weight"):
+            continue      # (torch index_add_ atomics, see above)
+        assert torch.equal(g0[n_], g1[n_]), f"{n_}: the aborted step's leftovers reached this step's gradient"
+    assert side.pending == [] and side.keep == [] and side.finals == []
+
+
 def _dropout_case(tag, dev):
     from autognothi_amd import ops
     from autognothi_amd.utils import synth

@@ -2,7 +2,7 @@
 """Dev tool (round 6): interleaved A/B of knob settings on the four encoder GEMMs of the benchmarked step, in ONE process.
 
   R6_VARIANTS="name:K=V,K=V;name2:..."   (default: phased vs pipelined main loop; the key LIB=<suffix> selects a variant build)
-  R6_M (302592)  R6_ROUNDS (7)  R6_REPS (12)  R6_ONLY=qkv|out|fc1|fc2
+  R6_M (302592)  R6_ROUNDS (7)  R6_REPS (12)  R6_ONLY=qkv|out|fc1|fc2  R6_SHAPES="name:N:K:epilogue;..." (other models' Linears)
 
 Every round runs every variant once per shape (order rotated per round); a variant's environment is applied and the library's
 knobs re-read (ag_reload_knobs) before its launches.  Reports median and min of the per-launch time (hipEvents around REPS
@@ -38,6 +38,8 @@ def apply(env):
 
 shapes = [("qkv", 2304, 768, L.AG_EPI_BIAS), ("out", 768, 768, L.AG_EPI_BIAS_RESID), ("fc1", 3072, 768, L.AG_EPI_BIAS_GELU),
           ("fc2", 768, 3072, L.AG_EPI_BIAS_RESID)]
+if os.environ.get("R6_SHAPES"):      # "name:N:K:epilogue;..." (epilogue 0 bias / 1 bias+gelu / 2 bias+residual)
+    shapes = [(f[0], int(f[1]), int(f[2]), int(f[3])) for f in (x.split(":") for x in os.environ["R6_SHAPES"].split(";"))]
 if only: shapes = [x for x in shapes if x[0] in only.split(",")]
 g = torch.Generator(device=dev); g.manual_seed(0)
 for name, n, k, epi in shapes:
