@@ -65,6 +65,30 @@ def test_sharding_and_order_invariance(cuda_device, workload):
     assert float(np.abs(joint.reshape(4, K, -1)[0] - joint.reshape(4, K, -1)[1]).max()) > 5e-2   # and so do inputs
 
 
+@pytest.mark.parametrize("workload,batch", [("vit_base", 48), ("bert_base", 48), ("vit_large", 24)])
+def test_benchmarked_step_equals_its_small_batches(cuda_device, workload, batch):
+    """the step bench.py times — 48 inputs x K = 32 (ViT-base: M = 302 592 token rows through the persistent 256^2 kernel, its tile groups,
+    the residual-through-LDS epilogue, the stream attention, the K/V-free last layer; BERT-base with token pruning) and 24 inputs x K = 64
+    of ViT-large (BASELINE config 4's K; QKV in two tile groups) — against the same rows forwarded four inputs at a time, where every
+    Linear meets other routes (under-filled launches, the planner's 128^2 units): the rows must agree within the bf16 model tolerance,
+    and the big step must replay bit for bit."""
+    import bench
+    from autognothi_amd import ops
+    k = bench.WORKLOADS[workload][2]
+    recipe, cfg, m, xs = _setup(workload, cuda_device, batch, seed=7)
+    P = recipe.n_players(cfg)
+    masks, _ = ops.mask_shapley_new(ops.DeviceMT19937(cuda_device, 29), batch * k, P, want_i64=True, want_bits=False)
+    joint = _probs(recipe, m, xs, masks)
+    assert joint.shape == (batch * k, cfg.num_labels) and np.isfinite(joint).all()
+    np.testing.assert_allclose(joint.sum(-1), 1.0, atol=1e-3)
+    np.testing.assert_array_equal(_probs(recipe, m, xs, masks), joint)
+    parts = np.concatenate([_probs(recipe, m, xs[i:i + 4], masks[i * k:(i + 4) * k]) for i in range(0, batch, 4)])
+    np.testing.assert_allclose(parts, joint, rtol=0, atol=TOL)
+    per_input = joint.reshape(batch, k, -1)
+    assert float(np.abs(per_input - per_input[:, :1]).max()) > 5e-2        # masks matter
+    assert float(np.abs(per_input[0] - per_input[1]).max()) > 5e-2         # and so do inputs
+
+
 @pytest.mark.parametrize("workload", ["vit_base", "bert_base"])
 def test_all_visible_equals_single_unmasked_forward(cuda_device, workload):
     """K all-ones masks (layer-0 sharing, and for BERT the token-pruned path with nothing pruned) == the K=1 forward."""
