@@ -139,6 +139,7 @@ SIGNATURES = {
     "ag_probe_dma": (i32, [i32, i32, i32, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_probe_store": (i32, [i32, i32, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
     "ag_launch_count": (i64, []),
+    "ag_gemm_last_plan": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ag_profile_enable": (i32, [i32]),
     "ag_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ag_encoder_workspace_bytes": (sz, [C.POINTER(ag_encoder_desc), i32]),

@@ -239,6 +239,8 @@ int ag_gemm_big(const void* d_A, int64_t lda, const void* d_W, const float* d_bi
 // the persistent kernel, rows [m1, m1 + m2) as `splits` contraction ranges side by side
 bool ag_resid_split_plan(int M, int N, int K, int* m1, int* m2, int* splits);
 int ag_device_cus();   // CUs of the current device, rounded down to a multiple of the 8 XCDs
+// gemm_big.hip: does the persistent 256^2 kernel run `tiles` tiles on `n_cu` workgroups with a half-height last round?  (the planner prices it)
+bool ag_big_half_tail(int tiles, int n_cu, int* half_from, int* ntail, int* grid);
 
 // gemm_tn.hip — the route of one masked-forward GEMM (ag_gemm_ws; csrc/encoder.cpp plans whole layers with it).
 //   AG_WS_GEMM       ag_gemm as it is (the persistent 256^2 kernel when the shape fills it, else the 128 / 64-tile kernel)

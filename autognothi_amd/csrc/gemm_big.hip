@@ -78,6 +78,9 @@ struct BigArgs {
     // contraction ranges side by side (gemm_stream_kernel, fp32-output epilogue only; ag_gemm_resid_split): `nbatch` products of the
     // same shape in one launch, product z reading A / W `bk_b` bytes further along K and writing `bc` output elements further
     int nbatch; long bk_b; long bc;
+    // half-height tail (gemm_stream_kernel<..., HT = true>): units [0, half_from) are whole 256^2 tiles (complete rounds of the resident
+    // workgroups); the `ntail` tiles left run as 128-row halves, two units each, all in the last round
+    int half_from, ntail;
 };
 
 // LDS-DMA issued through inline asm ON PURPOSE: hipcc does not count an asm load in its s_waitcnt
@@ -147,7 +150,15 @@ __device__ __forceinline__ uint4 frag_half(const char* lds_half, int row16base, 
 template <int EPI, bool LNF, bool STATS, bool RLN = false, int LAYOUT = 0>
 __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4][8], const int mw0, const int nw0,
                                               char* stg, const int lane, const char* smem_base, const int tile_n,
-                                              const char* tail_at = nullptr, const long c_ofs = 0) {
+                                              const char* tail_at = nullptr, const long c_ofs = 0, const int m_lim = -1, const bool idle = false) {
+    // m_lim: rows of the matrix this TILE may write (a half-height tile of gemm_stream_kernel ends 128 rows after its origin: the rows
+    // behind belong to another unit); idle: a wave none of whose rows the tile owns — it only keeps the workgroup's barriers
+    const int Mlim = m_lim >= 0 ? m_lim : p.M;
+    if (idle) {
+        if (EPI != AG_EPI_BIAS_F32) asm volatile("s_barrier" ::: "memory");
+        if (STATS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+    }
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_F32 = (EPI == AG_EPI_BIAS_F32);
     constexpr bool RESID = (EPI == AG_EPI_BIAS_RESID);
@@ -162,7 +173,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
     constexpr int STAT_OFF = LAYOUT ? 4608 : 8192;
     constexpr int WPIECE = LAYOUT ? 8192 : 16384, GPIECE = LAYOUT ? 65536 : 65536, GBASE = LAYOUT ? 32768 : 0;
     const bool full_cols = nw0 + 64 <= p.N;     // N % 8 == 0 guaranteed by eligibility
-    const bool edge_tile = !full_cols || mw0 + 128 > p.M;   // (wave-uniform) some of this wave's outputs lie outside the matrix
+    const bool edge_tile = !full_cols || mw0 + 128 > Mlim;   // (wave-uniform) some of this wave's outputs lie outside the matrix
 
     // ---- row and column constants: parked in the LDS tail by the kernel's prologue (tile_constants_*) ----
     const char* const tail = tail_at ? tail_at : smem_base + NSLOT * SLOT_BYTES;   // (gemm_stream_kernel alternates between two tails)
@@ -215,7 +226,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         const int sq = seq / p.share;
         r_seq_rem = seq - sq * p.share;
         r_base = (long)sq * p.T;
-        resid_issue(rnext, m < p.M);
+        resid_issue(rnext, m < Mlim);
     }
 
 #pragma unroll
@@ -227,7 +238,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
             for (int sn = 0; sn < 4; ++sn) rcur[sn] = rnext[sn];
             if (sm < 7) {
                 resid_advance();
-                resid_issue(rnext, m + 16 < p.M);
+                resid_issue(rnext, m + 16 < Mlim);
             }
         }
         float ln_mean = 0.f, ln_rstd = 1.f;
@@ -257,7 +268,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
         for (int sn = 0; sn < 4; ++sn) {
             const int n = nw0 + sn * 16 + fq * 4;
             float v[4] = {vlo[sn].x, vlo[sn].y, vhi[sn].x, vhi[sn].y};
-            const bool inb = (m < p.M) && (n < p.N);
+            const bool inb = (m < Mlim) && (n < p.N);
             if (RESID && RLN) {   // residual = LayerNorm of the stored pre-LN row (never materialised)
                 constexpr int SI = RLN ? 1 : 0;    // (gv / btv have one element in the other instantiations)
                 const float nm = -ln_mean;
@@ -301,7 +312,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 const int rr = i * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 val = *reinterpret_cast<const uint4*>(stg + rr * SROW + ch * 16);
                 const int mm = mw0 + (sm - 1) * 16 + rr;
-                if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+                if (mm < Mlim && (full_cols || nw0 + ch * 8 < p.N)) {
                     uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (p.nt_store) {
@@ -326,7 +337,7 @@ __device__ __forceinline__ void wave_epilogue(const BigArgs& p, f32x4_t (&acc)[4
                 t.x += u.x; t.y += u.y;
             }
             const int m = mw0 + row;
-            if (m < p.M) *reinterpret_cast<float2*>(p.stats_out + (long)tile_n * p.stats_slab + 2 * (long)m) = t;
+            if (m < Mlim) *reinterpret_cast<float2*>(p.stats_out + (long)tile_n * p.stats_slab + 2 * (long)m) = t;
         }
     }
 }
@@ -924,7 +935,15 @@ constexpr int STREAM_LDS_BYTES = STREAM_SINK + 256;
 // (ds_read_b64 in the accumulator layout, chunk-swizzled image), read back as whole 128-byte rows and stored; the next tile's step 0
 // goes into the slot-0 area as soon as the first half has left it.  Everything is private to the wave.  (L2 touches of the residual lines
 // a step ahead of the pieces, from behind the waves' last wait: +6 % on the out-projection — one line per lane is the dearest request shape.)
-template <int EPI, int VAR = 0, bool RLDS = false>
+// HT (round 6, half-height tail): the tiles left over after the last COMPLETE round of the resident workgroups (at most half a round of
+// them) run as two 128-row units each, side by side in that last round, instead of as one more whole round of 256^2 tiles on a part of the
+// chip: wave group 0 (rows [0, 128) of a tile) works as in any tile — it stages the 128 A rows it needs (waves 0, 1; waves 2, 3 request
+// nothing), reads its fragments, computes, runs the epilogue — and wave group 1 (rows [128, 256)) only stages W and keeps the barriers:
+// waves w and w + 4 share a SIMD, so every SIMD issues half the MFMAs of a whole tile per step.  Every output element is the same sum in the
+// same order as in a whole tile (bit-identical: tests/test_gpu_gemm_ring.py).  Units b >= half_from: tile half_from + (k & 7) + 8 (k >> 4),
+// half (k >> 3) & 1 with k = b - half_from — the two halves of a tile on workgroups 8 apart, i.e. on the same XCD.  A half-height unit is
+// always the last unit of its workgroup.
+template <int EPI, int VAR = 0, bool RLDS = false, bool HT = false>
 __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     BigArgs p = pin;
     p.M = __builtin_amdgcn_readfirstlane(ag_dyn_clamp(p.M, p.dyn));   // (a scalar: everything derived from it — tile counts, edges, has_next — stays in SGPRs)
@@ -939,8 +958,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     const int nwg_t = tiles_m * tiles_n;
     const int nwg = BATCH ? nwg_t * p.nbatch : nwg_t;
     const int nres = (int)gridDim.x;                  // resident workgroups: a multiple of 8 (or all tiles)
+    const int nunits = HT ? p.half_from + 2 * ((p.ntail + 7) & ~7) : nwg;
     int bt = blockIdx.x;
-    if (bt >= nwg) return;
+    if (bt >= nunits) return;
     const int ns = p.K / 64;                          // steps per tile (even)
     const bool stA = grp == 0;                        // group 0 stages A, group 1 stages W (see gemm_line_kernel)
     const int ldx = stA ? (int)p.lda_b : (int)p.ldw_b;
@@ -960,8 +980,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     asm volatile("" : "+v"(vA), "+v"(vW));
 
     // a tile of the stream: scalars only
-    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; long cz; };     // (whole words only: never copied through memory)
+    // (half: 0 a whole tile, 1 / 2 the lower / upper 128 rows of one; mhi: first row of the matrix the unit does NOT own; skip: nothing to do)
+    struct Tile { int m0, n0, tn; const char* x; uint32_t off_max; int edge; long cz; int half, mhi, skip; };     // (whole words only: never copied through memory)
     auto tile_of = [&](int b) {
+        int half = 0;
+        if (HT && b >= p.half_from) {
+            const int k = b - p.half_from;
+            b = p.half_from + (k & 7) + ((k >> 4) << 3);
+            half = 1 + ((k >> 3) & 1);
+        }
+        const bool beyond = HT && b >= nwg;           // (the padding of the tail to a multiple of 8 tiles)
+        if (beyond) b = nwg - 1;
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
         int bz = 0;
@@ -977,8 +1006,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             tm = rem / w; tn = (tiles_n / ngrp) * ngrp + rem % w;
         }
         Tile t;
-        t.m0 = __builtin_amdgcn_readfirstlane(tm * BT); t.n0 = __builtin_amdgcn_readfirstlane(tn * BT); t.tn = __builtin_amdgcn_readfirstlane(tn);
-        const int vrows = stA ? min(BT, p.M - t.m0) : min(BT, p.N - t.n0);
+        t.m0 = __builtin_amdgcn_readfirstlane(tm * BT + ((HT && half == 2) ? BT / 2 : 0)); t.n0 = __builtin_amdgcn_readfirstlane(tn * BT); t.tn = __builtin_amdgcn_readfirstlane(tn);
+        const int trows = (HT && half) ? BT / 2 : BT;                           // rows of A the unit needs
+        t.half = 0; t.mhi = 0; t.skip = 0;
+        if constexpr (HT) {
+            t.half = __builtin_amdgcn_readfirstlane(half);
+            t.mhi = __builtin_amdgcn_readfirstlane(min(p.M, t.m0 + trows));
+            t.skip = __builtin_amdgcn_readfirstlane((beyond || t.m0 >= p.M) ? 1 : 0);   // (the upper half of a ragged last row tile of <= 128 rows)
+            if (t.skip) { t.m0 = 0; t.mhi = 0; }                                // (addresses stay inside the matrix)
+        }
+        const int vrows = stA ? min(trows, p.M - t.m0) : min(BT, p.N - t.n0);
         t.x = stA ? p.A + (long)t.m0 * p.lda_b : p.W + (long)t.n0 * p.ldw_b;
         t.cz = 0;
         if (BATCH) {
@@ -987,10 +1024,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             t.cz = (long)bz * p.bc;
         }
         t.off_max = (uint32_t)((vrows - 1) * ldx + 112);
-        t.edge = vrows < BT ? 1 : 0;
+        t.edge = vrows < (stA ? trows : BT) ? 1 : 0;
         return t;
     };
     auto refill4 = [&](const Tile& t, int step, int slot, int h) {
+        if (HT && t.half && stA && gw >= 2) return;          // rows [128, 256) of a half-height unit's A image: nobody reads them
         const uint32_t lds = ldsX_w + slot * LOP_BYTES + h * 4096;
         if (!t.edge) {
             const char* b0 = t.x + (long)step * LROWB + (long)(2 * h) * d16;
@@ -1099,12 +1137,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
 
     f32x4_t acc[4][8];
     Tile cur = tile_of(bt);
+    if (HT && cur.skip) return;                                      // (workgroup-uniform, before any barrier)
     int par = 0;                                                     // which tail / raw area holds the current tile's constants
     request_constants(cur, 0);
     refill4(cur, 0, 0, 0); refill4(cur, 0, 0, 1);                    // the stream's first step image
     for (;;) {
         const int bn = bt + nres;
-        const bool has_next = bn < nwg;
+        const bool has_next0 = bn < nunits;
         if (p.dbg && tid == 0) {
             unsigned long long t_; uint32_t hw_;
             asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(hw_)::"memory");
@@ -1113,7 +1152,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
         // ---- top of a tile: its step 0 and its constants are in LDS (first tile: on their way).  Step 1's requests go out first; the next
         // tile's coordinates are worked out under their latency.  (Steps 0 and 1 were touched into L2 by the previous tile's last two
         // steps, step 2 is touched by step 0 as usual.)
-        const Tile nxt = tile_of(has_next ? bn : bt);                 // (no next tile: the prefetch slots re-touch this one)
+        const Tile nxt0 = tile_of(has_next0 ? bn : bt);               // (no next tile: the prefetch slots re-touch this one)
+        const bool has_next = HT ? (has_next0 && !nxt0.skip) : has_next0;     // (a padding unit of the half-height tail: no next tile either)
+        const Tile nxt = (HT && has_next0 && nxt0.skip) ? tile_of(bt) : nxt0;
+        // a wave none of whose rows this unit owns: no fragment reads, no MFMAs, no epilogue — its requests and its barriers only
+        const bool idle = HT && cur.half && grp == 1;
         refill4(cur, 1, 1, 0); refill4(cur, 1, 1, 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // all but step 1's pieces (after the first tile: nothing but store acknowledgements)
         finish_constants(cur, par);
@@ -1216,6 +1259,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             half(slot, 1, refill, rt, rstep, pt, pstep, false, last);
         };
         if (p.dbg && tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); p.dbg[8 * (long)bt + 4] = t_; }
+        if (HT && idle) {
+            // a wave of group 1 in a half-height unit (its workgroup's last unit: nothing is requested for a successor): every step's W
+            // requests, the waits on them and the barriers of `half`, nothing else.  (Its own copy of the loop: a wave-uniform branch per
+            // unit, none inside the working waves' loop.)
+            for (int si = 0; si < ns; ++si) {
+                const int slot = si & 1;
+                asm volatile("s_barrier" ::: "memory");                        // "a", lower half
+                if (si > 0 && si + 1 < ns) { refill4(cur, si + 1, slot ^ 1, 0); refill4(cur, si + 1, slot ^ 1, 1); }
+                asm volatile("s_barrier" ::: "memory");                        // "b"
+                asm volatile("s_barrier" ::: "memory");                        // "a", upper half
+                if (!(RLDS && si + 1 == ns)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");                        // "b"
+            }
+            // (nobody reads an idle wave's accumulators; defined here so that the previous unit's are not carried around the working waves' loop)
+#pragma unroll
+            for (int sn = 0; sn < 4; ++sn)
+#pragma unroll
+                for (int g = 0; g < 8; ++g) acc[sn][g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        } else {
         step(0, 0, false, true, false);                                    // step 1 was requested above
         int s = 1;
         for (; s + 1 < ns; s += 2) {
@@ -1223,6 +1285,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             step(s + 1, 0, true, false, false);
         }
         step(s, 1, has_next, false, true);                                              // s == ns - 1: requests the NEXT tile's step 0 into slot 0
+        }
 #if AG_STREAM_HOIST_HI
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (the asm MFMAs' results are read by vector instructions next: hipcc's hazard recogniser does not see them)
 #endif
@@ -1240,13 +1303,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const int frow = le & 15, fq = le >> 4;
             const int mw0 = cur.m0 + wm * 128, nw0 = cur.n0 + wn * 64;
             const bool full_cols = nw0 + 64 <= p.N;
-            const bool edge_tile = !full_cols || mw0 + 128 > p.M;               // (wave-uniform)
+            const int Mt = HT ? cur.mhi : p.M;                                  // rows this unit may write
+            const bool edge_tile = !full_cols || mw0 + 128 > Mt;                // (wave-uniform)
             char* const area = smem + (stA ? 0 : LW_BASE) + gw * 8192;          // this wave's piece area of slot 0; slot 1: + LOP_BYTES
             // this wave's 128 x (sum, sumsq) partials: in the raw-partials area of THIS tile's parity (consumed at the top of the tile; the
             // next tile's raw partials arrive in the other one)
             char* const part = smem + STREAM_RAW + par * 8192 + wave * 1024;
             const char* const tail = smem + STREAM_TAIL + par * TAIL_BYTES;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading slot 1
+            if (idle) {                                                         // (a half-height unit is its workgroup's last: nothing to request either)
+                if (STATS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
             res4(cur, 1, 0); res4(cur, 1, 1);                                   // rows [64, 128) of the residual sub-tile -> slot 1
             float4 bv[4], gv[RLN ? 4 : 1], btv[RLN ? 4 : 1];
 #pragma unroll
@@ -1292,7 +1359,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                             f32x2_t ra = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xFFFF0000u)};
                             f32x2_t rb = {__uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xFFFF0000u)};
                             if (edge_tile) {
-                                const float keep = (m < p.M && nw0 + sn * 16 + fq * 4 < p.N) ? 1.f : 0.f;
+                                const float keep = (m < Mt && nw0 + sn * 16 + fq * 4 < p.N) ? 1.f : 0.f;
                                 const f32x2_t k2 = {keep, keep};
                                 ra *= k2; rb *= k2;
                             }
@@ -1312,7 +1379,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                     const int rr = i * 8 + (le >> 3), ch = le & 7;
                     const uint4 val = *reinterpret_cast<const uint4*>(img + rr * 128 + ((ch ^ ((rr >> 1) & 7)) << 4));
                     const int mm = mw0 + h * 64 + rr;
-                    if (mm < p.M && (full_cols || nw0 + ch * 8 < p.N)) {
+                    if (mm < Mt && (full_cols || nw0 + ch * 8 < p.N)) {
                         uint4* dstp = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (long)mm * p.ldc + nw0 + ch * 8);
                         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                         if (p.nt_store) {
@@ -1346,9 +1413,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
                         t.x += u.x; t.y += u.y;
                     }
                     const int m = mw0 + row;
-                    if (m < p.M) *reinterpret_cast<float2*>(p.stats_out + (long)cur.tn * p.stats_slab + 2 * (long)m) = t;
+                    if (m < Mt) *reinterpret_cast<float2*>(p.stats_out + (long)cur.tn * p.stats_slab + 2 * (long)m) = t;
                 }
             }
+            }   // (!idle)
         } else
         {   // (the lane id re-made from an opaque value: the epilogue's per-lane addresses are tile-invariant, and hoisted out of the tile
             // loop they would be a dozen registers held across the main loop)
@@ -1357,7 +1425,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
             const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
             wave_epilogue<EPI, VAR == 1, VAR == 2 || VAR == 3, VAR == 3, 1>(p, acc, cur.m0 + wm * 128, cur.n0 + wn * 64,
                                                                               smem + 32768 + grp * 65536 + gw * 8192, lane_e, smem, cur.tn,
-                                                                              smem + STREAM_TAIL + par * TAIL_BYTES, cur.cz);
+                                                                              smem + STREAM_TAIL + par * TAIL_BYTES, cur.cz, HT ? cur.mhi : -1, idle);
         }
         if (p.dbg) {
             unsigned long long t1, t2;
@@ -1377,6 +1445,38 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(BigArgs pin) {
     }
 }
 
+}  // namespace
+
+// Half-height tail: `tiles` 256^2 tiles on `n_cu` resident workgroups = `rounds` complete rounds + a rest.  A rest that fits HALF a round
+// (padded to a multiple of the 8 XCDs) runs as 128-row halves next to each other instead of as one more round of whole tiles on part of the
+// chip.  Measured (tools/r6_gemm_ab.py, same box, whole -> half-height tail; profiles/HISTORY.md §12): a half-height unit takes 0.85-0.9 of a
+// whole tile's time, not 0.5 — a step is as long as its LDS-DMA pieces take to land, whatever the MFMAs under it — so the tail pays where it
+// is a large part of the launch: no complete round (ViT-base at one input, out-projection, 75 tiles: 21.8 -> 19.5 us; fc2 59.6 -> 50.8) or one
+// (fc1 at one input, 300 tiles: 44.5 -> 42.0; the out-projection at four inputs, 297: 44.6 -> 42.9); from two complete rounds on it is
+// within +-1 % (QKV at four inputs 85.6 / 86.0, ViT-large one input x 64 masks 75.6 / 76.1), and the benchmarked fc1 (55 rounds + 104 tiles)
+// loses 1.2 % to it: AG_GEMM_HALFTAIL_ROUNDS = the most complete rounds a launch may have (default 1).  AG_GEMM_HALFTAIL=0: never (A/B,
+// parity tests).
+bool ag_big_half_tail(int tiles, int n_cu, int* half_from, int* ntail, int* grid) {
+    static AgKnob k_ht("AG_GEMM_HALFTAIL"), k_rounds("AG_GEMM_HALFTAIL_ROUNDS");
+    if ((int)k_ht.get(1) == 0 || n_cu < 16 || (n_cu & 7) || tiles <= 0) return false;
+    const int rounds = tiles / n_cu, rest = tiles - rounds * n_cu, pad = (rest + 7) & ~7;
+    if (rest == 0 || 2 * pad > n_cu || rounds > (int)k_rounds.get(1)) return false;
+    *half_from = rounds * n_cu;
+    *ntail = rest;
+    *grid = rounds > 0 ? n_cu : 2 * pad;
+    return true;
+}
+
+static thread_local int g_last_plan[4] = {0, 0, 0, 0};      // {seen, grid, half_from, ntail} of this thread's last launch_stream_var
+extern "C" int ag_gemm_last_plan(int* grid, int* half_from, int* ntail) {
+    if (grid) *grid = g_last_plan[1];
+    if (half_from) *half_from = g_last_plan[2];
+    if (ntail) *ntail = g_last_plan[3];
+    return g_last_plan[0];
+}
+
+namespace {
+
 template <int EPI, int VAR, bool RLDS = false>
 int launch_stream_var(const BigArgs& a, hipStream_t s) {
     if constexpr (!RLDS && EPI == AG_EPI_BIAS_RESID && (VAR == 0 || VAR == 2 || VAR == 3)) {
@@ -1393,10 +1493,16 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return ag_fail(AG_ERR_HIP, "gemm_stream: hipGetDevice");
     if (dev < 0 || dev >= MAX_DEV) return ag_fail(AG_ERR_UNSUPPORTED, "gemm_stream: device index %d", dev);
+    constexpr bool BATCHED = (EPI == AG_EPI_BIAS_F32 && VAR == 0);
     if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
         if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream): %s", hipGetErrorString(e));
+        if constexpr (!BATCHED) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, VAR, RLDS, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_LDS_BYTES);
+            if (e != hipSuccess) return ag_fail(AG_ERR_HIP, "hipFuncSetAttribute(gemm_stream, half-height tail): %s", hipGetErrorString(e));
+        }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ag_fail(AG_ERR_HIP, "gemm_stream: device properties");
         // one resident workgroup per CU; a multiple of the 8 XCDs keeps a workgroup's tiles on its XCD (a partition with fewer than
@@ -1410,7 +1516,19 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
         const int sc = ag_stream_cus(s);
         if (sc > 0 && sc < n_cu) n_cu = sc >= 8 ? (sc & ~7) : sc;
     }
-    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT) * ((EPI == AG_EPI_BIAS_F32 && VAR == 0) ? a.nbatch : 1);
+    const int tiles = ceil_div(a.M, BT) * ceil_div(a.N, BT) * (BATCHED ? a.nbatch : 1);
+    if constexpr (!BATCHED) {
+        // half-height tail (gemm_stream_kernel<..., HT>): an exact row count only (the plan is made from M)
+        int half_from = 0, ntail = 0, hgrid = 0;
+        if (!a.dyn && ag_big_half_tail(tiles, n_cu, &half_from, &ntail, &hgrid)) {
+            BigArgs h = a;
+            h.half_from = half_from; h.ntail = ntail;
+            hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS, true>), dim3(hgrid), dim3(NT), STREAM_LDS_BYTES, s, h);
+            AG_LAUNCH_CHECK();
+            g_last_plan[0] = 1; g_last_plan[1] = hgrid; g_last_plan[2] = half_from; g_last_plan[3] = ntail;
+            return AG_OK;
+        }
+    }
     // resident workgroups: every CU — unless the same number of rounds is done by fewer: 297 tiles are two rounds on 256 CUs (the second with 41
     // busy) and two rounds on 152 (both full), and a tile is faster the fewer CUs share an XCD's L2 feed (the forward confined to 224 / 192 CUs:
     // 7 % / 15 % less time per tile, tools/gemm_cus_sweep.py).  Large launches (14+ rounds) come out at every CU.
@@ -1425,6 +1543,7 @@ int launch_stream_var(const BigArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm_stream_kernel<EPI, VAR, RLDS>), dim3(grid), dim3(NT), STREAM_LDS_BYTES, s, a);
     AG_LAUNCH_CHECK();
+    g_last_plan[0] = 1; g_last_plan[1] = grid; g_last_plan[2] = tiles; g_last_plan[3] = 0;
     return AG_OK;
 }
 

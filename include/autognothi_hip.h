@@ -26,11 +26,12 @@
 extern "C" {
 #endif
 
-#define AG_ABI_VERSION 5   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
+#define AG_ABI_VERSION 6   /* 2: device-side row counts are an explicit `d_rows` argument (was a thread-local mode, ag_dynamic_rows);
                             * 3: ag_gemm_ex + the fused training kernels + ag_gemm_resid_split (additions only);
                             * 4: ag_gemm_ws (additions only);
                             * 5: ag_cls_last_attention_rows (the kernel-level entry of the K / V-free last layer), ag_gemm_ex_group,
-                            *    ag_colsum_bf16_group (additions only) */
+                            *    ag_colsum_bf16_group (additions only);
+                            * 6: ag_gemm_last_plan (a diagnostic; addition only) */
 
 enum { AG_OK = 0, AG_ERR_INVALID = -1, AG_ERR_HIP = -2, AG_ERR_UNSUPPORTED = -3 };
 enum { AG_F32 = 0, AG_BF16 = 1 };
@@ -510,6 +511,11 @@ int ag_masked_attention_bwd_bf16(const void* d_qkv, const uint32_t* d_mask_bits,
 #define AG_PROF_GEMM_EX 10   /* ag_gemm_ex */
 /* number of kernels this library has launched in this process (diagnostics: launches per training step in bench.py). */
 int64_t ag_launch_count(void);
+/* (diagnostic) how the persistent large-M kernel behind ag_gemm / ag_gemm_resid_ln / ag_gemm_ws was last launched by the calling thread:
+ * resident workgroups, the first half-height unit (= the tile count when the launch had no half-height tail) and the number of 256^2
+ * tiles that ran as two 128-row units each in the last round (0: none).  Returns 1 if such a launch happened on this thread, else 0.
+ * The reference has no counterpart (torch picks its GEMM kernels out of sight): parity tests use it to prove which schedule they compared. */
+int ag_gemm_last_plan(int* grid, int* half_from, int* ntail);
 int ag_profile_enable(int on);
 int ag_profile_collect(int kernel_class, double* total_ms, double* total_flops, double* total_bytes, int64_t* launches);
 

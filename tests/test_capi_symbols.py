@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().ag_abi_version() == 5
+    assert _lib.lib().ag_abi_version() == 6
 
 
 def test_product_path_has_no_cpu_fallback():

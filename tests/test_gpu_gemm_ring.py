@@ -449,3 +449,102 @@ def test_whole_line_kernel_equals_the_k32_ring_bit_for_bit(cuda_device, ag_knobs
     for key in line:
         assert torch.equal(line[key], ring[key]), key
     np.testing.assert_allclose(line["bias"].float().cpu().numpy(), ref, **TOL)
+
+
+def _last_plan():
+    import ctypes as C
+    from autognothi_amd import _lib as L
+    g, h, t = C.c_int(), C.c_int(), C.c_int()
+    assert L.lib().ag_gemm_last_plan(C.byref(g), C.byref(h), C.byref(t)) == 1
+    return g.value, h.value, t.value
+
+
+@pytest.mark.parametrize("m,n,k", [
+    (6304, 768, 768),       # ViT-base, one input x 32 masks, out-projection: 75 tiles, none of a complete round: all of them as halves
+    (6304, 3072, 768),      # ... fc1: 300 tiles = one round of 256 + 44 (the last row tile has 160 rows: a ragged UPPER half)
+    (25216, 2304, 768),     # four inputs, QKV: 891 = 3 x 256 + 123
+    (1537, 776, 1024),      # 7 x 4 tiles, the last row tile ONE row high (its upper half is nobody's: the unit leaves at once), ragged N
+    (12608, 3072, 1024),    # ViT-large, one input x 64 masks, QKV: 600 = 2 x 256 + 88
+    (2048, 768, 3072),      # fc2: 24 tiles (tail padded to a multiple of 8: no padding unit here); K = 3 072
+    (1300, 520, 128),       # 18 tiles -> padded to 24: six padding units; two steps per tile
+])
+def test_half_height_tail_is_bit_identical_to_whole_tiles(cuda_device, ag_knobs, m, n, k):
+    """gemm_stream_kernel<..., HT> (csrc/gemm_big.hip): the tiles behind the last complete round run as two 128-row units each, wave group 1
+    idle in them.  Every epilogue of the shipped kernel — bias, GELU, fp32 output is not one (batched form), residual + row statistics through
+    LDS and through registers, LayerNorm-fold consumer, residual-LayerNorm — with the tail on and off: same bits, outputs and statistics; the
+    diagnostic proves which schedule each run took.  (Whole tiles are themselves pinned against the float64 oracle and the ring kernel above.)"""
+    from autognothi_amd import _lib as L, ops
+    g, a, w, b, ref = _case(m, n, k, 11)
+    dev = cuda_device
+    A, W, B = _dev(a, dev), _dev(w, dev), torch.from_numpy(b).to(dev)
+    R = _dev(_r(g.standard_normal((m, n)).astype(np.float32)), dev)
+    st_in = ops.row_stats(A) if k <= 1024 else None
+    colsum = W.float().sum(1).contiguous()
+    gam, bet = torch.from_numpy((1 + 0.1 * g.standard_normal(n)).astype(np.float32)).to(dev), torch.from_numpy((0.1 * g.standard_normal(n)).astype(np.float32)).to(dev)
+    r_st = ops.row_stats(R) if n % 8 == 0 and n <= 1024 else None
+    share = 32 if m % 6304 == 0 else 0                                     # (K masks share an input's residual rows: the register-path epilogue)
+
+    def run_all(expect_tail):
+        out, plans = {}, {}
+
+        def note(key):
+            plans[key] = _last_plan()
+            assert (plans[key][2] > 0) == expect_tail, (key, plans[key])
+
+        out["bias"] = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16); note("bias")
+        out["gelu"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16); note("gelu")
+        st = ops.new_row_stats(m, n, dev)
+        out["resid"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=R, stats_out=st); note("resid")
+        out["resid_stats"] = st
+        out["resid_plain"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=R); note("resid_plain")
+        if st_in is not None:
+            out["fold"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_GELU, BF16, ln_stats=st_in, ln_colsum=colsum, ln_eps=1e-12); note("fold")
+            out["fold_bias"] = ops.gemm(A, W, B, L.AG_EPI_BIAS, BF16, ln_stats=st_in, ln_colsum=colsum, ln_eps=1e-12); note("fold_bias")
+        if share:
+            st3 = ops.new_row_stats(m, n, dev)
+            out["resid_shared"] = ops.gemm(A, W, B, L.AG_EPI_BIAS_RESID, BF16, resid=R[: m // share].contiguous(), rows_per_seq=197, resid_share=share,
+                                           stats_out=st3); note("resid_shared")
+            out["resid_shared_stats"] = st3
+        if r_st is not None:
+            o, s2 = ops.gemm_resid_ln(A, W, B, R, r_st, gam, bet, 1e-12); note("rln")
+            out["rln"], out["rln_stats"] = o, s2
+        torch.cuda.synchronize()
+        return out, plans
+
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1, AG_GEMM_HALFTAIL=1, AG_GEMM_HALFTAIL_ROUNDS=8)
+    half, plans = run_all(True)
+    tiles = -(-m // 256) * -(-n // 256)
+    grid, half_from, ntail = plans["bias"]
+    assert half_from == (tiles // 256) * 256 and ntail == tiles - half_from and grid == (256 if half_from else 2 * ((ntail + 7) // 8 * 8))
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1, AG_GEMM_HALFTAIL=0)
+    whole, _ = run_all(False)
+    assert set(half) == set(whole)
+    for key in half:
+        assert torch.equal(half[key], whole[key]), key
+    np.testing.assert_allclose(half["bias"].float().cpu().numpy(), ref, **TOL)
+
+
+def test_half_height_tail_only_where_it_fits(cuda_device, ag_knobs):
+    """the plan: a rest of more than half a round, an exact multiple of the resident workgroups, a launch of more than
+    AG_GEMM_HALFTAIL_ROUNDS complete rounds (default 1: where the tail was measured to pay) and a device-side row count all keep whole tiles."""
+    from autognothi_amd import _lib as L, ops
+    dev = cuda_device
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1)
+
+    def plan_of(m, n, k=128, **kw):
+        A = torch.zeros((m, k), dtype=torch.bfloat16, device=dev)
+        W = torch.zeros((n, k), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, torch.zeros(n, device=dev), L.AG_EPI_BIAS, BF16, **kw)
+        return _last_plan()
+
+    assert plan_of(4096, 2304)[2] == 0                     # 144 tiles: more than half a round
+    assert plan_of(16384, 1024)[2] == 0                    # 256 tiles: no rest
+    assert plan_of(16384 + 2048, 1024) == (256, 256, 32)   # 288 = 256 + 32: one complete round, the default limit
+    assert plan_of(16384 + 2048, 1024, rows_dev=torch.tensor([18000], dtype=torch.int32, device=dev))[2] == 0     # row count known on the device only
+    assert plan_of(6304, 768, 768) == (160, 0, 75)         # ViT-base, one input: 75 tiles, all as halves (padded to 80 tiles)
+    assert plan_of(25216, 2304)[2] == 0                    # 891 = 3 x 256 + 123: more complete rounds than AG_GEMM_HALFTAIL_ROUNDS (1)
+    big = plan_of(302592, 3072)                            # the benchmarked fc1: 14 184 = 55 x 256 + 104 — a rest that would fit, 55 rounds: whole tiles
+    assert big[2] == 0 and big[0] <= 256
+    ag_knobs(AG_GEMM_BIG_MIN_TILES=1, AG_GEMM_HALFTAIL_ROUNDS=64)
+    assert plan_of(25216, 2304) == (256, 768, 123)
+    assert plan_of(302592, 3072) == (256, 55 * 256, 104)

@@ -12,11 +12,12 @@ shutil.copy(stats, os.path.join(pr, f"{tag}_kernel_stats_{suffix}.csv"))
 summ = json.load(open(os.path.join(go, f"prof_{tag}_summary.json")))
 json.dump(summ, open(os.path.join(pr, f"{tag}_pmc_summary_{suffix}.json"), "w"), indent=1)
 # bench.py kernel labels <- profiled kernel names (bf16 ViT hot path: LN-folded QKV / fc1+GELU, residual GEMMs with row stats)
-names = {"gemm<bias>": "gemm_stream_kernel<0, 1, false>", "gemm<bias+gelu>": "gemm_stream_kernel<1, 1, false>",
-         "gemm<bias+residual>": "gemm_stream_kernel<2, 2, true>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
+# (<EPI, VAR, RLDS, HT>: the whole-tile instantiations, HT = false — the half-height-tail ones only serve launches of at most one round)
+names = {"gemm<bias>": "gemm_stream_kernel<0, 1, false, false>", "gemm<bias+gelu>": "gemm_stream_kernel<1, 1, false, false>",
+         "gemm<bias+residual>": "gemm_stream_kernel<2, 2, true, false>", "layernorm": "layernorm_kernel<unsigned short, unsigned short>"}
 for lab, var in (("gemm<bias>", "0, 1"), ("gemm<bias+gelu>", "1, 1"), ("gemm<bias+residual>", "2, 2")):
     # (AG_GEMM_RLDS=0 / AG_GEMM_STREAM=0 / builds before round 3)
-    for old in (f"gemm_stream_kernel<{var}, false>", f"gemm_stream_kernel<{var}>", f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):
+    for old in (f"gemm_stream_kernel<{var}, true>", f"gemm_stream_kernel<{var}, false>", f"gemm_stream_kernel<{var}>", f"gemm_line_kernel<{var}>", f"gemm_ring_kernel<{var}, false>"):
         if names[lab] not in summ and old in summ:
             names[lab] = old
 attn = [k for k in summ if k.startswith("attn_stream3_kernel")] or [k for k in summ if k.startswith("attn_bf16_kernel")]
@@ -30,8 +31,12 @@ out = {"workload": workload, "batch": batch, "masks": masks, "precision": "bf16"
        "traffic_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
 for label, k in names.items():
     if k in summ:
-        for f in ("traffic_bytes_per_launch", "l2_hit_rate", "mfma_busy_frac"):
-            if f in summ[k]:
-                out[f][label] = summ[k][f]
+        # a class = its whole-tile instantiation + its half-height-tail one (<..., true>: the launches of at most one round, e.g. layer 0's
+        # QKV on the B distinct inputs): the launch-weighted mean over both, i.e. over the same launches as before the tail existed
+        parts = [summ[k]] + ([summ[k[:-len("false>")] + "true>"]] if k.endswith(", false>") and k[:-len("false>")] + "true>" in summ else [])
+        for f, cnt in (("traffic_bytes_per_launch", "FETCH_SIZE"), ("l2_hit_rate", "TCC_HIT_sum"), ("mfma_busy_frac", "SQ_VALU_MFMA_BUSY_CYCLES")):
+            have = [(q[f], q[cnt]["n"]) for q in parts if f in q and cnt in q]
+            if have:
+                out[f][label] = sum(v * n for v, n in have) / sum(n for _, n in have)
 json.dump(out, open(os.path.join(pr, "traffic.json"), "w"), indent=1)
 print(json.dumps(out["traffic_bytes_per_launch"]))
