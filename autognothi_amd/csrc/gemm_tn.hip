@@ -769,10 +769,10 @@ AgWsPlan ag_ws_plan(int M_bound, int N, int K, int64_t lda, int64_t ldc, int64_t
         if (stats_out && !(out_cols_ok & 1)) c.valid = false;
         if (big) {
             const int tiles = ceil_div(M, 256) * ceil_div(N, 256);
-            int hf = 0, nt = 0, hg = 0;
-            // (a half-height last round, gemm_big.hip: 0.88 of a whole one)
-            const double rounds = (!dyn_rows && ag_big_half_tail(tiles, n_cu, &hf, &nt, &hg)) ? tiles / n_cu + 0.88 : (double)ceil_div(tiles, n_cu);
-            c.cost_us = rounds * (ns * c_big + big_epi) + 2.0;
+            // (priced as whole tiles also where the launch will take a half-height last round, gemm_big.hip: with the measured 0.88 of a round
+            // the planner moved ViT-large's 8-mask shard and ViT-base at four inputs off routes that are faster than the model says —
+            // -2.4 % / -0.5 % per step, profiles/HISTORY.md §12; the tail speeds up the launches that were the big kernel's anyway)
+            c.cost_us = ceil_div(tiles, n_cu) * (ns * c_big + big_epi) + 2.0;
         } else {
             const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
             if (t128 < 384) c.cost_us = ceil_div((long)ceil_div(M, 64) * ceil_div(N, 64), 2 * n_cu) * (ns * 0.42 + 4.0) + 2.0;
