@@ -259,7 +259,7 @@ def test_two_stream_epoch_is_safe_after_foreign_streams_and_graphs(cuda_device):
     default forced on: 372 against 510 — while two idle waves on the two streams run perfectly beside each other, so the yes / no probe of
     TrainPartition.arm() cannot see it).  The default is therefore two streams only in a process that imported this package before it
     touched the GPU (_lib.HIP_TOUCHED_BEFORE_IMPORT): in a fresh process that did exactly what round 4 found fatal, the default epoch must
-    not be slower than AG_TRAIN_PARTITION=0 by more than 3 %."""
+    not be slower than AG_TRAIN_PARTITION=0 by more than 5 % (the failure it guards against costs 27 %; the best of two epochs each, run to run ± 1-2 %)."""
     import json
     import subprocess
     import sys
@@ -296,4 +296,4 @@ print(json.dumps(out))
     out = json.loads(r.stdout.strip().splitlines()[-1])
     one, two = max(out["one"]), max(out["two"])
     print(f"one stream {out['one']}, default schedule {out['two']} images/s")
-    assert two >= 0.97 * one, out
+    assert two >= 0.95 * one, out
